@@ -1,0 +1,183 @@
+/* sbr_hip.h — C-ABI of libsbr_hip.so, the MI355X (gfx950) engine behind sbr's
+ * sequence-recommender hot path.
+ *
+ * The reference crate (maciejkula/sbr-rs, mounted at /root/reference) has no FFI: its seam is the
+ * private trait pair SequenceModelParameters / SequenceModel (src/models/sequence_model.rs:14-45)
+ * under the public surface  Hyperparameters::build / fit, OnlineRankingModel, mrr_score and
+ * data::CompressedInteractions.  Each entry point below cites the reference interface it
+ * replaces; INTEGRATION.md shows the `extern "C"` block a maintainer of the Rust crate would add.
+ *
+ * Conventions: opaque handles; every call returns an sbr_status (no exceptions cross the ABI);
+ * the caller owns all host buffers; the library owns device memory until *_destroy; item ids are
+ * u32, CSR user pointers are u64 (reference: usize, src/lib.rs:77-81).  All float data is f32.
+ * Calls on one model are not thread-safe except the const ones (user_representation / predict /
+ * mrr_score), which serialise internally.
+ */
+#ifndef SBR_HIP_H
+#define SBR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: the two reference error enums (src/lib.rs:84-97) + ABI-level errors ------ */
+typedef enum sbr_status {
+    SBR_OK = 0,
+    SBR_ERR_NO_INTERACTIONS = 1,    /* FittingError::NoInteractions      (lib.rs:93-97)  */
+    SBR_ERR_INVALID_PREDICTION = 2, /* PredictionError::InvalidPredictionValue (lib.rs:84-89) */
+    SBR_ERR_INVALID_ARGUMENT = 3,
+    SBR_ERR_UNSUPPORTED = 4,
+    SBR_ERR_NO_DEVICE = 5, /* no gfx950 device / HIP runtime failure: the engine never falls back to CPU */
+    SBR_ERR_HIP = 6,
+    SBR_ERR_OUT_OF_MEMORY = 7
+} sbr_status;
+
+/* ---- enums (src/models/mod.rs:15-41, src/models/lstm.rs:28-35) ------------------------------- */
+typedef enum sbr_model_kind { SBR_MODEL_LSTM_NORMAL = 0, SBR_MODEL_LSTM_COUPLED = 1, SBR_MODEL_EWMA = 2 } sbr_model_kind;
+typedef enum sbr_loss { SBR_LOSS_BPR = 0, SBR_LOSS_HINGE = 1, SBR_LOSS_WARP = 2 } sbr_loss;
+typedef enum sbr_optimizer { SBR_OPT_ADAGRAD = 0, SBR_OPT_ADAM = 1 } sbr_optimizer;
+typedef enum sbr_parallelism { SBR_PAR_ASYNCHRONOUS = 0, SBR_PAR_SYNCHRONOUS = 1 } sbr_parallelism;
+
+/* ---- hyper-parameters: lstm::Hyperparameters (lstm.rs:39-52) / ewma::Hyperparameters
+ * (ewma.rs:45-57).  num_devices plays the role of num_threads (one partition of the shuffled
+ * subsequences per device, sequence_model.rs:91-98); batch_sequences is the GPU minibatch:
+ * that many subsequences are evaluated against one parameter snapshot and their gradients are
+ * summed into one optimiser step (batch_sequences = 1 is the reference's per-sequence SGD). */
+typedef struct sbr_hparams {
+    uint32_t num_items;
+    uint32_t max_sequence_length;
+    uint32_t embedding_dim; /* 16, 32, 64, 128 or 256 */
+    float learning_rate;
+    float l2_penalty;
+    int32_t model;       /* sbr_model_kind */
+    int32_t loss;        /* sbr_loss */
+    int32_t optimizer;   /* sbr_optimizer */
+    int32_t parallelism; /* sbr_parallelism */
+    uint8_t seed[16];    /* XorShiftRng::from_seed (lstm.rs:129-132) */
+    uint32_t num_epochs;
+    uint32_t num_devices;      /* world size; this process drives exactly one device */
+    uint32_t device_rank;      /* 0 <= rank < num_devices */
+    uint32_t batch_sequences;  /* subsequences per optimiser step and device */
+} sbr_hparams;
+
+typedef struct sbr_model sbr_model;
+typedef struct sbr_fit_plan sbr_fit_plan;
+
+/* Parameter blocks for get/set (golden-vector tests, checkpoint/resume: the serde derives at
+ * lstm.rs:204,386 / ewma.rs:208,401).  "*_ACC" are the Adagrad accumulators, which live next to
+ * the value in wyrm's HogwildParameter and persist across fit calls. */
+typedef enum sbr_param {
+    SBR_PARAM_ITEM_EMBEDDING = 0,     /* [num_items][dim]                         */
+    SBR_PARAM_ITEM_EMBEDDING_ACC = 1,
+    SBR_PARAM_ITEM_BIAS = 2,          /* [num_items]                              */
+    SBR_PARAM_ITEM_BIAS_ACC = 3,
+    SBR_PARAM_LSTM_W = 4,             /* [2*dim][gates*dim], rows = [x ; h], column blocks i,f,g,o (coupled: f,g,o) */
+    SBR_PARAM_LSTM_W_ACC = 5,
+    SBR_PARAM_LSTM_B = 6,             /* [gates*dim]                              */
+    SBR_PARAM_LSTM_B_ACC = 7,
+    SBR_PARAM_EWMA_ALPHA = 8,         /* [dim]                                    */
+    SBR_PARAM_EWMA_ALPHA_ACC = 9
+} sbr_param;
+
+/* Per-minibatch intermediates that tests fetch to compare against the oracle. */
+typedef enum sbr_debug_buffer {
+    SBR_DBG_HIDDEN = 0,     /* f32 [R][dim]   h_t (LSTM) / s_t (EWMA), packed time-major rows */
+    SBR_DBG_NEGATIVES = 1,  /* u32 [R]        sampled negative item ids                         */
+    SBR_DBG_COEF = 2,       /* f32 [R]        dloss/dneg                                        */
+    SBR_DBG_LOSS = 3,       /* f32 [R]        loss terms                                        */
+    SBR_DBG_DHIDDEN = 4,    /* f32 [R][dim]   dloss/dh from the scoring step                    */
+    SBR_DBG_DINPUT = 5,     /* f32 [R][dim]   gradient w.r.t. the gathered input embedding      */
+    SBR_DBG_DENSE_GRAD = 6, /* f32 dense grad block: LSTM [2*dim+1][gates*dim] (last row = bias) / EWMA [dim] */
+    SBR_DBG_IN_IDX = 7,     /* u32 [R] */
+    SBR_DBG_OUT_IDX = 8,    /* u32 [R] */
+    SBR_DBG_TRIES = 9       /* u32 [R] number of negatives scored (k of BASELINE.md §4) */
+} sbr_debug_buffer;
+
+/* ≙ Hyperparameters::build (lstm.rs:197-201, ewma.rs:201-205): allocates device parameters and
+ * initialises them from hp->seed (embedding_init lstm.rs:22-25; biases, alpha zero). */
+sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out);
+void sbr_model_destroy(sbr_model* m);
+
+/* ≙ ImplicitLSTMModel::fit / ImplicitEWMAModel::fit (lstm.rs:395-397, ewma.rs:408-410) →
+ * fit_sequence_model (sequence_model.rs:70-178).  CSR = CompressedInteractions
+ * (data.rs:227-234): user_ptr[num_users+1], item_ids[user_ptr[num_users]], time-sorted per user.
+ * Re-callable: every call trains num_epochs more epochs, optimiser state persists.
+ * Returns SBR_ERR_NO_INTERACTIONS when no subsequence of length > 2 exists (:86-88). */
+sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, float* out_loss);
+
+/* The same fit, staged, so a caller (bench.py, the multi-GPU driver) can keep inputs resident in
+ * HBM and time / interleave individual optimiser steps:
+ *   begin          = chunking + shuffle + partition      (sequence_model.rs:76-98)
+ *   epoch_prepare  = per-epoch reshuffle (:109) + packing + upload; returns #minibatches
+ *   step           = one minibatch: forward, negative sampling, loss, BPTT, optimiser (:111-169)
+ *   step_local/step_apply = the two halves of step around the multi-device exchange
+ *   end            = ≙ the fold at :173-177; returns loss_sum / (1 + examples)            */
+sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, sbr_fit_plan** out);
+sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches);
+sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
+sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows);
+sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples);
+void sbr_fit_plan_destroy(sbr_fit_plan* p);
+
+/* Multi-device halves of a step (user-sharded data parallelism, one process per GPU).
+ * step_local leaves this device's contribution in the exchange block; the host all-gathers the
+ * blocks of all devices (RCCL via torch.distributed) into one buffer laid out
+ * [device][exchange_bytes]; step_apply consumes it.  Every device applies the identical update,
+ * so replicas stay bit-identical. */
+sbr_status sbr_fit_exchange_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
+sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_exchange_out);
+sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* device_exchange_all);
+
+/* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
+sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);
+sbr_status sbr_model_synchronize(sbr_model* m);
+
+/* Debug / parity access to the last minibatch processed by sbr_fit_step*. */
+sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, uint64_t bytes);
+
+/* ≙ OnlineRankingModel::user_representation (lib.rs:105-108; impl sequence_model.rs:182-211):
+ * keeps the last max_sequence_length items; empty history = step 0 with item 0. */
+sbr_status sbr_user_representation(sbr_model* m, const uint32_t* item_ids, uint64_t n, float* out_dim);
+/* ≙ OnlineRankingModel::predict (lib.rs:111-115; impl sequence_model.rs:213-232):
+ * out[i] = bias[item_ids[i]] + <user, E[item_ids[i]]>; SBR_ERR_INVALID_PREDICTION if any is non-finite. */
+sbr_status sbr_predict(sbr_model* m, const float* user_dim, const uint32_t* item_ids, uint64_t n, float* out);
+/* ≙ evaluation::mrr_score (evaluation.rs:12-48).  out_ranks (optional) receives one u32 rank per
+ * test user with >= 2 interactions, in user order; out_num_ranked their count. */
+sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, float* out_mrr, uint32_t* out_ranks, uint64_t* out_num_ranked);
+
+/* ≙ the serde derives (lstm.rs:204,386; ewma.rs:208,401): element counts and raw access. */
+sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* out_count);
+sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uint64_t count);
+sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count);
+sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch);
+
+/* Library / device identification ("gfx950", CU count, HBM bytes); device_name may be NULL. */
+sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out_cus, uint64_t* out_hbm_bytes);
+const char* sbr_status_string(sbr_status s);
+uint32_t sbr_abi_version(void);
+
+/* Kernel timing hook for bench.py: wall time (ms, HIP events on the engine stream) and launch
+ * count accumulated per kernel family since the last reset.  Families: see sbr_kernel_family. */
+typedef enum sbr_kernel_family {
+    SBR_K_RECURRENT_FWD = 0,
+    SBR_K_SCORE = 1,       /* gather + negative sampling + loss: the HBM-roofline kernel */
+    SBR_K_RECURRENT_BWD = 2,
+    SBR_K_DENSE_GRAD = 3,
+    SBR_K_DENSE_UPDATE = 4,
+    SBR_K_SPARSE_UPDATE = 5,
+    SBR_K_RANK = 6,
+    SBR_K_FAMILIES = 7
+} sbr_kernel_family;
+sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable);
+sbr_status sbr_model_timing_read(sbr_model* m, double* out_ms /*[SBR_K_FAMILIES]*/, uint64_t* out_launches /*[SBR_K_FAMILIES]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBR_HIP_H */

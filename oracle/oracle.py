@@ -1,0 +1,234 @@
+"""ctypes binding of the CPU oracle (oracle/libsbr_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under sbr_rs_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from sbr_rs_amd._abi import SbrHparams, Status
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsbr_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "sbr_oracle.c")
+    hdr = os.path.join(_HERE, "..", "sbr_rs_amd", "csrc", "sbr_numerics.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libsbr_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, u64p, u32p, fp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        L.orc_model_create.argtypes = [C.POINTER(SbrHparams), C.POINTER(vp)]
+        L.orc_model_destroy.argtypes = [vp]
+        L.orc_model_destroy.restype = None
+        L.orc_model_param_count.argtypes = [vp, C.c_int, u64p]
+        L.orc_model_get_param.argtypes = [vp, C.c_int, vp, C.c_uint64]
+        L.orc_model_set_param.argtypes = [vp, C.c_int, vp, C.c_uint64]
+        L.orc_model_get_epoch.argtypes = [vp]
+        L.orc_model_get_epoch.restype = C.c_uint64
+        L.orc_chunk_lengths.argtypes = [C.c_uint64, C.c_uint64, u64p, C.c_int]
+        L.orc_fit_begin.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+        L.orc_fit_plan_destroy.argtypes = [vp]
+        L.orc_fit_plan_destroy.restype = None
+        L.orc_fit_epoch_prepare.argtypes = [vp, u64p]
+        L.orc_fit_minibatch_rows.argtypes = [vp, C.c_int, C.c_uint64, u64p]
+        L.orc_fit_step_local.argtypes = [vp, C.c_int, C.c_uint64]
+        L.orc_fit_exchange_bytes.argtypes = [vp]
+        L.orc_fit_exchange_bytes.restype = C.c_uint64
+        L.orc_fit_export_local.argtypes = [vp, C.c_int, vp]
+        L.orc_fit_step_apply.argtypes = [vp, vp]
+        L.orc_fit_step.argtypes = [vp, C.c_uint64]
+        L.orc_fit_end.argtypes = [vp, fp, u64p]
+        L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
+        L.orc_model_fit.argtypes = [vp, vp, vp, C.c_uint64, fp]
+        L.orc_user_representation.argtypes = [vp, vp, C.c_uint64, vp]
+        L.orc_predict.argtypes = [vp, vp, vp, C.c_uint64, vp]
+        L.orc_mrr_score.argtypes = [vp, vp, vp, C.c_uint64, fp, vp, u64p]
+        for name in ("orc_expf", "orc_sigmoidf", "orc_tanhf"):
+            getattr(L, name).argtypes = [C.c_float]
+            getattr(L, name).restype = C.c_float
+        for name in ("orc_dot_tree", "orc_dot_chain"):
+            getattr(L, name).argtypes = [vp, vp, C.c_int]
+            getattr(L, name).restype = C.c_float
+        L.orc_neg_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_neg_draw.restype = C.c_uint32
+        L.orc_epoch_key.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_epoch_key.restype = C.c_uint64
+        L.orc_adagrad.argtypes = [fp, fp, C.c_float, C.c_float, C.c_float]
+        L.orc_adagrad.restype = None
+        L.orc_xorshift_stream.argtypes = [vp, vp, C.c_int]
+        L.orc_xorshift_stream.restype = None
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, status):
+        self.status = Status(status)
+        super().__init__(f"oracle status {self.status.name}")
+
+
+def _check(st):
+    if st != 0:
+        raise OracleError(st)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_DBG_DTYPE = {1: np.uint32, 7: np.uint32, 8: np.uint32, 9: np.uint32}
+
+
+class OraclePlan:
+    def __init__(self, model: "OracleModel", user_ptr, item_ids):
+        self.model = model
+        self._up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        self._it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().orc_fit_begin(model._h, _ptr(self._up), _ptr(self._it), len(self._up) - 1, C.byref(h)))
+        self._h = h
+
+    def epoch_prepare(self) -> int:
+        n = C.c_uint64()
+        _check(lib().orc_fit_epoch_prepare(self._h, C.byref(n)))
+        return n.value
+
+    def minibatch_rows(self, mb: int, device: int = 0) -> int:
+        n = C.c_uint64()
+        _check(lib().orc_fit_minibatch_rows(self._h, device, mb, C.byref(n)))
+        return n.value
+
+    def step(self, mb: int):
+        _check(lib().orc_fit_step(self._h, mb))
+
+    def exchange_bytes(self) -> int:
+        return lib().orc_fit_exchange_bytes(self._h)
+
+    def step_local(self, mb: int, device: int = 0) -> np.ndarray:
+        _check(lib().orc_fit_step_local(self._h, device, mb))
+        out = np.zeros(self.exchange_bytes(), dtype=np.uint8)
+        _check(lib().orc_fit_export_local(self._h, device, _ptr(out)))
+        return out
+
+    def step_apply(self, all_blocks: np.ndarray):
+        all_blocks = np.ascontiguousarray(all_blocks, dtype=np.uint8)
+        _check(lib().orc_fit_step_apply(self._h, _ptr(all_blocks)))
+
+    def end(self):
+        loss, ex = C.c_float(), C.c_uint64()
+        _check(lib().orc_fit_end(self._h, C.byref(loss), C.byref(ex)))
+        return loss.value, ex.value
+
+    def debug_fetch(self, which: int, rows: int, device: int = 0) -> np.ndarray:
+        d = self.model.dim
+        which = int(which)
+        if which in (0, 4, 5):
+            out = np.zeros((rows, d), dtype=np.float32)
+        elif which == 6:
+            out = np.zeros(self.model.dense_count(), dtype=np.float32)
+        else:
+            out = np.zeros(rows, dtype=_DBG_DTYPE.get(which, np.float32))
+        _check(lib().orc_fit_debug_fetch(self._h, device, which, _ptr(out), out.nbytes))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().orc_fit_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OracleModel:
+    def __init__(self, hp: SbrHparams):
+        self.hp = hp
+        self.dim = int(hp.embedding_dim)
+        h = C.c_void_p()
+        _check(lib().orc_model_create(C.byref(hp), C.byref(h)))
+        self._h = h
+
+    def dense_count(self) -> int:
+        d = self.dim
+        ng = {0: 4, 1: 3, 2: 0}[int(self.hp.model)]
+        return (2 * d + 1) * ng * d if ng else d
+
+    def param_count(self, which: int) -> int:
+        n = C.c_uint64()
+        _check(lib().orc_model_param_count(self._h, int(which), C.byref(n)))
+        return n.value
+
+    def get_param(self, which: int) -> np.ndarray:
+        out = np.zeros(self.param_count(which), dtype=np.float32)
+        _check(lib().orc_model_get_param(self._h, int(which), _ptr(out), out.size))
+        return out
+
+    def set_param(self, which: int, values: np.ndarray):
+        values = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        _check(lib().orc_model_set_param(self._h, int(which), _ptr(values), values.size))
+
+    def global_epoch(self) -> int:
+        return lib().orc_model_get_epoch(self._h)
+
+    def fit(self, user_ptr, item_ids) -> float:
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        loss = C.c_float()
+        _check(lib().orc_model_fit(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
+        return loss.value
+
+    def fit_begin(self, user_ptr, item_ids) -> OraclePlan:
+        return OraclePlan(self, user_ptr, item_ids)
+
+    def user_representation(self, item_ids) -> np.ndarray:
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        out = np.zeros(self.dim, dtype=np.float32)
+        _check(lib().orc_user_representation(self._h, _ptr(it), it.size, _ptr(out)))
+        return out
+
+    def predict(self, user, item_ids) -> np.ndarray:
+        user = np.ascontiguousarray(user, dtype=np.float32)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        out = np.zeros(it.size, dtype=np.float32)
+        _check(lib().orc_predict(self._h, _ptr(user), _ptr(it), it.size, _ptr(out)))
+        return out
+
+    def mrr_score(self, user_ptr, item_ids):
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        ranks = np.zeros(len(up) - 1, dtype=np.uint32)
+        mrr, n = C.c_float(), C.c_uint64()
+        _check(lib().orc_mrr_score(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(mrr), _ptr(ranks), C.byref(n)))
+        return mrr.value, ranks[: n.value].copy()
+
+    def close(self):
+        if self._h:
+            lib().orc_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,872 @@
+/* sbr_oracle.c — CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C, single-threaded restatement of the sbr-rs sequence-recommender hot path, used only
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the HIP
+ * engine (libsbr_hip.so).  Nothing under sbr_rs_amd/ links, imports or executes this file.
+ *
+ * PARITY STATUS: the reference's arithmetic lives in the un-vendored crates wyrm ^0.9.1
+ * (autodiff, LSTM cell, Adagrad, simd_dot; Cargo.toml:29, feature "fast-math"), rand ^0.5
+ * (XorShiftRng, Uniform, Normal; Cargo.toml:19) and ndarray ^0.11; no Rust toolchain exists in
+ * this image and Cargo.lock is git-ignored, so the reference cannot be built or run here.  The
+ * oracle therefore restates the published algorithms (classic LSTM cell, Adagrad, xorshift128)
+ * and is pinned against everything the reference's own tests hold for this path:
+ *   - exact chunking known-answer test           src/data.rs:629-660   (tests/test_oracle.py)
+ *   - FittingError::NoInteractions               src/models/lstm.rs:522-530
+ *   - the five MovieLens-100K test-MRR lower bounds  lstm.rs:450-520, ewma.rs:463-507
+ *   - split/CSR conservation property            src/data.rs:587-627
+ * No reference test pins a float, an RNG output, a gradient or a rank, so bit-level parity with
+ * the Rust path is UNPINNED ("parity unpinned" in DESIGN.md); parity of the HIP engine is
+ * claimed against this oracle.
+ *
+ * Functions cite the reference lines they follow.  Scalar arithmetic (activations, dot orders,
+ * losses, Adagrad, LSTM cell, negative-draw hash) comes from sbr_rs_amd/csrc/sbr_numerics.h, the
+ * shared contract header, so that device and oracle are bit-comparable.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/sbr_hip.h"
+#include "../sbr_rs_amd/csrc/sbr_numerics.h"
+
+#define ORC_EWMA_CHUNK_SEQS 256
+
+typedef struct orc_model {
+    sbr_hparams hp;
+    int d, ng; /* ng = gate blocks in W: 4 (normal) / 3 (coupled) / 0 (ewma) */
+    float *E, *Eacc, *b, *bacc;
+    float *W, *Wacc, *bW, *bWacc; /* W [2d][ng*d] */
+    float *alpha, *alpha_acc;
+    sbr_xorshift rng;
+    uint64_t global_epoch;
+} orc_model;
+
+typedef struct orc_local { /* one device's view of one minibatch */
+    int R, B, Tm;
+    int* off; /* [Tm+1] */
+    uint32_t *in_idx, *out_idx, *ctr, *neg, *tries;
+    float *coef, *loss;
+    float *H, *C, *G, *dH, *dZ, *dX;
+    float* dense;
+    double loss_sum;
+    uint64_t examples;
+} orc_local;
+
+typedef struct orc_plan {
+    orc_model* m;
+    int ndev;
+    uint64_t nseq_total;
+    uint64_t part_len;   /* subsequences per device partition */
+    uint64_t* seq_start; /* [ndev][part_len] offsets into item_ids */
+    uint32_t* seq_len;
+    sbr_xorshift* part_rng; /* [ndev] */
+    uint64_t* fit_seed;     /* [ndev] */
+    uint32_t* items;        /* copy of item_ids */
+    uint64_t nnz;
+    int Rmax;
+    orc_local* loc; /* [ndev] */
+    double loss_sum;
+    uint64_t examples;
+    uint64_t epochs_prepared;
+    uint64_t epoch_key_epoch;
+} orc_plan;
+
+/* ------------------------------------------------------------------------------------------ */
+static double orc_normal(sbr_xorshift* r, int* have, double* spare) {
+    /* Marsaglia polar; both variates used.  (Reference: rand 0.5 Normal = ziggurat, unpinned.) */
+    if (*have) { *have = 0; return *spare; }
+    for (;;) {
+        double u = 2.0 * sbr_xs_unit(r) - 1.0;
+        double v = 2.0 * sbr_xs_unit(r) - 1.0;
+        double s = u * u + v * v;
+        if (s >= 1.0 || s == 0.0) continue;
+        double f = sqrt(-2.0 * log(s) / s);
+        *spare = v * f;
+        *have = 1;
+        return u * f;
+    }
+}
+
+static int orc_dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
+
+/* ≙ Hyperparameters::build_params (lstm.rs:174-194, ewma.rs:167-198): E ~ N(0,(1/d)^2) drawn
+ * row-major from the model RNG (embedding_init, lstm.rs:22-25), biases 0, alpha 0; then the LSTM
+ * weights from the same RNG (wyrm nn::lstm::Parameters::new — distribution recalled as
+ * xavier_normal with std 1/sqrt(rows) = 1/sqrt(2d)). */
+int orc_model_create(const sbr_hparams* hp, orc_model** out) {
+    if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
+    if (!orc_dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
+        hp->num_devices == 0 || hp->batch_sequences == 0)
+        return SBR_ERR_INVALID_ARGUMENT;
+    if (hp->optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_UNSUPPORTED;
+    orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
+    m->hp = *hp;
+    int d = m->d = (int)hp->embedding_dim;
+    m->ng = hp->model == SBR_MODEL_LSTM_NORMAL ? 4 : hp->model == SBR_MODEL_LSTM_COUPLED ? 3 : 0;
+    size_t I = hp->num_items;
+    m->E = (float*)malloc(I * d * sizeof(float));
+    m->Eacc = (float*)calloc(I * d, sizeof(float));
+    m->b = (float*)calloc(I, sizeof(float));
+    m->bacc = (float*)calloc(I, sizeof(float));
+    sbr_xs_seed(&m->rng, hp->seed);
+    int have = 0;
+    double spare = 0.0;
+    double std_e = 1.0 / (double)d;
+    for (size_t i = 0; i < I * (size_t)d; ++i) m->E[i] = (float)(orc_normal(&m->rng, &have, &spare) * std_e);
+    if (m->ng) {
+        size_t nw = (size_t)2 * d * m->ng * d;
+        m->W = (float*)malloc(nw * sizeof(float));
+        m->Wacc = (float*)calloc(nw, sizeof(float));
+        m->bW = (float*)calloc((size_t)m->ng * d, sizeof(float));
+        m->bWacc = (float*)calloc((size_t)m->ng * d, sizeof(float));
+        double std_w = 1.0 / sqrt(2.0 * d);
+        have = 0;
+        for (size_t i = 0; i < nw; ++i) m->W[i] = (float)(orc_normal(&m->rng, &have, &spare) * std_w);
+    } else {
+        m->alpha = (float*)calloc(d, sizeof(float));
+        m->alpha_acc = (float*)calloc(d, sizeof(float));
+    }
+    *out = m;
+    return SBR_OK;
+}
+
+void orc_model_destroy(orc_model* m) {
+    if (!m) return;
+    free(m->E); free(m->Eacc); free(m->b); free(m->bacc);
+    free(m->W); free(m->Wacc); free(m->bW); free(m->bWacc);
+    free(m->alpha); free(m->alpha_acc);
+    free(m);
+}
+
+static float* orc_param_ptr(orc_model* m, int which, uint64_t* count) {
+    uint64_t I = m->hp.num_items, d = (uint64_t)m->d, ng = (uint64_t)m->ng;
+    switch (which) {
+        case SBR_PARAM_ITEM_EMBEDDING: *count = I * d; return m->E;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: *count = I * d; return m->Eacc;
+        case SBR_PARAM_ITEM_BIAS: *count = I; return m->b;
+        case SBR_PARAM_ITEM_BIAS_ACC: *count = I; return m->bacc;
+        case SBR_PARAM_LSTM_W: *count = 2 * d * ng * d; return m->W;
+        case SBR_PARAM_LSTM_W_ACC: *count = 2 * d * ng * d; return m->Wacc;
+        case SBR_PARAM_LSTM_B: *count = ng * d; return m->bW;
+        case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return m->bWacc;
+        case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return m->alpha;
+        case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return m->alpha_acc;
+    }
+    *count = 0;
+    return NULL;
+}
+int orc_model_param_count(orc_model* m, int which, uint64_t* out) {
+    orc_param_ptr(m, which, out);
+    return SBR_OK;
+}
+int orc_model_get_param(orc_model* m, int which, float* out, uint64_t count) {
+    uint64_t n;
+    float* p = orc_param_ptr(m, which, &n);
+    if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
+    memcpy(out, p, n * sizeof(float));
+    return SBR_OK;
+}
+int orc_model_set_param(orc_model* m, int which, const float* in, uint64_t count) {
+    uint64_t n;
+    float* p = orc_param_ptr(m, which, &n);
+    if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
+    memcpy(p, in, n * sizeof(float));
+    return SBR_OK;
+}
+uint64_t orc_model_get_epoch(orc_model* m) { return m->global_epoch; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* ≙ CompressedInteractionsUserChunkIterator::next (data.rs:406-431): the FIRST chunk is the
+ * short one.  Writes chunk lengths; returns their number. */
+int orc_chunk_lengths(uint64_t user_len, uint64_t chunk_size, uint64_t* out, int max_out) {
+    int n = 0;
+    uint64_t idx = 0;
+    while (idx < user_len) {
+        uint64_t mod = (user_len - idx) % chunk_size;
+        uint64_t cs = mod == 0 ? chunk_size : mod;
+        if (n < max_out) out[n] = cs;
+        ++n;
+        idx += cs;
+    }
+    return n;
+}
+
+/* Fisher-Yates from the end (rand 0.5 Rng::shuffle as recalled) on (start,len) */
+static void orc_shuffle(uint64_t* start, uint32_t* len, uint64_t n, sbr_xorshift* r) {
+    for (uint64_t i = n; i > 1; --i) {
+        uint64_t j = sbr_xs_below(r, i);
+        uint64_t ts = start[i - 1]; start[i - 1] = start[j]; start[j] = ts;
+        uint32_t tl = len[i - 1]; len[i - 1] = len[j]; len[j] = tl;
+    }
+}
+
+static void orc_local_alloc(orc_local* L, int Rmax, int Tmax, int d, int ng) {
+    memset(L, 0, sizeof(*L));
+    L->off = (int*)calloc(Tmax + 1, sizeof(int));
+    L->in_idx = (uint32_t*)calloc(Rmax, 4); L->out_idx = (uint32_t*)calloc(Rmax, 4);
+    L->ctr = (uint32_t*)calloc(Rmax, 4); L->neg = (uint32_t*)calloc(Rmax, 4);
+    L->tries = (uint32_t*)calloc(Rmax, 4);
+    L->coef = (float*)calloc(Rmax, 4); L->loss = (float*)calloc(Rmax, 4);
+    size_t rd = (size_t)Rmax * d;
+    L->H = (float*)calloc(rd, 4); L->dH = (float*)calloc(rd, 4); L->dX = (float*)calloc(rd, 4);
+    if (ng) {
+        L->C = (float*)calloc(rd, 4);
+        L->G = (float*)calloc(rd * 4, 4);
+        L->dZ = (float*)calloc(rd * ng, 4);
+        L->dense = (float*)calloc((size_t)(2 * d + 1) * ng * d, 4);
+    } else {
+        L->dense = (float*)calloc(d, 4);
+    }
+}
+static void orc_local_free(orc_local* L) {
+    free(L->off); free(L->in_idx); free(L->out_idx); free(L->ctr); free(L->neg); free(L->tries);
+    free(L->coef); free(L->loss); free(L->H); free(L->dH); free(L->dX); free(L->C); free(L->G);
+    free(L->dZ); free(L->dense);
+}
+
+/* ≙ fit_sequence_model, set-up part (sequence_model.rs:74-98): subsequences = chunks with
+ * len > 2 (:76-83); shuffle with the model RNG (:84); NoInteractions if empty (:86-88);
+ * num_chunks = len / num_threads, zip drops the remainder (:91-98); one RNG per partition seeded
+ * with 16 bytes from the model RNG (:97). */
+int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                  orc_plan** out) {
+    uint64_t T = m->hp.max_sequence_length;
+    uint64_t nseq = 0;
+    for (uint64_t u = 0; u < num_users; ++u) {
+        uint64_t n = user_ptr[u + 1] - user_ptr[u], idx = 0;
+        while (idx < n) {
+            uint64_t mod = (n - idx) % T, cs = mod == 0 ? T : mod;
+            if (cs > 2) ++nseq;
+            idx += cs;
+        }
+    }
+    if (nseq == 0) return SBR_ERR_NO_INTERACTIONS;
+    uint64_t* start = (uint64_t*)malloc(nseq * 8);
+    uint32_t* len = (uint32_t*)malloc(nseq * 4);
+    uint64_t k = 0;
+    for (uint64_t u = 0; u < num_users; ++u) {
+        uint64_t n = user_ptr[u + 1] - user_ptr[u], idx = 0;
+        while (idx < n) {
+            uint64_t mod = (n - idx) % T, cs = mod == 0 ? T : mod;
+            if (cs > 2) { start[k] = user_ptr[u] + idx; len[k] = (uint32_t)cs; ++k; }
+            idx += cs;
+        }
+    }
+    orc_shuffle(start, len, nseq, &m->rng);
+    int ndev = (int)m->hp.num_devices;
+    uint64_t part = nseq / ndev;
+    if (part == 0) { free(start); free(len); return SBR_ERR_INVALID_ARGUMENT; } /* reference panics (chunks_mut(0)) */
+    orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
+    p->m = m; p->ndev = ndev; p->nseq_total = nseq; p->part_len = part;
+    p->seq_start = start; p->seq_len = len;
+    p->part_rng = (sbr_xorshift*)calloc(ndev, sizeof(sbr_xorshift));
+    p->fit_seed = (uint64_t*)calloc(ndev, 8);
+    for (int q = 0; q < ndev; ++q) {
+        uint8_t seed[16];
+        for (int i = 0; i < 4; ++i) {
+            uint32_t v = sbr_xs_u32(&m->rng);
+            seed[4 * i] = v & 255; seed[4 * i + 1] = (v >> 8) & 255; seed[4 * i + 2] = (v >> 16) & 255; seed[4 * i + 3] = (v >> 24) & 255;
+        }
+        sbr_xs_seed(&p->part_rng[q], seed);
+        p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
+    }
+    p->nnz = user_ptr[num_users];
+    p->items = (uint32_t*)malloc((p->nnz ? p->nnz : 1) * 4);
+    memcpy(p->items, item_ids, p->nnz * 4);
+    p->Rmax = (int)(m->hp.batch_sequences * (T - 1));
+    p->loc = (orc_local*)calloc(ndev, sizeof(orc_local));
+    for (int q = 0; q < ndev; ++q) orc_local_alloc(&p->loc[q], p->Rmax, (int)T, m->d, m->ng);
+    *out = p;
+    return SBR_OK;
+}
+
+void orc_fit_plan_destroy(orc_plan* p) {
+    if (!p) return;
+    for (int q = 0; q < p->ndev; ++q) orc_local_free(&p->loc[q]);
+    free(p->loc); free(p->seq_start); free(p->seq_len); free(p->part_rng); free(p->fit_seed); free(p->items);
+    free(p);
+}
+
+/* ≙ thread_rng.shuffle(partition) at the top of every epoch (sequence_model.rs:109) */
+int orc_fit_epoch_prepare(orc_plan* p, uint64_t* out_num_minibatches) {
+    for (int q = 0; q < p->ndev; ++q)
+        orc_shuffle(p->seq_start + (uint64_t)q * p->part_len, p->seq_len + (uint64_t)q * p->part_len, p->part_len,
+                    &p->part_rng[q]);
+    p->epoch_key_epoch = p->m->global_epoch;
+    p->m->global_epoch += 1;
+    p->epochs_prepared += 1;
+    uint64_t B = p->m->hp.batch_sequences;
+    if (out_num_minibatches) *out_num_minibatches = (p->part_len + B - 1) / B;
+    return SBR_OK;
+}
+
+/* Pack minibatch mb of device q: subsequences [mb*B, min((mb+1)*B, part_len)) of the partition,
+ * ordered by length descending (stable), rows time-major: row(t, b) = off[t] + b.
+ * ≙ the per-step index assignment loop (sequence_model.rs:115-142): in_t = item[t],
+ * out_t = item[t+1] for t = 0..len-2. */
+static void orc_pack(orc_plan* p, int q, uint64_t mb, orc_local* L) {
+    uint64_t B = p->m->hp.batch_sequences, T = p->m->hp.max_sequence_length;
+    uint64_t p0 = mb * B, p1 = p0 + B;
+    if (p1 > p->part_len) p1 = p->part_len;
+    int nb = (int)(p1 - p0);
+    const uint64_t* st = p->seq_start + (uint64_t)q * p->part_len;
+    const uint32_t* ln = p->seq_len + (uint64_t)q * p->part_len;
+    /* stable counting sort by length descending */
+    int* order = (int*)malloc(sizeof(int) * (nb ? nb : 1));
+    int* cnt = (int*)calloc(T + 2, sizeof(int));
+    for (int i = 0; i < nb; ++i) cnt[ln[p0 + i]]++;
+    int* pos = (int*)calloc(T + 2, sizeof(int));
+    int acc = 0;
+    for (int l = (int)T; l >= 0; --l) { pos[l] = acc; acc += cnt[l]; }
+    for (int i = 0; i < nb; ++i) order[pos[ln[p0 + i]]++] = i;
+    int Tm = nb ? (int)ln[p0 + order[0]] - 1 : 0;
+    L->B = nb; L->Tm = Tm;
+    L->off[0] = 0;
+    for (int t = 0; t < Tm; ++t) {
+        int bt = 0;
+        for (int b = 0; b < nb; ++b) if ((int)ln[p0 + order[b]] - 1 > t) bt = b + 1; else break;
+        L->off[t + 1] = L->off[t] + bt;
+    }
+    L->R = L->off[Tm];
+    for (int b = 0; b < nb; ++b) {
+        uint64_t pp = p0 + order[b];
+        int n = (int)ln[pp];
+        for (int t = 0; t < n - 1; ++t) {
+            int r = L->off[t] + b;
+            L->in_idx[r] = p->items[st[pp] + t];
+            L->out_idx[r] = p->items[st[pp] + t + 1];
+            L->ctr[r] = (uint32_t)(pp * T + (uint64_t)t);
+        }
+    }
+    free(order); free(cnt); free(pos);
+}
+
+int orc_fit_minibatch_rows(orc_plan* p, int q, uint64_t mb, uint64_t* out_rows) {
+    uint64_t B = p->m->hp.batch_sequences;
+    uint64_t p0 = mb * B, p1 = p0 + B;
+    if (p1 > p->part_len) p1 = p->part_len;
+    const uint32_t* ln = p->seq_len + (uint64_t)q * p->part_len;
+    uint64_t r = 0;
+    for (uint64_t i = p0; i < p1; ++i) r += ln[i] - 1;
+    *out_rows = r;
+    return SBR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Recurrent forward over the packed minibatch.
+ * LSTM (≙ wyrm nn::lstm Layer::forward, lstm.rs:293-298): z = bW + [x_t ; h_{t-1}] W as a
+ * k-ascending fma chain per output column, h_{-1} = c_{-1} = 0.
+ * EWMA (≙ ewma.rs:302-313): s_0 = E[in_0]; s_t = sig(alpha) * s_{t-1} + (1 - sig(alpha)) * E[in_t]. */
+static void orc_forward(orc_model* m, orc_local* L) {
+    int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
+    if (ng) {
+        int nz = ng * d;
+        float* z = (float*)malloc(sizeof(float) * nz);
+        for (int t = 0; t < L->Tm; ++t) {
+            int bt = L->off[t + 1] - L->off[t];
+            for (int b = 0; b < bt; ++b) {
+                int r = L->off[t] + b;
+                const float* x = m->E + (size_t)L->in_idx[r] * d;
+                const float* hp = t ? L->H + (size_t)(L->off[t - 1] + b) * d : NULL;
+                const float* cp = t ? L->C + (size_t)(L->off[t - 1] + b) * d : NULL;
+                for (int j = 0; j < nz; ++j) z[j] = m->bW[j];
+                for (int k = 0; k < d; ++k) {
+                    float xv = x[k];
+                    const float* w = m->W + (size_t)k * nz;
+                    for (int j = 0; j < nz; ++j) z[j] = sbr_fma(xv, w[j], z[j]);
+                }
+                for (int k = 0; k < d; ++k) {
+                    float hv = hp ? hp[k] : 0.0f;
+                    const float* w = m->W + (size_t)(d + k) * nz;
+                    for (int j = 0; j < nz; ++j) z[j] = sbr_fma(hv, w[j], z[j]);
+                }
+                float* g = L->G + (size_t)r * 4 * d;
+                for (int u = 0; u < d; ++u) {
+                    float zi = coupled ? 0.0f : z[u];
+                    float zf = coupled ? z[u] : z[d + u];
+                    float zg = coupled ? z[d + u] : z[2 * d + u];
+                    float zo = coupled ? z[2 * d + u] : z[3 * d + u];
+                    sbr_lstm_cell_fwd(zi, zf, zg, zo, cp ? cp[u] : 0.0f, coupled, &g[u], &g[d + u], &g[2 * d + u],
+                                      &g[3 * d + u], &L->C[(size_t)r * d + u], &L->H[(size_t)r * d + u]);
+                }
+            }
+        }
+        free(z);
+    } else {
+        for (int t = 0; t < L->Tm; ++t) {
+            int bt = L->off[t + 1] - L->off[t];
+            for (int b = 0; b < bt; ++b) {
+                int r = L->off[t] + b;
+                const float* x = m->E + (size_t)L->in_idx[r] * d;
+                float* s = L->H + (size_t)r * d;
+                if (t == 0) {
+                    for (int k = 0; k < d; ++k) s[k] = x[k];
+                } else {
+                    const float* sp = L->H + (size_t)(L->off[t - 1] + b) * d;
+                    for (int k = 0; k < d; ++k) {
+                        float a = sbr_sigmoidf(m->alpha[k]);
+                        float oma = 1.0f - a;
+                        s[k] = sbr_fma(a, sp[k], oma * x[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ≙ predict_single in training (lstm.rs:338-350): bias + dot, "tree" order */
+static float orc_score_tree(const orc_model* m, const float* h, uint32_t item) {
+    return m->b[item] + sbr_dot_tree(h, m->E + (size_t)item * m->d, m->d);
+}
+
+/* Negative sampling + loss + dloss/dh for every packed row.
+ * ≙ sequence_model.rs:125-141 (negative choice), sample_warp_negative (:47-68), the loss nodes
+ * (lstm.rs:300-320) and the dot-node backward into h. */
+static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
+    int d = m->d;
+    uint32_t I = m->hp.num_items;
+    L->loss_sum = 0.0;
+    for (int r = 0; r < L->R; ++r) {
+        const float* h = L->H + (size_t)r * d;
+        uint32_t pi = L->out_idx[r];
+        float pos = orc_score_tree(m, h, pi);
+        uint32_t nj = 0;
+        float neg = 0.0f;
+        uint32_t tries = 0;
+        int max_tries = m->hp.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+        for (int k = 0; k < max_tries; ++k) {
+            nj = sbr_neg_draw(epoch_key, L->ctr[r], (uint32_t)k, I);
+            neg = orc_score_tree(m, h, nj);
+            ++tries;
+            if (sbr_warp_violates(pos, neg)) break;
+        }
+        float g, l;
+        if (m->hp.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g); else l = sbr_loss_hinge(pos, neg, &g);
+        L->neg[r] = nj; L->tries[r] = tries; L->coef[r] = g; L->loss[r] = l;
+        L->loss_sum += (double)l;
+        const float* en = m->E + (size_t)nj * d;
+        const float* ep = m->E + (size_t)pi * d;
+        float* dh = L->dH + (size_t)r * d;
+        for (int k = 0; k < d; ++k) dh[k] = g * en[k] - g * ep[k];
+    }
+    L->examples = (uint64_t)L->R;
+}
+
+/* BPTT (≙ loss.backward(1.0), sequence_model.rs:161) + dense gradient of this device.
+ * Dense reduction order: packed rows are cut into chunks of SBR_DW_CHUNK_ROWS; inside a chunk a
+ * row-ascending fma chain from 0; chunk partials added in chunk order. */
+static void orc_backward(orc_model* m, orc_local* L) {
+    int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
+    if (ng) {
+        int nz = ng * d;
+        float* dh_rec = (float*)calloc((size_t)L->B * d, 4);
+        float* dc_rec = (float*)calloc((size_t)L->B * d, 4);
+        float* dxh = (float*)malloc(sizeof(float) * 2 * d);
+        /* W^T so the j-chain runs over contiguous memory */
+        float* WT = (float*)malloc(sizeof(float) * (size_t)2 * d * nz);
+        for (int k = 0; k < 2 * d; ++k) for (int j = 0; j < nz; ++j) WT[(size_t)j * 2 * d + k] = m->W[(size_t)k * nz + j];
+        for (int t = L->Tm - 1; t >= 0; --t) {
+            int bt = L->off[t + 1] - L->off[t];
+            int bnext = t + 1 < L->Tm ? L->off[t + 2] - L->off[t + 1] : 0;
+            for (int b = 0; b < bt; ++b) {
+                int r = L->off[t] + b;
+                int last = b >= bnext;
+                const float* g = L->G + (size_t)r * 4 * d;
+                const float* cp = t ? L->C + (size_t)(L->off[t - 1] + b) * d : NULL;
+                float* dz = L->dZ + (size_t)r * nz;
+                for (int u = 0; u < d; ++u) {
+                    float dh = L->dH[(size_t)r * d + u] + (last ? 0.0f : dh_rec[(size_t)b * d + u]);
+                    float dzi, dzf, dzg, dzo, dco;
+                    sbr_lstm_cell_bwd(dh, last ? 0.0f : dc_rec[(size_t)b * d + u], g[u], g[d + u], g[2 * d + u],
+                                      g[3 * d + u], L->C[(size_t)r * d + u], cp ? cp[u] : 0.0f, coupled, &dzi, &dzf,
+                                      &dzg, &dzo, &dco);
+                    dc_rec[(size_t)b * d + u] = dco;
+                    if (coupled) { dz[u] = dzf; dz[d + u] = dzg; dz[2 * d + u] = dzo; }
+                    else { dz[u] = dzi; dz[d + u] = dzf; dz[2 * d + u] = dzg; dz[3 * d + u] = dzo; }
+                }
+                /* dxh[k] = chain_j fma(dz[j], W[k][j], acc), acc0 = 0 */
+                for (int k = 0; k < 2 * d; ++k) dxh[k] = 0.0f;
+                for (int j = 0; j < nz; ++j) {
+                    float dv = dz[j];
+                    const float* w = WT + (size_t)j * 2 * d;
+                    for (int k = 0; k < 2 * d; ++k) dxh[k] = sbr_fma(dv, w[k], dxh[k]);
+                }
+                for (int k = 0; k < d; ++k) L->dX[(size_t)r * d + k] = dxh[k];
+                for (int k = 0; k < d; ++k) dh_rec[(size_t)b * d + k] = dxh[d + k];
+            }
+        }
+        /* dense: dW[k][j] = sum_r xh[r][k] dz[r][j]; row 2d = bias grad = sum_r dz[r][j] */
+        size_t nd = (size_t)(2 * d + 1) * nz;
+        float* part = (float*)malloc(sizeof(float) * nd);
+        for (size_t i = 0; i < nd; ++i) L->dense[i] = 0.0f;
+        int nchunks = (L->R + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
+        /* row -> (t, b) lookup */
+        int* row_t = (int*)malloc(sizeof(int) * (L->R ? L->R : 1));
+        for (int t = 0; t < L->Tm; ++t) for (int r = L->off[t]; r < L->off[t + 1]; ++r) row_t[r] = t;
+        for (int c = 0; c < nchunks; ++c) {
+            int r0 = c * SBR_DW_CHUNK_ROWS, r1 = r0 + SBR_DW_CHUNK_ROWS;
+            if (r1 > L->R) r1 = L->R;
+            for (size_t i = 0; i < nd; ++i) part[i] = 0.0f;
+            for (int r = r0; r < r1; ++r) {
+                int t = row_t[r], b = r - L->off[t];
+                const float* x = m->E + (size_t)L->in_idx[r] * d;
+                const float* hp = t ? L->H + (size_t)(L->off[t - 1] + b) * d : NULL;
+                const float* dz = L->dZ + (size_t)r * nz;
+                for (int k = 0; k < d; ++k) {
+                    float xv = x[k];
+                    float* pr = part + (size_t)k * nz;
+                    for (int j = 0; j < nz; ++j) pr[j] = sbr_fma(xv, dz[j], pr[j]);
+                }
+                for (int k = 0; k < d; ++k) {
+                    float hv = hp ? hp[k] : 0.0f;
+                    float* pr = part + (size_t)(d + k) * nz;
+                    for (int j = 0; j < nz; ++j) pr[j] = sbr_fma(hv, dz[j], pr[j]);
+                }
+                float* pb = part + (size_t)2 * d * nz;
+                for (int j = 0; j < nz; ++j) pb[j] = pb[j] + dz[j];
+            }
+            if (c == 0) for (size_t i = 0; i < nd; ++i) L->dense[i] = part[i];
+            else for (size_t i = 0; i < nd; ++i) L->dense[i] = L->dense[i] + part[i];
+        }
+        free(row_t); free(part); free(WT); free(dxh); free(dh_rec); free(dc_rec);
+    } else {
+        /* EWMA: ds_t = dH_t + a*ds_{t+1}; dX_t = (1-a)*ds_t (t>0) / ds_0; per-sequence partial
+         * da_b = chain over t descending of fma(ds_t, s_{t-1} - x_t, .); sequences reduced in
+         * chunks of ORC_EWMA_CHUNK_SEQS (chain inside, chain across); times a(1-a). */
+        float* carry = (float*)calloc((size_t)L->B * d, 4);
+        float* dab = (float*)calloc((size_t)L->B * d, 4);
+        float* av = (float*)malloc(sizeof(float) * d);
+        for (int k = 0; k < d; ++k) av[k] = sbr_sigmoidf(m->alpha[k]);
+        for (int t = L->Tm - 1; t >= 0; --t) {
+            int bt = L->off[t + 1] - L->off[t];
+            int bnext = t + 1 < L->Tm ? L->off[t + 2] - L->off[t + 1] : 0;
+            for (int b = 0; b < bt; ++b) {
+                int r = L->off[t] + b;
+                int last = b >= bnext;
+                const float* x = m->E + (size_t)L->in_idx[r] * d;
+                const float* sp = t ? L->H + (size_t)(L->off[t - 1] + b) * d : NULL;
+                for (int k = 0; k < d; ++k) {
+                    float ds = L->dH[(size_t)r * d + k] + (last ? 0.0f : carry[(size_t)b * d + k]);
+                    if (t > 0) {
+                        float a = av[k], oma = 1.0f - a;
+                        L->dX[(size_t)r * d + k] = oma * ds;
+                        carry[(size_t)b * d + k] = a * ds;
+                        dab[(size_t)b * d + k] = sbr_fma(ds, sp[k] - x[k], dab[(size_t)b * d + k]);
+                    } else {
+                        L->dX[(size_t)r * d + k] = ds;
+                    }
+                }
+            }
+        }
+        int nchunks = (L->B + ORC_EWMA_CHUNK_SEQS - 1) / ORC_EWMA_CHUNK_SEQS;
+        for (int k = 0; k < d; ++k) {
+            float tot = 0.0f;
+            for (int c = 0; c < nchunks; ++c) {
+                int b0 = c * ORC_EWMA_CHUNK_SEQS, b1 = b0 + ORC_EWMA_CHUNK_SEQS;
+                if (b1 > L->B) b1 = L->B;
+                float pc = 0.0f;
+                for (int b = b0; b < b1; ++b) pc = pc + dab[(size_t)b * d + k];
+                tot = c == 0 ? pc : tot + pc;
+            }
+            float a = av[k];
+            L->dense[k] = tot * (a * (1.0f - a));
+        }
+        free(carry); free(dab); free(av);
+    }
+}
+
+int orc_fit_step_local(orc_plan* p, int q, uint64_t mb) {
+    orc_local* L = &p->loc[q];
+    orc_pack(p, q, mb, L);
+    orc_forward(p->m, L);
+    orc_score(p->m, L, sbr_epoch_key(p->fit_seed[q], p->epoch_key_epoch));
+    orc_backward(p->m, L);
+    return SBR_OK;
+}
+
+/* ---- exchange block: what one device contributes to an optimiser step --------------------- */
+/* layout (all 4-byte words unless noted), Rmax = batch_sequences*(T-1):
+ *   [0]      u32 R
+ *   [1..3]   pad
+ *   [4..5]   f64 loss_sum     [6..7] u64 examples
+ *   in_idx[Rmax] out_idx[Rmax] neg[Rmax] coef[Rmax]  H[Rmax*d] dX[Rmax*d]  dense[ndense]  */
+static uint64_t orc_ndense(const orc_model* m) {
+    return m->ng ? (uint64_t)(2 * m->d + 1) * m->ng * m->d : (uint64_t)m->d;
+}
+uint64_t orc_fit_exchange_bytes(orc_plan* p) {
+    uint64_t R = (uint64_t)p->Rmax, d = (uint64_t)p->m->d;
+    uint64_t words = 8 + 4 * R + 2 * R * d + orc_ndense(p->m);
+    return ((words * 4 + 15) / 16) * 16;
+}
+int orc_fit_export_local(orc_plan* p, int q, void* out) {
+    orc_local* L = &p->loc[q];
+    uint64_t R = (uint64_t)p->Rmax, d = (uint64_t)p->m->d;
+    uint32_t* w = (uint32_t*)out;
+    memset(out, 0, orc_fit_exchange_bytes(p));
+    w[0] = (uint32_t)L->R;
+    memcpy(w + 4, &L->loss_sum, 8);
+    memcpy(w + 6, &L->examples, 8);
+    uint32_t* q0 = w + 8;
+    memcpy(q0, L->in_idx, (size_t)L->R * 4); q0 += R;
+    memcpy(q0, L->out_idx, (size_t)L->R * 4); q0 += R;
+    memcpy(q0, L->neg, (size_t)L->R * 4); q0 += R;
+    memcpy(q0, L->coef, (size_t)L->R * 4); q0 += R;
+    memcpy(q0, L->H, (size_t)L->R * d * 4); q0 += R * d;
+    memcpy(q0, L->dX, (size_t)L->R * d * 4); q0 += R * d;
+    memcpy(q0, L->dense, orc_ndense(p->m) * 4);
+    return SBR_OK;
+}
+
+typedef struct { uint32_t row; uint32_t src; } orc_entry; /* src = device*3*Rmax + 3*r + kind */
+static int orc_entry_cmp(const void* a, const void* b) {
+    const orc_entry* x = (const orc_entry*)a; const orc_entry* y = (const orc_entry*)b;
+    if (x->row != y->row) return x->row < y->row ? -1 : 1;
+    if (x->src != y->src) return x->src < y->src ? -1 : 1;
+    return 0;
+}
+
+/* Optimiser step from the gathered exchange blocks of all devices
+ * (≙ optimizer.step / sync_optim.step, sequence_model.rs:163-169; wyrm Adagrad as recalled):
+ *  dense: gradients of the devices added in device order, then Adagrad on every element;
+ *  sparse: every (row, source) entry — input row with dX, target row with -g*h, negative row
+ *  with +g*h — sorted by (row, device, packed row, kind); duplicates added in that order; one
+ *  Adagrad update (with L2) per touched row, also for rows whose summed data-gradient is zero
+ *  (SURVEY App. A-14); biases likewise for target/negative rows. */
+int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
+    orc_model* m = p->m;
+    int d = m->d, ndev = p->ndev;
+    uint64_t Rmax = (uint64_t)p->Rmax, bytes = orc_fit_exchange_bytes(p), nd = orc_ndense(m);
+    float lr = m->hp.learning_rate, l2 = m->hp.l2_penalty;
+    /* dense */
+    float* dg = (float*)malloc(nd * 4);
+    uint64_t total_entries = 0;
+    for (int q = 0; q < ndev; ++q) {
+        const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
+        const float* dense = (const float*)(w + 8 + 4 * Rmax + 2 * Rmax * (uint64_t)d);
+        if (q == 0) memcpy(dg, dense, nd * 4); else for (uint64_t i = 0; i < nd; ++i) dg[i] = dg[i] + dense[i];
+        total_entries += 3ull * w[0];
+        double ls; uint64_t ex;
+        memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
+        p->loss_sum += ls; p->examples += ex;
+    }
+    if (m->ng) {
+        int nz = m->ng * d;
+        for (size_t i = 0; i < (size_t)2 * d * nz; ++i) sbr_adagrad(&m->W[i], &m->Wacc[i], dg[i], lr, l2);
+        for (int j = 0; j < nz; ++j) sbr_adagrad(&m->bW[j], &m->bWacc[j], dg[(size_t)2 * d * nz + j], lr, l2);
+    } else {
+        for (int k = 0; k < d; ++k) sbr_adagrad(&m->alpha[k], &m->alpha_acc[k], dg[k], lr, l2);
+    }
+    free(dg);
+    /* sparse */
+    orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (total_entries ? total_entries : 1));
+    uint64_t ne = 0;
+    for (int q = 0; q < ndev; ++q) {
+        const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
+        uint32_t R = w[0];
+        const uint32_t* in_idx = w + 8; const uint32_t* out_idx = in_idx + Rmax; const uint32_t* neg = out_idx + Rmax;
+        for (uint32_t r = 0; r < R; ++r) {
+            uint32_t base = (uint32_t)((uint64_t)q * 3 * Rmax + 3ull * r);
+            ent[ne].row = in_idx[r]; ent[ne].src = base; ++ne;
+            ent[ne].row = out_idx[r]; ent[ne].src = base + 1; ++ne;
+            ent[ne].row = neg[r]; ent[ne].src = base + 2; ++ne;
+        }
+    }
+    qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
+    float* gsum = (float*)malloc(sizeof(float) * d);
+    uint64_t i = 0;
+    while (i < ne) {
+        uint32_t row = ent[i].row;
+        float gb = 0.0f; int has_b = 0, first = 1;
+        uint64_t j = i;
+        for (; j < ne && ent[j].row == row; ++j) {
+            uint32_t src = ent[j].src;
+            uint32_t q = (uint32_t)(src / (3 * Rmax)), rem = (uint32_t)(src % (3 * Rmax)), r = rem / 3, kind = rem % 3;
+            const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
+            const float* coef = (const float*)(w + 8 + 3 * Rmax);
+            const float* H = (const float*)(w + 8 + 4 * Rmax);
+            const float* dX = H + Rmax * (uint64_t)d;
+            const float* srcv = kind == 0 ? dX + (size_t)r * d : H + (size_t)r * d;
+            float scale = kind == 0 ? 1.0f : kind == 1 ? -coef[r] : coef[r];
+            if (first) { for (int k = 0; k < d; ++k) gsum[k] = scale * srcv[k]; first = 0; }
+            else for (int k = 0; k < d; ++k) gsum[k] = gsum[k] + scale * srcv[k];
+            if (kind != 0) { gb = has_b ? gb + scale : scale; has_b = 1; }
+        }
+        float* wrow = m->E + (size_t)row * d; float* arow = m->Eacc + (size_t)row * d;
+        for (int k = 0; k < d; ++k) sbr_adagrad(&wrow[k], &arow[k], gsum[k], lr, l2);
+        if (has_b) sbr_adagrad(&m->b[row], &m->bacc[row], gb, lr, l2);
+        i = j;
+    }
+    free(gsum); free(ent);
+    return SBR_OK;
+}
+
+/* One full optimiser step, all devices emulated in this process. */
+int orc_fit_step(orc_plan* p, uint64_t mb) {
+    uint64_t bytes = orc_fit_exchange_bytes(p);
+    char* all = (char*)malloc(bytes * p->ndev);
+    for (int q = 0; q < p->ndev; ++q) {
+        orc_fit_step_local(p, q, mb);
+        orc_fit_export_local(p, q, all + (size_t)q * bytes);
+    }
+    int st = orc_fit_step_apply(p, all);
+    free(all);
+    return st;
+}
+
+int orc_fit_end(orc_plan* p, float* out_loss, uint64_t* out_examples) {
+    /* ≙ loss_value / (1.0 + examples) (sequence_model.rs:173).  The reference reads a stale node
+     * value (:157 before :160); the engine reports the true summed loss. */
+    if (out_loss) *out_loss = (float)(p->loss_sum / (1.0 + (double)p->examples));
+    if (out_examples) *out_examples = p->examples;
+    return SBR_OK;
+}
+
+int orc_fit_debug_fetch(orc_plan* p, int q, int which, void* out, uint64_t bytes) {
+    orc_local* L = &p->loc[q];
+    uint64_t R = (uint64_t)L->R, d = (uint64_t)p->m->d;
+    const void* src = NULL; uint64_t n = 0;
+    switch (which) {
+        case SBR_DBG_HIDDEN: src = L->H; n = R * d * 4; break;
+        case SBR_DBG_NEGATIVES: src = L->neg; n = R * 4; break;
+        case SBR_DBG_COEF: src = L->coef; n = R * 4; break;
+        case SBR_DBG_LOSS: src = L->loss; n = R * 4; break;
+        case SBR_DBG_DHIDDEN: src = L->dH; n = R * d * 4; break;
+        case SBR_DBG_DINPUT: src = L->dX; n = R * d * 4; break;
+        case SBR_DBG_DENSE_GRAD: src = L->dense; n = orc_ndense(p->m) * 4; break;
+        case SBR_DBG_IN_IDX: src = L->in_idx; n = R * 4; break;
+        case SBR_DBG_OUT_IDX: src = L->out_idx; n = R * 4; break;
+        case SBR_DBG_TRIES: src = L->tries; n = R * 4; break;
+        default: return SBR_ERR_INVALID_ARGUMENT;
+    }
+    if (bytes < n) return SBR_ERR_INVALID_ARGUMENT;
+    memcpy(out, src, n);
+    return SBR_OK;
+}
+
+/* ≙ fit_sequence_model (sequence_model.rs:70-178), whole call */
+int orc_model_fit(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                  float* out_loss) {
+    orc_plan* p = NULL;
+    int st = orc_fit_begin(m, user_ptr, item_ids, num_users, &p);
+    if (st != SBR_OK) return st;
+    for (uint32_t e = 0; e < m->hp.num_epochs; ++e) {
+        uint64_t nmb = 0;
+        orc_fit_epoch_prepare(p, &nmb);
+        for (uint64_t mb = 0; mb < nmb; ++mb) orc_fit_step(p, mb);
+    }
+    orc_fit_end(p, out_loss, NULL);
+    orc_fit_plan_destroy(p);
+    return SBR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ≙ user_representation (sequence_model.rs:182-211): last T items; empty history = one step
+ * with the default index 0 (IndexInputNode::new(&[0;1]), lstm.rs:262-264). */
+int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, float* out) {
+    int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
+    uint64_t T = m->hp.max_sequence_length;
+    uint32_t zero = 0;
+    if (n > T) { item_ids += n - T; n = T; }
+    if (n == 0) { item_ids = &zero; n = 1; }
+    for (uint64_t t = 0; t < n; ++t) if (item_ids[t] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+    if (ng) {
+        int nz = ng * d;
+        float* z = (float*)malloc(sizeof(float) * nz);
+        float* h = (float*)calloc(d, 4); float* c = (float*)calloc(d, 4);
+        float* hn = (float*)calloc(d, 4);
+        for (uint64_t t = 0; t < n; ++t) {
+            const float* x = m->E + (size_t)item_ids[t] * d;
+            for (int j = 0; j < nz; ++j) z[j] = m->bW[j];
+            for (int k = 0; k < d; ++k) { float xv = x[k]; const float* w = m->W + (size_t)k * nz; for (int j = 0; j < nz; ++j) z[j] = sbr_fma(xv, w[j], z[j]); }
+            for (int k = 0; k < d; ++k) { float hv = h[k]; const float* w = m->W + (size_t)(d + k) * nz; for (int j = 0; j < nz; ++j) z[j] = sbr_fma(hv, w[j], z[j]); }
+            for (int u = 0; u < d; ++u) {
+                float gi, gf, gg, go, cc, hh;
+                float zi = coupled ? 0.0f : z[u];
+                float zf = coupled ? z[u] : z[d + u];
+                float zg = coupled ? z[d + u] : z[2 * d + u];
+                float zo = coupled ? z[2 * d + u] : z[3 * d + u];
+                sbr_lstm_cell_fwd(zi, zf, zg, zo, c[u], coupled, &gi, &gf, &gg, &go, &cc, &hh);
+                c[u] = cc; hn[u] = hh;
+            }
+            memcpy(h, hn, sizeof(float) * d);
+        }
+        memcpy(out, h, sizeof(float) * d);
+        free(z); free(h); free(c); free(hn);
+    } else {
+        for (int k = 0; k < d; ++k) out[k] = m->E[(size_t)item_ids[0] * d + k];
+        for (uint64_t t = 1; t < n; ++t) {
+            const float* x = m->E + (size_t)item_ids[t] * d;
+            for (int k = 0; k < d; ++k) {
+                float a = sbr_sigmoidf(m->alpha[k]);
+                float oma = 1.0f - a;
+                out[k] = sbr_fma(a, out[k], oma * x[k]);
+            }
+        }
+    }
+    return SBR_OK;
+}
+
+/* ≙ predict (sequence_model.rs:213-232): bias + dot ("chain" order); non-finite fails the call */
+int orc_predict(orc_model* m, const float* user, const uint32_t* item_ids, uint64_t n, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+        float s = m->b[item_ids[i]] + sbr_dot_chain(user, m->E + (size_t)item_ids[i] * m->d, m->d);
+        if (!isfinite(s)) return SBR_ERR_INVALID_PREDICTION;
+        out[i] = s;
+    }
+    return SBR_OK;
+}
+
+/* ≙ mrr_score (evaluation.rs:12-48) */
+int orc_mrr_score(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                  float* out_mrr, uint32_t* out_ranks, uint64_t* out_num_ranked) {
+    uint32_t I = m->hp.num_items;
+    float* pred = (float*)malloc(sizeof(float) * I);
+    float* rep = (float*)malloc(sizeof(float) * m->d);
+    uint32_t* all = (uint32_t*)malloc(sizeof(uint32_t) * I);
+    for (uint32_t i = 0; i < I; ++i) all[i] = i;
+    float sum = 0.0f;
+    uint64_t cnt = 0;
+    int st = SBR_OK;
+    for (uint64_t u = 0; u < num_users && st == SBR_OK; ++u) {
+        uint64_t n = user_ptr[u + 1] - user_ptr[u];
+        if (n < 2) continue; /* evaluation.rs:20 */
+        const uint32_t* it = item_ids + user_ptr[u];
+        uint32_t test_item = it[n - 1];
+        st = orc_user_representation(m, it, n - 1, rep);
+        if (st != SBR_OK) break;
+        st = orc_predict(m, rep, all, I, pred);
+        if (st != SBR_OK) break;
+        for (uint64_t t = 0; t + 1 < n; ++t) pred[it[t]] = SBR_F32_MIN; /* :30-32, ALL history items */
+        float ts = pred[test_item];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < I; ++i) if (pred[i] >= ts) ++rank; /* :37-41 */
+        if (out_ranks) out_ranks[cnt] = rank;
+        sum += 1.0f / (float)rank; /* :43, :47 sequential f32 sum */
+        ++cnt;
+    }
+    free(pred); free(rep); free(all);
+    if (st != SBR_OK) return st;
+    if (out_num_ranked) *out_num_ranked = cnt;
+    if (out_mrr) *out_mrr = sum / (float)cnt;
+    return SBR_OK;
+}
+
+/* ---- scalar primitives exported for unit tests --------------------------------------------- */
+float orc_expf(float x) { return sbr_expf(x); }
+float orc_sigmoidf(float x) { return sbr_sigmoidf(x); }
+float orc_tanhf(float x) { return sbr_tanhf(x); }
+float orc_dot_tree(const float* x, const float* y, int d) { return sbr_dot_tree(x, y, d); }
+float orc_dot_chain(const float* x, const float* y, int d) { return sbr_dot_chain(x, y, d); }
+uint32_t orc_neg_draw(uint64_t epoch_key, uint32_t ctr, uint32_t try_idx, uint32_t num_items) {
+    return sbr_neg_draw(epoch_key, ctr, try_idx, num_items);
+}
+uint64_t orc_epoch_key(uint64_t fit_seed, uint64_t epoch) { return sbr_epoch_key(fit_seed, epoch); }
+void orc_adagrad(float* w, float* G, float g, float lr, float l2) { sbr_adagrad(w, G, g, lr, l2); }
+void orc_xorshift_stream(const uint8_t seed[16], uint32_t* out, int n) {
+    sbr_xorshift r;
+    sbr_xs_seed(&r, seed);
+    for (int i = 0; i < n; ++i) out[i] = sbr_xs_u32(&r);
+}

@@ -75,6 +75,8 @@ def lib():
         L.orc_adagrad.restype = None
         L.orc_xorshift_stream.argtypes = [vp, vp, C.c_int]
         L.orc_xorshift_stream.restype = None
+        L.orc_fma_chain_gemm.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_fma_chain_gemm.restype = None
         _lib = L
     return _lib
 
@@ -232,3 +234,17 @@ class OracleModel:
             self.close()
         except Exception:
             pass
+
+
+def fma_chain_gemm(a: np.ndarray, b: np.ndarray, c0=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    M, K = a.shape
+    N = b.shape[1]
+    out = np.zeros((M, N), dtype=np.float32)
+    c0p = None
+    if c0 is not None:
+        c0 = np.ascontiguousarray(c0, dtype=np.float32)
+        c0p = _ptr(c0)
+    lib().orc_fma_chain_gemm(_ptr(a), _ptr(b), c0p, M, K, N, _ptr(out))
+    return out

@@ -870,3 +870,13 @@ void orc_xorshift_stream(const uint8_t seed[16], uint32_t* out, int n) {
     sbr_xs_seed(&r, seed);
     for (int i = 0; i < n; ++i) out[i] = sbr_xs_u32(&r);
 }
+/* out[M][N] = k-ascending fma chain seeded with c0 (NULL = 0): what an f32 MFMA accumulation
+ * computes; used by tests/test_numerics_gpu.py to pin the "MFMA == fmaf chain" premise. */
+void orc_fma_chain_gemm(const float* a, const float* b, const float* c0, int M, int K, int N, float* out) {
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            float acc = c0 ? c0[i * N + j] : 0.0f;
+            for (int k = 0; k < K; ++k) acc = sbr_fma(a[i * K + k], b[k * N + j], acc);
+            out[i * N + j] = acc;
+        }
+}

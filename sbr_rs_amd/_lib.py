@@ -1,0 +1,85 @@
+"""Loader of libsbr_hip.so (the gfx950 engine).  There is no CPU fallback: if the library is
+missing or no HIP device is visible, the engine raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._abi import ABI_VERSION, SbrHparams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbr_hip.so")
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    """libsbr_hip.so cannot be loaded (not built) — the product path never falls back to CPU."""
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -m sbr_rs_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64p, u32p, fp = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    sig = {
+        "sbr_model_create": [C.POINTER(SbrHparams), C.POINTER(vp)],
+        "sbr_model_fit": [vp, vp, vp, C.c_uint64, fp],
+        "sbr_fit_begin": [vp, vp, vp, C.c_uint64, C.POINTER(vp)],
+        "sbr_fit_epoch_prepare": [vp, u64p],
+        "sbr_fit_step": [vp, C.c_uint64],
+        "sbr_fit_minibatch_rows": [vp, C.c_uint64, u64p],
+        "sbr_fit_end": [vp, fp, u64p],
+        "sbr_fit_exchange_bytes": [vp, u64p],
+        "sbr_fit_step_local": [vp, C.c_uint64, vp],
+        "sbr_fit_step_apply": [vp, C.c_uint64, vp],
+        "sbr_model_set_stream": [vp, vp],
+        "sbr_model_synchronize": [vp],
+        "sbr_fit_debug_fetch": [vp, C.c_int32, vp, C.c_uint64],
+        "sbr_user_representation": [vp, vp, C.c_uint64, vp],
+        "sbr_predict": [vp, vp, vp, C.c_uint64, vp],
+        "sbr_mrr_score": [vp, vp, vp, C.c_uint64, fp, vp, u64p],
+        "sbr_model_param_count": [vp, C.c_int32, u64p],
+        "sbr_model_get_param": [vp, C.c_int32, vp, C.c_uint64],
+        "sbr_model_set_param": [vp, C.c_int32, vp, C.c_uint64],
+        "sbr_model_get_epoch": [vp, u64p],
+        "sbr_device_info": [C.c_char_p, C.c_uint64, u32p, u64p],
+        "sbr_model_timing_enable": [vp, C.c_int32],
+        "sbr_model_timing_read": [vp, C.POINTER(C.c_double), u64p],
+        "sbr_set_device": [C.c_int32],
+        "sbr_selftest_math": [vp, C.c_uint64, vp, vp, vp],
+        "sbr_selftest_dot_tree": [vp, vp, C.c_uint32, C.c_uint64, vp],
+        "sbr_selftest_mfma": [vp, vp, vp, C.c_uint32, vp, vp, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.sbr_model_destroy.argtypes = [vp]
+    L.sbr_model_destroy.restype = None
+    L.sbr_fit_plan_destroy.argtypes = [vp]
+    L.sbr_fit_plan_destroy.restype = None
+    L.sbr_status_string.argtypes = [C.c_int]
+    L.sbr_status_string.restype = C.c_char_p
+    L.sbr_abi_version.argtypes = []
+    L.sbr_abi_version.restype = C.c_uint32
+    if L.sbr_abi_version() != ABI_VERSION:
+        raise EngineUnavailable("libsbr_hip.so ABI version mismatch; rebuild with `python -m sbr_rs_amd.build`")
+    _lib = L
+    return L
+
+
+# every symbol include/sbr_hip.h declares (tests/test_abi.py checks the export table)
+DECLARED_SYMBOLS = [
+    "sbr_model_create", "sbr_model_destroy", "sbr_model_fit", "sbr_fit_begin", "sbr_fit_epoch_prepare",
+    "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_plan_destroy", "sbr_fit_exchange_bytes",
+    "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_model_set_stream", "sbr_model_synchronize",
+    "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
+    "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_device_info", "sbr_status_string",
+    "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_timing_read", "sbr_set_device", "sbr_selftest_math",
+    "sbr_selftest_dot_tree", "sbr_selftest_mfma",
+]

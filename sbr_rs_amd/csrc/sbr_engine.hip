@@ -1,0 +1,1038 @@
+// sbr_engine.hip — host side of libsbr_hip.so: the C-ABI of include/sbr_hip.h.
+//
+// Owns device memory (parameters resident in HBM for the life of the model), restates the
+// reference's training driver (fit_sequence_model, /root/reference/src/models/sequence_model.rs:
+// 70-178) as host-side index work (chunking, shuffles, partitioning, packing) and drives the
+// gfx950 kernels of sbr_kernels.hip on one HIP stream.  There is no CPU compute fallback: without
+// a HIP device every entry point returns SBR_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/sbr_hip.h"
+#include "sbr_kernels.h"
+#include "sbr_numerics.h"
+
+namespace {
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            std::fprintf(stderr, "[sbr_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? SBR_ERR_OUT_OF_MEMORY                  \
+                   : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice) ? SBR_ERR_NO_DEVICE : SBR_ERR_HIP; \
+        }                                                                             \
+    } while (0)
+
+#define SBRCHK(expr)                     \
+    do {                                 \
+        sbr_status _s = (expr);          \
+        if (_s != SBR_OK) return _s;     \
+    } while (0)
+
+template <typename T>
+sbr_status dmalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return SBR_OK;
+}
+
+int dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
+
+struct Normal { /* Marsaglia polar, both variates used (same generator as the oracle's) */
+    sbr_xorshift* r;
+    bool have = false;
+    double spare = 0.0;
+    double next() {
+        if (have) { have = false; return spare; }
+        for (;;) {
+            const double u = 2.0 * sbr_xs_unit(r) - 1.0;
+            const double v = 2.0 * sbr_xs_unit(r) - 1.0;
+            const double s = u * u + v * v;
+            if (s >= 1.0 || s == 0.0) continue;
+            const double f = std::sqrt(-2.0 * std::log(s) / s);
+            spare = v * f;
+            have = true;
+            return u * f;
+        }
+    }
+};
+
+struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
+
+}  // namespace
+
+struct sbr_model {
+    sbr_hparams hp;
+    int d = 0, ng = 0;
+    int device = 0;
+    sbr::ModelView mv;
+    sbr_xorshift rng;
+    uint64_t global_epoch = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+    bool timing = false;
+    std::vector<TimingPair> pending;
+    double ms[SBR_K_FAMILIES] = {0};
+    uint64_t launches[SBR_K_FAMILIES] = {0};
+};
+
+namespace {
+
+struct ScopedTimer {
+    sbr_model* m;
+    TimingPair tp;
+    bool on;
+    ScopedTimer(sbr_model* model, int family, uint64_t launches) : m(model), on(model->timing) {
+        if (!on) return;
+        tp.family = family;
+        tp.launches = launches;
+        hipEventCreate(&tp.a);
+        hipEventCreate(&tp.b);
+        hipEventRecord(tp.a, m->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        hipEventRecord(tp.b, m->stream);
+        m->pending.push_back(tp);
+    }
+};
+
+uint64_t dense_count(const sbr_model* m) {
+    return m->ng ? (uint64_t)(2 * m->d + 1) * m->ng * m->d : (uint64_t)m->d;
+}
+
+/* exchange block geometry (identical to the oracle's) */
+uint64_t block_bytes_for(const sbr_model* m, uint64_t rmax) {
+    const uint64_t words = 8 + 4 * rmax + 2 * rmax * (uint64_t)m->d + dense_count(m);
+    return ((words * 4 + 15) / 16) * 16;
+}
+uint64_t dense_offset_bytes(const sbr_model* m, uint64_t rmax) { return (8 + 4 * rmax + 2 * rmax * (uint64_t)m->d) * 4; }
+
+sbr::BlockView block_view(const sbr_model* m, void* block, uint64_t rmax) {
+    sbr::BlockView v;
+    uint32_t* w = reinterpret_cast<uint32_t*>(block);
+    v.header = w;
+    v.in_idx = w + 8;
+    v.out_idx = v.in_idx + rmax;
+    v.neg = v.out_idx + rmax;
+    v.coef = reinterpret_cast<float*>(v.neg + rmax);
+    v.H = reinterpret_cast<float*>(w + 8 + 4 * rmax);
+    v.dX = v.H + rmax * (uint64_t)m->d;
+    v.dense = v.dX + rmax * (uint64_t)m->d;
+    return v;
+}
+
+/* host-side packed description of a set of sequences (training minibatch or evaluation batch) */
+struct Packed {
+    int R = 0, B = 0, Tm = 0;
+    std::vector<int> off, steps, prev_row, order; /* order[b] = index of the b-th sequence in the input */
+    std::vector<uint32_t> in_idx, out_idx, ctr;
+};
+
+/* Sequences are given as (pointer to first item, number of steps, has_target).  Training:
+ * steps = len - 1, in_t = item[t], out_t = item[t+1] (sequence_model.rs:115-122).  Evaluation:
+ * steps = len, no targets (sequence_model.rs:192-194).  Ordered by steps descending (stable). */
+void pack_sequences(const std::vector<const uint32_t*>& first, const std::vector<int>& nsteps, bool with_targets,
+                    const std::vector<uint64_t>* ctr_base, int maxT, Packed* out) {
+    const int nb = (int)first.size();
+    out->B = nb;
+    out->order.resize(nb);
+    std::vector<int> cnt(maxT + 2, 0), pos(maxT + 2, 0);
+    for (int i = 0; i < nb; ++i) cnt[nsteps[i]]++;
+    int acc = 0;
+    for (int l = maxT; l >= 0; --l) { pos[l] = acc; acc += cnt[l]; }
+    for (int i = 0; i < nb; ++i) out->order[pos[nsteps[i]]++] = i;
+    const int Tm = nb ? nsteps[out->order[0]] : 0;
+    out->Tm = Tm;
+    out->off.assign(Tm + 1, 0);
+    out->steps.resize(nb);
+    for (int b = 0; b < nb; ++b) out->steps[b] = nsteps[out->order[b]];
+    {
+        int alive = nb;
+        for (int t = 0; t < Tm; ++t) {
+            while (alive > 0 && out->steps[alive - 1] <= t) --alive;
+            out->off[t + 1] = out->off[t] + alive;
+        }
+    }
+    const int R = out->off[Tm];
+    out->R = R;
+    out->in_idx.assign(R, 0);
+    out->out_idx.assign(R, 0);
+    out->ctr.assign(R, 0);
+    out->prev_row.assign(R, -1);
+    for (int b = 0; b < nb; ++b) {
+        const int src = out->order[b];
+        const uint32_t* it = first[src];
+        for (int t = 0; t < out->steps[b]; ++t) {
+            const int r = out->off[t] + b;
+            out->in_idx[r] = it[t];
+            if (with_targets) out->out_idx[r] = it[t + 1];
+            if (ctr_base) out->ctr[r] = (uint32_t)((*ctr_base)[src] + (uint64_t)t);
+            out->prev_row[r] = t ? out->off[t - 1] + b : -1;
+        }
+    }
+}
+
+struct DevicePacked { /* device image of one or more Packed, concatenated */
+    int* off = nullptr;
+    int* steps = nullptr;
+    int* prev_row = nullptr;
+    uint32_t *in_idx = nullptr, *out_idx = nullptr, *ctr = nullptr;
+    void release() {
+        hipFree(off); hipFree(steps); hipFree(prev_row); hipFree(in_idx); hipFree(out_idx); hipFree(ctr);
+        off = steps = prev_row = nullptr;
+        in_idx = out_idx = ctr = nullptr;
+    }
+};
+
+struct WorkBuffers {
+    sbr::WorkView v{};
+    void release() {
+        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
+        hipFree(v.partials); hipFree(v.loss); hipFree(v.tries);
+        v = sbr::WorkView{};
+    }
+};
+
+sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool training, WorkBuffers* wb) {
+    const uint64_t d = (uint64_t)m->d;
+    sbr::WorkView& v = wb->v;
+    if (m->ng) {
+        SBRCHK(dmalloc(&v.C, rmax * d));
+        SBRCHK(dmalloc(&v.G, rmax * d * 4));
+    }
+    if (training) {
+        SBRCHK(dmalloc(&v.dH, rmax * d));
+        SBRCHK(dmalloc(&v.loss, rmax));
+        SBRCHK(dmalloc(&v.tries, rmax));
+        if (m->ng) {
+            SBRCHK(dmalloc(&v.dZ, rmax * d * (uint64_t)m->ng));
+            SBRCHK(dmalloc(&v.dHrec, bmax * d));
+            SBRCHK(dmalloc(&v.dCrec, bmax * d));
+            const uint64_t nch = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
+            SBRCHK(dmalloc(&v.partials, nch * dense_count(m)));
+        } else {
+            SBRCHK(dmalloc(&v.dab, bmax * d));
+            SBRCHK(dmalloc(&v.partials, ((bmax + 255) / 256) * d));
+        }
+    }
+    return SBR_OK;
+}
+
+}  // namespace
+
+struct sbr_fit_plan {
+    sbr_model* m = nullptr;
+    int ndev = 1, rank = 0, T = 0;
+    uint64_t nseq_total = 0, part_len = 0;
+    std::vector<uint64_t> seq_start; /* [ndev * part_len], offsets into items */
+    std::vector<uint32_t> seq_len;
+    std::vector<sbr_xorshift> part_rng;
+    std::vector<uint64_t> fit_seed;
+    std::vector<uint32_t> items; /* host copy of the CSR item ids */
+    uint64_t rmax = 0, bmax = 0;
+    /* current epoch */
+    uint64_t epoch_key_epoch = 0;
+    uint64_t num_mb = 0;
+    struct Mb { int R, B, Tm; uint64_t row_base, off_base, seq_base; };
+    std::vector<Mb> mbs;
+    std::vector<int> off_host;             /* concatenated off tables of this rank */
+    std::vector<uint32_t> rows_of_dev;     /* [num_mb][ndev] */
+    DevicePacked dp;
+    uint64_t dp_rows_cap = 0, dp_off_cap = 0, dp_seq_cap = 0;
+    /* work */
+    WorkBuffers wb;
+    uint8_t* block = nullptr;
+    uint64_t block_bytes = 0;
+    uint64_t *keys = nullptr, *keys_sorted = nullptr;
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    int key_bits = 64;
+    double* loss_acc = nullptr;
+    unsigned long long* ex_acc = nullptr;
+    /* last step (debug) */
+    int last_R = 0;
+    const void* last_block = nullptr;
+};
+
+namespace {
+
+sbr::MbView mb_view(const sbr_fit_plan* p, uint64_t i) {
+    const sbr_fit_plan::Mb& mb = p->mbs[i];
+    sbr::MbView v;
+    v.R = mb.R; v.B = mb.B; v.Tm = mb.Tm;
+    v.off = p->dp.off + mb.off_base;
+    v.steps = p->dp.steps + mb.seq_base;
+    v.prev_row = p->dp.prev_row + mb.row_base;
+    v.in_idx = p->dp.in_idx + mb.row_base;
+    v.out_idx = p->dp.out_idx + mb.row_base;
+    v.ctr = p->dp.ctr + mb.row_base;
+    return v;
+}
+
+void shuffle_pairs(uint64_t* start, uint32_t* len, uint64_t n, sbr_xorshift* r) {
+    for (uint64_t i = n; i > 1; --i) { /* Fisher-Yates from the end */
+        const uint64_t j = sbr_xs_below(r, i);
+        std::swap(start[i - 1], start[j]);
+        std::swap(len[i - 1], len[j]);
+    }
+}
+
+sbr_status ensure_device(const sbr_model* m) {
+    HIPCHK(hipSetDevice(m->device));
+    return SBR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t sbr_abi_version(void) { return 1; }
+
+const char* sbr_status_string(sbr_status s) {
+    switch (s) {
+        case SBR_OK: return "ok";
+        case SBR_ERR_NO_INTERACTIONS: return "No interactions were supplied.";
+        case SBR_ERR_INVALID_PREDICTION: return "Invalid prediction value: non-finite or not a number.";
+        case SBR_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case SBR_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SBR_ERR_NO_DEVICE: return "no HIP device (the engine has no CPU fallback)";
+        case SBR_ERR_HIP: return "HIP runtime error";
+        case SBR_ERR_OUT_OF_MEMORY: return "out of device memory";
+    }
+    return "unknown";
+}
+
+sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out_cus, uint64_t* out_hbm_bytes) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return SBR_ERR_NO_DEVICE;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (device_name && name_bytes) {
+        std::snprintf(device_name, (size_t)name_bytes, "%s", prop.gcnArchName);
+    }
+    if (out_cus) *out_cus = (uint32_t)prop.multiProcessorCount;
+    if (out_hbm_bytes) *out_hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
+    if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 || hp->num_devices == 0 ||
+        hp->num_devices > 16 || hp->device_rank >= hp->num_devices || hp->batch_sequences == 0 ||
+        hp->model < 0 || hp->model > 2 || hp->loss < 0 || hp->loss > 2)
+        return SBR_ERR_INVALID_ARGUMENT;
+    if (hp->optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_UNSUPPORTED; /* Adam: SURVEY §8f-2, not built yet */
+    int ndevices = 0;
+    if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
+    sbr_model* m = new (std::nothrow) sbr_model();
+    if (!m) return SBR_ERR_OUT_OF_MEMORY;
+    m->hp = *hp;
+    m->d = (int)hp->embedding_dim;
+    m->ng = hp->model == SBR_MODEL_LSTM_NORMAL ? 4 : hp->model == SBR_MODEL_LSTM_COUPLED ? 3 : 0;
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; return SBR_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return SBR_ERR_HIP; }
+    m->own_stream = true;
+    sbr::ModelView& v = m->mv;
+    std::memset(&v, 0, sizeof(v));
+    v.d = m->d; v.ng = m->ng; v.coupled = m->ng == 3;
+    v.num_items = hp->num_items; v.loss = hp->loss; v.lr = hp->learning_rate; v.l2 = hp->l2_penalty;
+    const uint64_t I = hp->num_items, d = (uint64_t)m->d;
+    sbr_status st = SBR_OK;
+    auto fail = [&](sbr_status s) { sbr_model_destroy(m); return s; };
+    if ((st = dmalloc(&v.E, I * d)) != SBR_OK) return fail(st);
+    if ((st = dmalloc(&v.Eacc, I * d)) != SBR_OK) return fail(st);
+    if ((st = dmalloc(&v.b, I)) != SBR_OK) return fail(st);
+    if ((st = dmalloc(&v.bacc, I)) != SBR_OK) return fail(st);
+    hipMemsetAsync(v.Eacc, 0, I * d * 4, m->stream);
+    hipMemsetAsync(v.b, 0, I * 4, m->stream);
+    hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
+    /* ≙ build_params (lstm.rs:174-194): embeddings first, then the recurrent weights, same RNG */
+    sbr_xs_seed(&m->rng, hp->seed);
+    {
+        std::vector<float> host(I * d);
+        Normal nrm{&m->rng};
+        const double std_e = 1.0 / (double)d;
+        for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_e);
+        if (hipMemcpy(v.E, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
+    }
+    if (m->ng) {
+        const uint64_t nw = 2 * d * (uint64_t)m->ng * d, nb = (uint64_t)m->ng * d;
+        if ((st = dmalloc(&v.W, nw)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.Wacc, nw)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.Wp, nw)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.WTp, nw)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.bW, nb)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.bWacc, nb)) != SBR_OK) return fail(st);
+        hipMemsetAsync(v.Wacc, 0, nw * 4, m->stream);
+        hipMemsetAsync(v.bW, 0, nb * 4, m->stream);
+        hipMemsetAsync(v.bWacc, 0, nb * 4, m->stream);
+        std::vector<float> host(nw);
+        Normal nrm{&m->rng};
+        const double std_w = 1.0 / std::sqrt(2.0 * (double)d);
+        for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_w);
+        if (hipMemcpy(v.W, host.data(), nw * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
+        sbr::launch_repack_lstm(v, m->stream);
+    } else {
+        if ((st = dmalloc(&v.alpha, d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.alpha_acc, d)) != SBR_OK) return fail(st);
+        hipMemsetAsync(v.alpha, 0, d * 4, m->stream);
+        hipMemsetAsync(v.alpha_acc, 0, d * 4, m->stream);
+    }
+    if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(SBR_ERR_HIP);
+    *out = m;
+    return SBR_OK;
+}
+
+void sbr_model_destroy(sbr_model* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    sbr::ModelView& v = m->mv;
+    hipFree(v.E); hipFree(v.Eacc); hipFree(v.b); hipFree(v.bacc);
+    hipFree(v.W); hipFree(v.Wacc); hipFree(v.bW); hipFree(v.bWacc); hipFree(v.Wp); hipFree(v.WTp);
+    hipFree(v.alpha); hipFree(v.alpha_acc);
+    for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
+    if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
+    m->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    m->own_stream = false;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_synchronize(sbr_model* m) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return SBR_OK;
+}
+
+static float* param_ptr(sbr_model* m, int32_t which, uint64_t* count) {
+    const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, ng = (uint64_t)m->ng;
+    sbr::ModelView& v = m->mv;
+    switch (which) {
+        case SBR_PARAM_ITEM_EMBEDDING: *count = I * d; return v.E;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: *count = I * d; return v.Eacc;
+        case SBR_PARAM_ITEM_BIAS: *count = I; return v.b;
+        case SBR_PARAM_ITEM_BIAS_ACC: *count = I; return v.bacc;
+        case SBR_PARAM_LSTM_W: *count = 2 * d * ng * d; return v.W;
+        case SBR_PARAM_LSTM_W_ACC: *count = 2 * d * ng * d; return v.Wacc;
+        case SBR_PARAM_LSTM_B: *count = ng * d; return v.bW;
+        case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return v.bWacc;
+        case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return v.alpha;
+        case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return v.alpha_acc;
+    }
+    *count = 0;
+    return nullptr;
+}
+
+sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* out_count) {
+    if (!m || !out_count) return SBR_ERR_INVALID_ARGUMENT;
+    param_ptr(const_cast<sbr_model*>(m), which, out_count);
+    return SBR_OK;
+}
+
+sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uint64_t count) {
+    if (!m || !host_out) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t n = 0;
+    float* p = param_ptr(m, which, &n);
+    if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(host_out, p, n * 4, hipMemcpyDeviceToHost));
+    return SBR_OK;
+}
+
+sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count) {
+    if (!m || !host_in) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t n = 0;
+    float* p = param_ptr(m, which, &n);
+    if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipMemcpy(p, host_in, n * 4, hipMemcpyHostToDevice));
+    if (which == SBR_PARAM_LSTM_W) {
+        sbr::launch_repack_lstm(m->mv, m->stream);
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    return SBR_OK;
+}
+
+sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch) {
+    if (!m || !out_global_epoch) return SBR_ERR_INVALID_ARGUMENT;
+    *out_global_epoch = m->global_epoch;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    m->timing = enable != 0;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_timing_read(sbr_model* m, double* out_ms, uint64_t* out_launches) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    for (auto& tp : m->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tp.a, tp.b) == hipSuccess) {
+            m->ms[tp.family] += (double)ms;
+            m->launches[tp.family] += tp.launches;
+        }
+        hipEventDestroy(tp.a);
+        hipEventDestroy(tp.b);
+    }
+    m->pending.clear();
+    for (int f = 0; f < SBR_K_FAMILIES; ++f) {
+        if (out_ms) out_ms[f] = m->ms[f];
+        if (out_launches) out_launches[f] = m->launches[f];
+        m->ms[f] = 0.0;
+        m->launches[f] = 0;
+    }
+    return SBR_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * fit
+ * ------------------------------------------------------------------------------------------- */
+sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                         sbr_fit_plan** out) {
+    if (!m || !user_ptr || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    SBRCHK(ensure_device(m));
+    const uint64_t T = m->hp.max_sequence_length;
+    const uint64_t nnz = user_ptr[num_users];
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+    /* subsequences = chunks (first chunk short, data.rs:406-431) with len > 2 (sequence_model.rs:76-83) */
+    std::vector<uint64_t> start;
+    std::vector<uint32_t> len;
+    for (uint64_t u = 0; u < num_users; ++u) {
+        const uint64_t n = user_ptr[u + 1] - user_ptr[u];
+        uint64_t idx = 0;
+        while (idx < n) {
+            const uint64_t mod = (n - idx) % T, cs = mod == 0 ? T : mod;
+            if (cs > 2) { start.push_back(user_ptr[u] + idx); len.push_back((uint32_t)cs); }
+            idx += cs;
+        }
+    }
+    const uint64_t nseq = start.size();
+    if (nseq == 0) return SBR_ERR_NO_INTERACTIONS; /* :86-88 */
+    shuffle_pairs(start.data(), len.data(), nseq, &m->rng); /* :84, model RNG */
+    const int ndev = (int)m->hp.num_devices;
+    const uint64_t part = nseq / ndev; /* :91; the zip at :94-98 drops the remainder */
+    if (part == 0) return SBR_ERR_INVALID_ARGUMENT; /* the reference panics here (chunks_mut(0)) */
+    sbr_fit_plan* p = new (std::nothrow) sbr_fit_plan();
+    if (!p) return SBR_ERR_OUT_OF_MEMORY;
+    p->m = m; p->ndev = ndev; p->rank = (int)m->hp.device_rank; p->T = (int)T;
+    p->nseq_total = nseq; p->part_len = part;
+    start.resize((size_t)ndev * part);
+    len.resize((size_t)ndev * part);
+    p->seq_start.swap(start);
+    p->seq_len.swap(len);
+    p->part_rng.resize(ndev);
+    p->fit_seed.resize(ndev);
+    for (int q = 0; q < ndev; ++q) { /* :97 — XorShiftRng::from_seed(parameters.rng().gen()) */
+        uint8_t seed[16];
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t v = sbr_xs_u32(&m->rng);
+            seed[4 * i] = v & 255; seed[4 * i + 1] = (v >> 8) & 255; seed[4 * i + 2] = (v >> 16) & 255; seed[4 * i + 3] = (v >> 24) & 255;
+        }
+        sbr_xs_seed(&p->part_rng[q], seed);
+        p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
+    }
+    p->items.assign(item_ids, item_ids + nnz);
+    p->bmax = m->hp.batch_sequences;
+    p->rmax = p->bmax * (T - 1);
+    if ((uint64_t)ndev * 3 * p->rmax >= (1ull << 32) || part * T >= (1ull << 32)) { delete p; return SBR_ERR_INVALID_ARGUMENT; }
+    sbr_status st = alloc_work(m, p->rmax, p->bmax, true, &p->wb);
+    if (st == SBR_OK) { p->block_bytes = block_bytes_for(m, p->rmax); st = dmalloc(&p->block, p->block_bytes); }
+    const uint64_t max_entries = (uint64_t)ndev * 3 * p->rmax;
+    int item_bits = 1;
+    while ((1ull << item_bits) < (uint64_t)m->hp.num_items) ++item_bits;
+    p->key_bits = 32 + item_bits;
+    if (st == SBR_OK) st = dmalloc(&p->keys, max_entries);
+    if (st == SBR_OK) st = dmalloc(&p->keys_sorted, max_entries);
+    if (st == SBR_OK) {
+        p->sort_temp_bytes = sbr::sparse_sort_temp_bytes(max_entries, p->key_bits);
+        uint8_t* tmp = nullptr;
+        st = dmalloc(&tmp, p->sort_temp_bytes);
+        p->sort_temp = tmp;
+    }
+    if (st == SBR_OK) st = dmalloc(&p->loss_acc, 1);
+    if (st == SBR_OK) st = dmalloc(&p->ex_acc, 1);
+    if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
+    hipMemsetAsync(p->loss_acc, 0, sizeof(double), m->stream);
+    hipMemsetAsync(p->ex_acc, 0, sizeof(unsigned long long), m->stream);
+    hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
+    *out = p;
+    return SBR_OK;
+}
+
+void sbr_fit_plan_destroy(sbr_fit_plan* p) {
+    if (!p) return;
+    hipSetDevice(p->m->device);
+    hipStreamSynchronize(p->m->stream);
+    p->dp.release();
+    p->wb.release();
+    hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
+    hipFree(p->loss_acc); hipFree(p->ex_acc);
+    delete p;
+}
+
+sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    /* ≙ thread_rng.shuffle(partition) (sequence_model.rs:109) — every partition, so that each
+     * device also knows the row counts its peers contribute to a step */
+    for (int q = 0; q < p->ndev; ++q)
+        shuffle_pairs(p->seq_start.data() + (size_t)q * p->part_len, p->seq_len.data() + (size_t)q * p->part_len,
+                      p->part_len, &p->part_rng[q]);
+    p->epoch_key_epoch = m->global_epoch;
+    m->global_epoch += 1;
+    const uint64_t B = p->bmax;
+    const uint64_t nmb = (p->part_len + B - 1) / B;
+    p->num_mb = nmb;
+    p->rows_of_dev.assign(nmb * p->ndev, 0);
+    for (int q = 0; q < p->ndev; ++q) {
+        const uint32_t* ln = p->seq_len.data() + (size_t)q * p->part_len;
+        for (uint64_t mb = 0; mb < nmb; ++mb) {
+            const uint64_t p0 = mb * B, p1 = std::min(p0 + B, p->part_len);
+            uint32_t r = 0;
+            for (uint64_t i = p0; i < p1; ++i) r += ln[i] - 1;
+            p->rows_of_dev[mb * p->ndev + q] = r;
+        }
+    }
+    /* pack this rank's minibatches */
+    const uint64_t* st = p->seq_start.data() + (size_t)p->rank * p->part_len;
+    const uint32_t* ln = p->seq_len.data() + (size_t)p->rank * p->part_len;
+    p->mbs.resize(nmb);
+    p->off_host.clear();
+    std::vector<int> steps_all, prev_all;
+    std::vector<uint32_t> in_all, out_all, ctr_all;
+    uint64_t row_base = 0, seq_base = 0;
+    Packed pk;
+    std::vector<const uint32_t*> first;
+    std::vector<int> nsteps;
+    std::vector<uint64_t> ctr_base;
+    for (uint64_t mb = 0; mb < nmb; ++mb) {
+        const uint64_t p0 = mb * B, p1 = std::min(p0 + B, p->part_len);
+        first.clear(); nsteps.clear(); ctr_base.clear();
+        for (uint64_t i = p0; i < p1; ++i) {
+            first.push_back(p->items.data() + st[i]);
+            nsteps.push_back((int)ln[i] - 1);
+            ctr_base.push_back(i * (uint64_t)p->T);
+        }
+        pack_sequences(first, nsteps, true, &ctr_base, p->T, &pk);
+        sbr_fit_plan::Mb& d = p->mbs[mb];
+        d.R = pk.R; d.B = pk.B; d.Tm = pk.Tm;
+        d.row_base = row_base; d.seq_base = seq_base; d.off_base = p->off_host.size();
+        p->off_host.insert(p->off_host.end(), pk.off.begin(), pk.off.end());
+        steps_all.insert(steps_all.end(), pk.steps.begin(), pk.steps.end());
+        prev_all.insert(prev_all.end(), pk.prev_row.begin(), pk.prev_row.end());
+        in_all.insert(in_all.end(), pk.in_idx.begin(), pk.in_idx.end());
+        out_all.insert(out_all.end(), pk.out_idx.begin(), pk.out_idx.end());
+        ctr_all.insert(ctr_all.end(), pk.ctr.begin(), pk.ctr.end());
+        row_base += (uint64_t)pk.R;
+        seq_base += (uint64_t)pk.B;
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (row_base > p->dp_rows_cap || p->off_host.size() > p->dp_off_cap || seq_base > p->dp_seq_cap) {
+        p->dp.release();
+        SBRCHK(dmalloc(&p->dp.in_idx, row_base));
+        SBRCHK(dmalloc(&p->dp.out_idx, row_base));
+        SBRCHK(dmalloc(&p->dp.ctr, row_base));
+        SBRCHK(dmalloc(&p->dp.prev_row, row_base));
+        SBRCHK(dmalloc(&p->dp.off, p->off_host.size()));
+        SBRCHK(dmalloc(&p->dp.steps, seq_base));
+        p->dp_rows_cap = row_base; p->dp_off_cap = p->off_host.size(); p->dp_seq_cap = seq_base;
+    }
+    HIPCHK(hipMemcpy(p->dp.in_idx, in_all.data(), row_base * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dp.out_idx, out_all.data(), row_base * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dp.ctr, ctr_all.data(), row_base * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dp.prev_row, prev_all.data(), row_base * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dp.off, p->off_host.data(), p->off_host.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->dp.steps, steps_all.data(), seq_base * 4, hipMemcpyHostToDevice));
+    if (out_num_minibatches) *out_num_minibatches = nmb;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows) {
+    if (!p || !out_rows || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    *out_rows = (uint64_t)p->mbs[minibatch].R;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_exchange_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
+    if (!p || !out_bytes) return SBR_ERR_INVALID_ARGUMENT;
+    *out_bytes = p->block_bytes;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_exchange_out) {
+    if (!p || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    void* block = device_exchange_out ? device_exchange_out : p->block;
+    const sbr_fit_plan::Mb& mb = p->mbs[minibatch];
+    const sbr::MbView mv = mb_view(p, minibatch);
+    const sbr::BlockView bv = block_view(m, block, p->rmax);
+    const int* off_host = p->off_host.data() + mb.off_base;
+    {
+        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng ? (uint64_t)mb.Tm : 1);
+        sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
+    }
+    {
+        ScopedTimer t(m, SBR_K_SCORE, 1);
+        sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], p->epoch_key_epoch), mb.R, m->stream);
+    }
+    {
+        ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng ? (uint64_t)mb.Tm : 1);
+        sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
+    }
+    p->last_R = mb.R;
+    p->last_block = block;
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* device_exchange_all) {
+    if (!p || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const uint8_t* all = reinterpret_cast<const uint8_t*>(device_exchange_all ? device_exchange_all : p->block);
+    if (!device_exchange_all && p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT;
+    sbr::launch_accumulate_loss(all, p->block_bytes, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    {
+        ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
+        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), p->ndev, m->stream);
+    }
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, p->ndev, p->rmax, p->rows_of_dev.data() + minibatch * p->ndev,
+                                 p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: step_local + all-gather + step_apply */
+    SBRCHK(sbr_fit_step_local(p, minibatch, nullptr));
+    return sbr_fit_step_apply(p, minibatch, nullptr);
+}
+
+sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    double loss = 0.0;
+    unsigned long long ex = 0;
+    HIPCHK(hipMemcpy(&loss, p->loss_acc, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&ex, p->ex_acc, sizeof(ex), hipMemcpyDeviceToHost));
+    /* ≙ loss_value / (1.0 + examples) (sequence_model.rs:173); true loss, not the stale node value */
+    if (out_loss) *out_loss = (float)(loss / (1.0 + (double)ex));
+    if (out_examples) *out_examples = (uint64_t)ex;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                         float* out_loss) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->hp.num_devices != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device fits are driven by the host (distributed.py) */
+    sbr_fit_plan* p = nullptr;
+    SBRCHK(sbr_fit_begin(m, user_ptr, item_ids, num_users, &p));
+    sbr_status st = SBR_OK;
+    for (uint32_t e = 0; e < m->hp.num_epochs && st == SBR_OK; ++e) {
+        uint64_t nmb = 0;
+        st = sbr_fit_epoch_prepare(p, &nmb);
+        for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) st = sbr_fit_step(p, mb);
+    }
+    if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
+    sbr_fit_plan_destroy(p);
+    return st;
+}
+
+sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, uint64_t bytes) {
+    if (!p || !host_out || !p->last_block) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const sbr::BlockView bv = block_view(m, const_cast<void*>(p->last_block), p->rmax);
+    const uint64_t R = (uint64_t)p->last_R, d = (uint64_t)m->d;
+    const void* src = nullptr;
+    uint64_t n = 0;
+    switch (which) {
+        case SBR_DBG_HIDDEN: src = bv.H; n = R * d * 4; break;
+        case SBR_DBG_NEGATIVES: src = bv.neg; n = R * 4; break;
+        case SBR_DBG_COEF: src = bv.coef; n = R * 4; break;
+        case SBR_DBG_LOSS: src = p->wb.v.loss; n = R * 4; break;
+        case SBR_DBG_DHIDDEN: src = p->wb.v.dH; n = R * d * 4; break;
+        case SBR_DBG_DINPUT: src = bv.dX; n = R * d * 4; break;
+        case SBR_DBG_DENSE_GRAD: src = bv.dense; n = dense_count(m) * 4; break;
+        case SBR_DBG_IN_IDX: src = bv.in_idx; n = R * 4; break;
+        case SBR_DBG_OUT_IDX: src = bv.out_idx; n = R * 4; break;
+        case SBR_DBG_TRIES: src = p->wb.v.tries; n = R * 4; break;
+        default: return SBR_ERR_INVALID_ARGUMENT;
+    }
+    if (bytes < n) return SBR_ERR_INVALID_ARGUMENT;
+    if (n) HIPCHK(hipMemcpy(host_out, src, n, hipMemcpyDeviceToHost));
+    return SBR_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * prediction side
+ * ------------------------------------------------------------------------------------------- */
+namespace {
+
+/* Runs the recurrent forward for a batch of histories and leaves the hidden states in *H_out
+ * (device, caller frees); rep_row[i] = packed row of the final state of history i. */
+sbr_status forward_histories(sbr_model* m, const std::vector<const uint32_t*>& first, const std::vector<int>& nsteps,
+                             float** H_out, std::vector<int>* rep_row) {
+    Packed pk;
+    pack_sequences(first, nsteps, false, nullptr, (int)m->hp.max_sequence_length, &pk);
+    DevicePacked dp;
+    WorkBuffers wb;
+    float* H = nullptr;
+    sbr_status st = SBR_OK;
+    auto cleanup = [&]() { dp.release(); wb.release(); };
+    if ((st = dmalloc(&dp.in_idx, pk.R)) != SBR_OK || (st = dmalloc(&dp.out_idx, pk.R)) != SBR_OK ||
+        (st = dmalloc(&dp.ctr, pk.R)) != SBR_OK || (st = dmalloc(&dp.prev_row, pk.R)) != SBR_OK ||
+        (st = dmalloc(&dp.off, pk.off.size())) != SBR_OK || (st = dmalloc(&dp.steps, pk.B)) != SBR_OK ||
+        (st = alloc_work(m, pk.R, pk.B, false, &wb)) != SBR_OK || (st = dmalloc(&H, (uint64_t)pk.R * m->d)) != SBR_OK) {
+        cleanup();
+        hipFree(H);
+        return st;
+    }
+    hipMemcpy(dp.in_idx, pk.in_idx.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dp.prev_row, pk.prev_row.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dp.off, pk.off.data(), pk.off.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dp.steps, pk.steps.data(), (size_t)pk.B * 4, hipMemcpyHostToDevice);
+    sbr::MbView mv;
+    mv.R = pk.R; mv.B = pk.B; mv.Tm = pk.Tm;
+    mv.off = dp.off; mv.steps = dp.steps; mv.prev_row = dp.prev_row;
+    mv.in_idx = dp.in_idx; mv.out_idx = dp.out_idx; mv.ctr = dp.ctr;
+    {
+        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng ? (uint64_t)pk.Tm : 1);
+        sbr::launch_recurrent_forward(m->mv, mv, H, wb.v, pk.Tm, pk.off.data(), m->stream);
+    }
+    hipError_t e = hipStreamSynchronize(m->stream);
+    cleanup();
+    if (e != hipSuccess) { hipFree(H); return SBR_ERR_HIP; }
+    rep_row->assign(first.size(), 0);
+    for (int b = 0; b < pk.B; ++b) (*rep_row)[pk.order[b]] = pk.off[pk.steps[b] - 1] + b;
+    *H_out = H;
+    return SBR_OK;
+}
+
+}  // namespace
+
+sbr_status sbr_user_representation(sbr_model* m, const uint32_t* item_ids, uint64_t n, float* out_dim) {
+    if (!m || !out_dim || (n && !item_ids)) return SBR_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(m->mu);
+    SBRCHK(ensure_device(m));
+    const uint64_t T = m->hp.max_sequence_length;
+    static const uint32_t zero = 0;
+    if (n > T) { item_ids += n - T; n = T; } /* sequence_model.rs:188 */
+    if (n == 0) { item_ids = &zero; n = 1; } /* default index 0 (lstm.rs:262-264) */
+    for (uint64_t t = 0; t < n; ++t)
+        if (item_ids[t] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+    std::vector<const uint32_t*> first{item_ids};
+    std::vector<int> nsteps{(int)n};
+    float* H = nullptr;
+    std::vector<int> rep_row;
+    SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
+    hipError_t e = hipMemcpy(out_dim, H + (size_t)rep_row[0] * m->d, (size_t)m->d * 4, hipMemcpyDeviceToHost);
+    hipFree(H);
+    return e == hipSuccess ? SBR_OK : SBR_ERR_HIP;
+}
+
+sbr_status sbr_predict(sbr_model* m, const float* user_dim, const uint32_t* item_ids, uint64_t n, float* out) {
+    if (!m || !user_dim || (n && (!item_ids || !out))) return SBR_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(m->mu);
+    SBRCHK(ensure_device(m));
+    for (uint64_t i = 0; i < n; ++i)
+        if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+    if (n == 0) return SBR_OK;
+    float *d_user = nullptr, *d_out = nullptr;
+    uint32_t* d_items = nullptr;
+    sbr_status st = SBR_OK;
+    if ((st = dmalloc(&d_user, m->d)) == SBR_OK && (st = dmalloc(&d_items, n)) == SBR_OK && (st = dmalloc(&d_out, n)) == SBR_OK) {
+        hipMemcpy(d_user, user_dim, (size_t)m->d * 4, hipMemcpyHostToDevice);
+        hipMemcpy(d_items, item_ids, n * 4, hipMemcpyHostToDevice);
+        sbr::launch_predict(m->mv, d_user, d_items, n, d_out, m->stream);
+        if (hipStreamSynchronize(m->stream) != hipSuccess || hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            st = SBR_ERR_HIP;
+    }
+    hipFree(d_user); hipFree(d_items); hipFree(d_out);
+    if (st != SBR_OK) return st;
+    for (uint64_t i = 0; i < n; ++i)
+        if (!std::isfinite(out[i])) return SBR_ERR_INVALID_PREDICTION; /* sequence_model.rs:225-229 */
+    return SBR_OK;
+}
+
+sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                         float* out_mrr, uint32_t* out_ranks, uint64_t* out_num_ranked) {
+    if (!m || !user_ptr || !out_mrr) return SBR_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lock(m->mu);
+    SBRCHK(ensure_device(m));
+    const uint64_t T = m->hp.max_sequence_length;
+    const uint64_t nnz = user_ptr[num_users];
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
+    std::vector<uint64_t> users; /* users with >= 2 interactions (evaluation.rs:20) */
+    for (uint64_t u = 0; u < num_users; ++u)
+        if (user_ptr[u + 1] - user_ptr[u] >= 2) users.push_back(u);
+    if (out_num_ranked) *out_num_ranked = users.size();
+    std::vector<uint32_t> ranks(users.size(), 0);
+    const size_t EVAL_B = 2048;
+    for (size_t c0 = 0; c0 < users.size(); c0 += EVAL_B) {
+        const size_t c1 = std::min(c0 + EVAL_B, users.size());
+        const size_t nu = c1 - c0;
+        std::vector<const uint32_t*> first(nu);
+        std::vector<int> nsteps(nu);
+        std::vector<uint32_t> test_item(nu), test_in_hist(nu, 0), hist_items;
+        std::vector<uint64_t> hist_ptr(nu + 1, 0);
+        for (size_t i = 0; i < nu; ++i) {
+            const uint64_t u = users[c0 + i];
+            const uint32_t* it = item_ids + user_ptr[u];
+            const uint64_t n = user_ptr[u + 1] - user_ptr[u];
+            const uint64_t nh = n - 1; /* train_items = all but last (evaluation.rs:24) */
+            test_item[i] = it[n - 1];
+            const uint64_t keep = std::min(nh, T); /* last T items feed the state (sequence_model.rs:188) */
+            first[i] = it + (nh - keep);
+            nsteps[i] = (int)keep;
+            std::vector<uint32_t> h(it, it + nh); /* ALL history items are masked (evaluation.rs:30-32) */
+            std::sort(h.begin(), h.end());
+            h.erase(std::unique(h.begin(), h.end()), h.end());
+            test_in_hist[i] = std::binary_search(h.begin(), h.end(), test_item[i]) ? 1u : 0u;
+            hist_items.insert(hist_items.end(), h.begin(), h.end());
+            hist_ptr[i + 1] = hist_items.size();
+        }
+        float* H = nullptr;
+        std::vector<int> rep_row;
+        SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
+        int* d_rep = nullptr;
+        uint32_t *d_test = nullptr, *d_tih = nullptr, *d_hist = nullptr, *d_ranks = nullptr, *d_flag = nullptr;
+        uint64_t* d_hptr = nullptr;
+        sbr_status st = SBR_OK;
+        if ((st = dmalloc(&d_rep, nu)) == SBR_OK && (st = dmalloc(&d_test, nu)) == SBR_OK && (st = dmalloc(&d_tih, nu)) == SBR_OK &&
+            (st = dmalloc(&d_hist, hist_items.size())) == SBR_OK && (st = dmalloc(&d_ranks, nu)) == SBR_OK &&
+            (st = dmalloc(&d_flag, 1)) == SBR_OK && (st = dmalloc(&d_hptr, nu + 1)) == SBR_OK) {
+            hipMemcpy(d_rep, rep_row.data(), nu * 4, hipMemcpyHostToDevice);
+            hipMemcpy(d_test, test_item.data(), nu * 4, hipMemcpyHostToDevice);
+            hipMemcpy(d_tih, test_in_hist.data(), nu * 4, hipMemcpyHostToDevice);
+            if (!hist_items.empty()) hipMemcpy(d_hist, hist_items.data(), hist_items.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(d_hptr, hist_ptr.data(), (nu + 1) * 8, hipMemcpyHostToDevice);
+            hipMemset(d_flag, 0, 4);
+            {
+                ScopedTimer t(m, SBR_K_RANK, 1);
+                sbr::launch_rank(m->mv, H, d_rep, (uint32_t)nu, d_test, d_tih, d_hptr, d_hist, d_ranks, d_flag, m->stream);
+            }
+            uint32_t flag = 0;
+            if (hipStreamSynchronize(m->stream) != hipSuccess ||
+                hipMemcpy(ranks.data() + c0, d_ranks, nu * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                st = SBR_ERR_HIP;
+            else if (flag)
+                st = SBR_ERR_INVALID_PREDICTION; /* predict fails the call on a non-finite score */
+        }
+        hipFree(H); hipFree(d_rep); hipFree(d_test); hipFree(d_tih); hipFree(d_hist); hipFree(d_ranks); hipFree(d_flag); hipFree(d_hptr);
+        if (st != SBR_OK) return st;
+    }
+    float sum = 0.0f; /* evaluation.rs:47 — sequential f32 sum in user order */
+    for (size_t i = 0; i < ranks.size(); ++i) sum += 1.0f / (float)ranks[i];
+    *out_mrr = sum / (float)ranks.size();
+    if (out_ranks) std::memcpy(out_ranks, ranks.data(), ranks.size() * 4);
+    return SBR_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * numerics self-tests (tests/test_numerics_gpu.py): run the contract's primitives on the device
+ * ------------------------------------------------------------------------------------------- */
+sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_exp, float* out_sig, float* out_tanh) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
+    float *dx, *de, *ds, *dt;
+    SBRCHK(dmalloc(&dx, n)); SBRCHK(dmalloc(&de, n)); SBRCHK(dmalloc(&ds, n)); SBRCHK(dmalloc(&dt, n));
+    HIPCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    sbr::launch_selftest_math(dx, de, ds, dt, n, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_exp, de, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_sig, ds, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_tanh, dt, n * 4, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(de); hipFree(ds); hipFree(dt);
+    return SBR_OK;
+}
+
+sbr_status sbr_selftest_dot_tree(const float* x, const float* y, uint32_t d, uint64_t nrows, float* out) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
+    if (!dim_ok(d) || nrows == 0) return SBR_ERR_INVALID_ARGUMENT;
+    float *dx, *dy, *dout;
+    SBRCHK(dmalloc(&dx, nrows * d)); SBRCHK(dmalloc(&dy, nrows * d)); SBRCHK(dmalloc(&dout, nrows));
+    HIPCHK(hipMemcpy(dx, x, nrows * d * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dy, y, nrows * d * 4, hipMemcpyHostToDevice));
+    sbr::launch_selftest_dot_tree(dx, dy, (int)d, nrows, dout, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, nrows * 4, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return SBR_OK;
+}
+
+/* out[16][16] = c0 + a[16][k] b[k][16] on v_mfma_f32_16x16x4_f32; out32[32][32] = a32[32][k] b32[k][32]
+ * on v_mfma_f32_32x32x2_f32 (k multiple of 4) */
+sbr_status sbr_selftest_mfma(const float* a, const float* b, const float* c0, uint32_t k, float* out,
+                             const float* a32, const float* b32, float* out32) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
+    if (k == 0 || k % 4) return SBR_ERR_INVALID_ARGUMENT;
+    float *da, *db, *dc, *dout, *da32, *db32, *dout32;
+    SBRCHK(dmalloc(&da, 16 * k)); SBRCHK(dmalloc(&db, 16 * k)); SBRCHK(dmalloc(&dc, 256)); SBRCHK(dmalloc(&dout, 256));
+    SBRCHK(dmalloc(&da32, 32 * k)); SBRCHK(dmalloc(&db32, 32 * k)); SBRCHK(dmalloc(&dout32, 1024));
+    HIPCHK(hipMemcpy(da, a, 16 * k * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, 16 * k * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc, c0, 256 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(da32, a32, 32 * k * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db32, b32, 32 * k * 4, hipMemcpyHostToDevice));
+    sbr::launch_selftest_mfma_chain(da, db, dc, (int)k, dout, nullptr);
+    sbr::launch_selftest_mfma32_chain(da32, db32, (int)k, dout32, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, 256 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out32, dout32, 1024 * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dc); hipFree(dout); hipFree(da32); hipFree(db32); hipFree(dout32);
+    return SBR_OK;
+}
+
+sbr_status sbr_set_device(int32_t ordinal) {
+    HIPCHK(hipSetDevice(ordinal));
+    return SBR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+/* sbr_kernels.h — launch interface between the host engine (sbr_engine.hip) and the gfx950
+ * kernels (sbr_kernels.hip).  Internal to libsbr_hip.so; the public ABI is include/sbr_hip.h. */
+#ifndef SBR_KERNELS_H
+#define SBR_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbr {
+
+/* One device-local packed minibatch.  Rows are time-major: row(t, b) = off[t] + b, sequences b in
+ * length-descending order, so the rows of step t are a prefix of the sequences of step t-1. */
+struct MbView {
+    int R;                   /* packed rows = sum over sequences of steps                     */
+    int B;                   /* sequences                                                     */
+    int Tm;                  /* max steps                                                     */
+    const int* off;          /* device [Tm+1]                                                 */
+    const int* steps;        /* device [B]   steps of sequence b                              */
+    const int* prev_row;     /* device [R]   packed row of (t-1, b) or -1                      */
+    const uint32_t* in_idx;  /* device [R]                                                    */
+    const uint32_t* out_idx; /* device [R]                                                    */
+    const uint32_t* ctr;     /* device [R]   p * max_sequence_length + t                       */
+};
+
+/* Views into one exchange block (layout: oracle/sbr_oracle.c "exchange block"). */
+struct BlockView {
+    uint32_t* header; /* [0]=R, [4..5]=f64 loss_sum, [6..7]=u64 examples */
+    uint32_t* in_idx;
+    uint32_t* out_idx;
+    uint32_t* neg;
+    float* coef;
+    float* H;
+    float* dX;
+    float* dense;
+};
+
+struct ModelView {
+    int d, ng;          /* ng = 4 / 3 / 0 */
+    int coupled;
+    uint32_t num_items;
+    int loss;           /* sbr_loss */
+    float lr, l2;
+    float *E, *Eacc, *b, *bacc;
+    float *W, *Wacc, *bW, *bWacc, *Wp, *WTp;
+    float *alpha, *alpha_acc;
+};
+
+struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
+    float *C, *G, *dH, *dZ;
+    float *dHrec, *dCrec;   /* [Bmax][d] */
+    float* dab;             /* EWMA per-sequence dalpha partials [Bmax][d] */
+    float* partials;        /* dense-gradient chunk partials */
+    float* loss;            /* [Rmax] */
+    uint32_t* tries;        /* [Rmax] */
+};
+
+/* recurrent forward over all steps of the minibatch (LSTM: one launch per step) */
+void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
+                              const int* off_host, hipStream_t s);
+/* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */
+void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                  int rows_host, hipStream_t s);
+/* BPTT + dense gradient into blk.dense */
+void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                               int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s);
+/* dense: sum over device blocks in device order + Adagrad (+ repack of the LSTM weights) */
+void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
+                        int ndev, hipStream_t s);
+void launch_repack_lstm(const ModelView& m, hipStream_t s);
+/* sparse: keys -> sort -> per-row ordered reduction + Adagrad */
+size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits);
+void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                         size_t sort_temp_bytes, int key_bits, hipStream_t s);
+/* accumulate loss/examples headers of all blocks into the plan accumulators */
+void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
+                            unsigned long long* ex_acc, hipStream_t s);
+/* prediction side */
+void launch_predict(const ModelView& m, const float* user, const uint32_t* items, uint64_t n, float* out, hipStream_t s);
+void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint32_t num_users, const uint32_t* test_item,
+                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, uint32_t* ranks,
+                 uint32_t* nonfinite_flag, hipStream_t s);
+/* device self-tests of the numerics contract (tests/test_numerics_gpu.py) */
+void launch_selftest_math(const float* x, float* out_exp, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s);
+void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s);
+void launch_selftest_mfma_chain(const float* a, const float* b, const float* c0, int k, float* out, hipStream_t s);
+void launch_selftest_mfma32_chain(const float* a, const float* b, int k, float* out, hipStream_t s);
+
+}  // namespace sbr
+#endif

@@ -1,0 +1,933 @@
+// sbr_kernels.hip — gfx950 (CDNA4, MI355X) kernels of the sequence-recommender hot path.
+//
+// Every kernel reproduces, bit for bit, the association orders fixed in sbr_numerics.h and
+// restated sequentially by the CPU oracle (oracle/sbr_oracle.c):
+//   * length-d score dots   : 16-byte-per-lane partials + xor butterfly inside a d/4-lane group
+//   * LSTM gate / BPTT GEMMs: v_mfma_f32_16x16x4_f32, one accumulator per output, k ascending
+//                             (an f32 MFMA is a k-ordered fmaf chain on gfx950)
+//   * dense gradients       : v_mfma_f32_32x32x2_f32 over fixed 1024-row chunks, chunk partials
+//                             added in chunk order
+//   * sparse row gradients  : radix sort of (row, source) keys, per-row in-order reduction,
+//                             one Adagrad read-modify-write per touched row
+// Reference call sites replaced: the wyrm graph built by Parameters::build
+// (/root/reference/src/models/lstm.rs:258-337, ewma.rs:266-352), driven by fit_sequence_model
+// (/root/reference/src/models/sequence_model.rs:111-169), predict_single (lstm.rs:338-350) and
+// the ranking loop of mrr_score (/root/reference/src/evaluation.rs:27-43).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see sbr_rs_amd/build.py).
+
+#include "sbr_kernels.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/sbr_hip.h"
+#include "sbr_numerics.h"
+
+namespace sbr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define EWMA_CHUNK_SEQS 256
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+template <int L>
+__device__ __forceinline__ float group_allreduce(float p) {
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    return p;
+}
+__device__ __forceinline__ float dot4(float4 x, float4 y) {
+    float p = x.x * y.x;
+    p = sbr_fma(x.y, y.y, p);
+    p = sbr_fma(x.z, y.z, p);
+    p = sbr_fma(x.w, y.w, p);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1+K3+K4: gather + negative sampling + loss + dloss/dh  (the HBM-roofline kernel)
+// One d/4-lane group per packed row; 16 B per lane per gathered embedding row.
+// ------------------------------------------------------------------------------------------------
+__global__ void block_header_init(uint32_t* header, int R) {
+    header[0] = (uint32_t)R;
+    header[1] = header[2] = header[3] = 0;
+    *reinterpret_cast<double*>(header + 4) = 0.0;
+    *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
+                                                    uint64_t epoch_key) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int lg = lane % L;
+    const int grp = lane / L;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+    double wave_loss = 0.0;
+    for (int base = wave * GPW; base < mb.R; base += nwaves * GPW) {
+        const int r = base + grp;
+        const bool valid = r < mb.R;
+        const int rr = valid ? r : mb.R - 1;
+        const float4 h = ld4(blk.H + (size_t)rr * D + 4 * lg);
+        const uint32_t pi = mb.out_idx[rr];
+        const uint32_t ctr = mb.ctr[rr];
+        const float4 ep = ld4(m.E + (size_t)pi * D + 4 * lg);
+        const float bp = m.b[pi];
+        // first candidate is always scored: issue its gather together with the positive's
+        uint32_t cand = sbr_neg_draw(epoch_key, ctr, 0u, m.num_items);
+        float4 ec = ld4(m.E + (size_t)cand * D + 4 * lg);
+        float bc = m.b[cand];
+        const float pos = bp + group_allreduce<L>(dot4(h, ep));
+        bool done = false;
+        uint32_t nj = 0, tries = 0;
+        float neg = 0.0f;
+        float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < max_tries; ++k) {
+            if (k > 0) {
+                if (__all(done)) break;
+                cand = sbr_neg_draw(epoch_key, ctr, (uint32_t)k, m.num_items);
+                if (!done) {
+                    ec = ld4(m.E + (size_t)cand * D + 4 * lg);
+                    bc = m.b[cand];
+                }
+            }
+            const float s = bc + group_allreduce<L>(dot4(h, ec));
+            if (!done) {
+                nj = cand;
+                neg = s;
+                en = ec;
+                ++tries;
+                if (sbr_warp_violates(pos, s)) done = true;
+            }
+        }
+        float g, l;
+        if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
+        else l = sbr_loss_hinge(pos, neg, &g);
+        if (valid) {
+            float4 dh;
+            dh.x = g * en.x - g * ep.x;
+            dh.y = g * en.y - g * ep.y;
+            dh.z = g * en.z - g * ep.z;
+            dh.w = g * en.w - g * ep.w;
+            st4(w.dH + (size_t)r * D + 4 * lg, dh);
+            if (lg == 0) {
+                blk.neg[r] = nj;
+                blk.coef[r] = g;
+                blk.in_idx[r] = mb.in_idx[r];
+                blk.out_idx[r] = pi;
+                w.loss[r] = l;
+                w.tries[r] = tries;
+                wave_loss += (double)l;
+            }
+        }
+    }
+    // loss is reporting only (tolerance parity): order-free f64 accumulation
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) wave_loss += __shfl_xor(wave_loss, off, 64);
+    if (lane == 0 && wave_loss != 0.0) atomicAdd(reinterpret_cast<double*>(blk.header + 4), wave_loss);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2': EWMA forward / backward scans — one d/4-lane group per sequence
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void ewma_forward_kernel(ModelView m, MbView mb, float* H) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float a[4], oma[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = sbr_sigmoidf(m.alpha[4 * lg + j]);
+        oma[j] = 1.0f - a[j];
+    }
+    for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) {
+        const int n = mb.steps[b];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < n; ++t) {
+            const int r = mb.off[t] + b;
+            const float4 x = ld4(m.E + (size_t)mb.in_idx[r] * D + 4 * lg);
+            if (t == 0) {
+                s = x;
+            } else {
+                s.x = sbr_fma(a[0], s.x, oma[0] * x.x);
+                s.y = sbr_fma(a[1], s.y, oma[1] * x.y);
+                s.z = sbr_fma(a[2], s.z, oma[2] * x.z);
+                s.w = sbr_fma(a[3], s.w, oma[3] * x.w);
+            }
+            st4(H + (size_t)r * D + 4 * lg, s);
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float a[4], oma[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = sbr_sigmoidf(m.alpha[4 * lg + j]);
+        oma[j] = 1.0f - a[j];
+    }
+    for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) {
+        const int n = mb.steps[b];
+        float carry[4] = {0.f, 0.f, 0.f, 0.f};
+        float da[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = n - 1; t >= 0; --t) {
+            const int r = mb.off[t] + b;
+            const float4 dh = ld4(w.dH + (size_t)r * D + 4 * lg);
+            float ds[4] = {dh.x, dh.y, dh.z, dh.w};
+            if (t != n - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
+            }
+            float4 dx;
+            if (t > 0) {
+                const float4 x = ld4(m.E + (size_t)mb.in_idx[r] * D + 4 * lg);
+                const float4 sp = ld4(blk.H + (size_t)(mb.off[t - 1] + b) * D + 4 * lg);
+                const float xs[4] = {x.x, x.y, x.z, x.w};
+                const float sps[4] = {sp.x, sp.y, sp.z, sp.w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = oma[j] * ds[j];
+                    carry[j] = a[j] * ds[j];
+                    da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+                }
+                dx = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            }
+            st4(blk.dX + (size_t)r * D + 4 * lg, dx);
+        }
+        st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
+    }
+}
+
+// dalpha: chunk partials (chain over sequences inside a chunk), then chain across chunks
+__global__ void ewma_dab_chunk_kernel(const float* dab, int B, int D, float* partials) {
+    const int c = blockIdx.x;
+    const int k = threadIdx.x;
+    if (k >= D) return;
+    int b0 = c * EWMA_CHUNK_SEQS, b1 = b0 + EWMA_CHUNK_SEQS;
+    if (b1 > B) b1 = B;
+    float pc = 0.0f;
+    for (int b = b0; b < b1; ++b) pc = pc + dab[(size_t)b * D + k];
+    partials[(size_t)c * D + k] = pc;
+}
+__global__ void ewma_dense_final_kernel(const float* partials, int nchunks, int D, const float* alpha, float* dense) {
+    const int k = threadIdx.x;
+    if (k >= D) return;
+    float tot = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+        const float pc = partials[(size_t)c * D + k];
+        tot = c == 0 ? pc : tot + pc;
+    }
+    const float a = sbr_sigmoidf(alpha[k]);
+    dense[k] = tot * (a * (1.0f - a));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: LSTM step, forward.  One workgroup = 16 packed rows of step t; z = [x_t ; h_{t-1}] Wp + b on
+// v_mfma_f32_16x16x4_f32 (accumulator seeded with the bias, k ascending), cell fused in the
+// epilogue.  A tile (16 x 2D) staged through LDS; weights read in the MFMA-fragment packing Wp.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct LstmCfg {
+    static constexpr int UT = D / 16;                 // 16-unit tiles
+    static constexpr int NW = UT < 8 ? UT : 8;        // waves per workgroup
+};
+
+template <int D, int NG>
+__global__ __launch_bounds__(LstmCfg<D>::NW * 64) void lstm_fwd_step_kernel(ModelView m, MbView mb, int t, float* H,
+                                                                            WorkView w) {
+    constexpr int K2 = 2 * D;
+    constexpr int LDA = K2 + 2;
+    constexpr int NW = LstmCfg<D>::NW;
+    __shared__ float As[16 * LDA];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_begin = mb.off[t];
+    const int bt = mb.off[t + 1] - row_begin;
+    const int b0 = blockIdx.x * 16;
+    const int nrows = bt - b0 < 16 ? bt - b0 : 16;
+    const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
+    // stage A = [E[in_idx[row]] ; H[prev row]] for the 16 rows
+    for (int idx = tid; idx < 16 * (K2 / 4); idx += NW * 64) {
+        const int i = idx / (K2 / 4);
+        const int c4 = (idx % (K2 / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nrows) {
+            if (c4 < D) v = ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4);
+            else if (t > 0) v = ld4(H + (size_t)(prev_begin + b0 + i) * D + (c4 - D));
+        }
+        float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
+        dst[0] = make_float2(v.x, v.y);
+        dst[1] = make_float2(v.z, v.w);
+    }
+    __syncthreads();
+    const int j16 = lane & 15;
+    const int kq = lane >> 4;
+    for (int ut = wave; ut < D / 16; ut += NW) {
+        f32x4 acc[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float bv = m.bW[g * D + ut * 16 + j16];
+            acc[g] = (f32x4){bv, bv, bv, bv};
+        }
+        const float* arow = &As[j16 * LDA + kq];
+        const float* wp = m.Wp + ((size_t)(ut * NG) * (K2 / 16) * 64 + lane) * 4;
+#pragma unroll 2
+        for (int S = 0; S < K2 / 16; ++S) {
+            float4 bf[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) bf[g] = ld4(wp + ((size_t)g * (K2 / 16) + S) * 256);
+            const float a0 = arow[16 * S + 0], a1 = arow[16 * S + 4], a2 = arow[16 * S + 8], a3 = arow[16 * S + 12];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[g].w, acc[g], 0, 0, 0);
+        }
+        // epilogue: lane holds rows i = kq*4 + reg, unit u
+        const int u = ut * 16 + j16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = kq * 4 + reg;
+            if (i < nrows) {
+                const size_t r = (size_t)(row_begin + b0 + i);
+                const float cprev = t > 0 ? w.C[(size_t)(prev_begin + b0 + i) * D + u] : 0.0f;
+                float zi, zf, zg, zo;
+                if (NG == 4) { zi = acc[0][reg]; zf = acc[1][reg]; zg = acc[2][reg]; zo = acc[NG - 1][reg]; }
+                else { zi = 0.0f; zf = acc[0][reg]; zg = acc[1][reg]; zo = acc[2][reg]; }
+                float gi, gf, gg, go, cc, hh;
+                sbr_lstm_cell_fwd(zi, zf, zg, zo, cprev, NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
+                float* G = w.G + r * 4 * D;
+                G[u] = gi; G[D + u] = gf; G[2 * D + u] = gg; G[3 * D + u] = go;
+                w.C[r * D + u] = cc;
+                H[r * D + u] = hh;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: LSTM step, backward.  Phase A: cell backward for the 16 rows (all units) -> dz tile in LDS
+// (and in HBM for the dense-gradient GEMM).  Phase B: dxh = dz * W^T on MFMA (accumulator from 0,
+// j ascending); columns < D are dX of this row, columns >= D the recurrent dh for step t-1.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NG>
+__global__ __launch_bounds__(LstmCfg<D>::NW * 64) void lstm_bwd_step_kernel(ModelView m, MbView mb, int t,
+                                                                            BlockView blk, WorkView w) {
+    constexpr int K2 = 2 * D;
+    constexpr int NGD = NG * D;
+    constexpr int LDZ = NGD + 2;
+    constexpr int NW = LstmCfg<D>::NW;
+    __shared__ float Zs[16 * LDZ];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row_begin = mb.off[t];
+    const int bt = mb.off[t + 1] - row_begin;
+    const int bnext = t + 1 < mb.Tm ? mb.off[t + 2] - mb.off[t + 1] : 0;
+    const int b0 = blockIdx.x * 16;
+    const int nrows = bt - b0 < 16 ? bt - b0 : 16;
+    const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
+    for (int idx = tid; idx < 16 * D; idx += NW * 64) {
+        const int i = idx / D;
+        const int u = idx % D;
+        float dz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (i < nrows) {
+            const int b = b0 + i;
+            const size_t r = (size_t)(row_begin + b);
+            const bool last = b >= bnext;
+            const float dh = w.dH[r * D + u] + (last ? 0.0f : w.dHrec[(size_t)b * D + u]);
+            const float dc_in = last ? 0.0f : w.dCrec[(size_t)b * D + u];
+            const float* G = w.G + r * 4 * D;
+            const float cprev = t > 0 ? w.C[(size_t)(prev_begin + b) * D + u] : 0.0f;
+            float dco;
+            sbr_lstm_cell_bwd(dh, dc_in, G[u], G[D + u], G[2 * D + u], G[3 * D + u], w.C[r * D + u], cprev, NG == 3,
+                              &dz[0], &dz[1], &dz[2], &dz[3], &dco);
+            w.dCrec[(size_t)b * D + u] = dco;
+            float* dZ = w.dZ + r * NGD;
+            if (NG == 4) { dZ[u] = dz[0]; dZ[D + u] = dz[1]; dZ[2 * D + u] = dz[2]; dZ[3 * D + u] = dz[3]; }
+            else { dZ[u] = dz[1]; dZ[D + u] = dz[2]; dZ[2 * D + u] = dz[3]; }
+        }
+        if (NG == 4) { Zs[i * LDZ + u] = dz[0]; Zs[i * LDZ + D + u] = dz[1]; Zs[i * LDZ + 2 * D + u] = dz[2]; Zs[i * LDZ + 3 * D + u] = dz[3]; }
+        else { Zs[i * LDZ + u] = dz[1]; Zs[i * LDZ + D + u] = dz[2]; Zs[i * LDZ + 2 * D + u] = dz[3]; }
+    }
+    __syncthreads();
+    const int c16 = lane & 15;
+    const int kq = lane >> 4;
+    for (int ct = wave; ct < K2 / 16; ct += NW) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* arow = &Zs[c16 * LDZ + kq];
+        const float* wp = m.WTp + ((size_t)ct * (NGD / 16) * 64 + lane) * 4;
+#pragma unroll 4
+        for (int S = 0; S < NGD / 16; ++S) {
+            const float4 bf = ld4(wp + (size_t)S * 256);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 0], bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 4], bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 8], bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 12], bf.w, acc, 0, 0, 0);
+        }
+        const int col = ct * 16 + c16;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = kq * 4 + reg;
+            if (i < nrows) {
+                const int b = b0 + i;
+                if (col < D) blk.dX[(size_t)(row_begin + b) * D + col] = acc[reg];
+                else w.dHrec[(size_t)b * D + (col - D)] = acc[reg];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense gradient dW[k][j] = sum_r xh[r][k] dz[r][j] : v_mfma_f32_32x32x2_f32, one wave per 64x64
+// output tile and 1024-row chunk (chain over rows inside the chunk, accumulator from 0).
+// ------------------------------------------------------------------------------------------------
+template <int D, int NG>
+__global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+    constexpr int K2 = 2 * D;
+    constexpr int NGD = NG * D;
+    constexpr int TK = (K2 + 63) / 64;
+    constexpr int TJ = (NGD + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= TK * TJ) return;
+    const int tk = tile / TJ, tj = tile % TJ;
+    const int c = blockIdx.y;
+    const int r0 = c * SBR_DW_CHUNK_ROWS;
+    int r1 = r0 + SBR_DW_CHUNK_ROWS;
+    if (r1 > mb.R) r1 = mb.R;
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+    const int ka[2] = {tk * 64 + l31, tk * 64 + 32 + l31};
+    const int jb[2] = {tj * 64 + l31, tj * 64 + 32 + l31};
+    for (int r = r0; r < r1; r += 2) {
+        const int rr = r + hh;
+        const bool rv = rr < r1;
+        float av[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
+        if (rv) {
+            const uint32_t it = mb.in_idx[rr];
+            const int pr = mb.prev_row[rr];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int k = ka[a];
+                if (k < D) av[a] = m.E[(size_t)it * D + k];
+                else if (k < K2 && pr >= 0) av[a] = blk.H[(size_t)pr * D + (k - D)];
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (jb[b] < NGD) bv[b] = w.dZ[(size_t)rr * NGD + jb[b]];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    float* part = w.partials + (size_t)c * (K2 + 1) * NGD;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = tj * 64 + b * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = tk * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                if (k < K2 && j < NGD) part[(size_t)k * NGD + j] = acc[a][b][q];
+            }
+        }
+}
+
+// bias-gradient row of the partials: chain of plain adds over the rows of the chunk
+__global__ void lstm_dbias_kernel(MbView mb, const float* dZ, int K2, int NGD, float* partials) {
+    const int c = blockIdx.x;
+    const int r0 = c * SBR_DW_CHUNK_ROWS;
+    int r1 = r0 + SBR_DW_CHUNK_ROWS;
+    if (r1 > mb.R) r1 = mb.R;
+    for (int j = threadIdx.x; j < NGD; j += blockDim.x) {
+        float acc = 0.0f;
+        for (int r = r0; r < r1; ++r) acc = acc + dZ[(size_t)r * NGD + j];
+        partials[((size_t)c * (K2 + 1) + K2) * NGD + j] = acc;
+    }
+}
+
+__global__ void dense_reduce_local_kernel(const float* partials, int nchunks, size_t n, float* dense) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = partials[i];
+    for (int c = 1; c < nchunks; ++c) acc = acc + partials[(size_t)c * n + i];
+    dense[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 dense: sum of the device blocks in device order + Adagrad; LSTM weights are re-emitted in the
+// two MFMA-fragment packings (Wp for the forward GEMM, WTp for the BPTT GEMM).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t wp_index(int k, int jcol, int D, int NG) {
+    const int K2 = 2 * D;
+    const int g = jcol / D, u = jcol % D;
+    const int ut = u >> 4, j16 = u & 15;
+    const int S = k >> 4, sub = (k & 15) >> 2, kq = k & 3;
+    const int lane = kq * 16 + j16;
+    return ((((size_t)(ut * NG + g) * (K2 / 16) + S) * 64 + lane) * 4 + sub);
+}
+__device__ __forceinline__ size_t wtp_index(int k, int jcol, int D, int NG) {
+    const int NGD = NG * D;
+    const int ct = k >> 4, c16 = k & 15;
+    const int S = jcol >> 4, sub = (jcol & 15) >> 2, kq = jcol & 3;
+    const int lane = kq * 16 + c16;
+    return ((((size_t)ct * (NGD / 16) + S) * 64 + lane) * 4 + sub);
+}
+
+__global__ void dense_apply_kernel(ModelView m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
+                                   int ndev, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g = reinterpret_cast<const float*>(all_blocks + dense_off)[i];
+    for (int q = 1; q < ndev; ++q) g = g + reinterpret_cast<const float*>(all_blocks + (size_t)q * block_bytes + dense_off)[i];
+    if (m.ng) {
+        const int NGD = m.ng * m.d;
+        const size_t nw = (size_t)2 * m.d * NGD;
+        if (i < nw) {
+            float wv = m.W[i], G = m.Wacc[i];
+            sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+            m.W[i] = wv;
+            m.Wacc[i] = G;
+            const int k = (int)(i / NGD), jcol = (int)(i % NGD);
+            m.Wp[wp_index(k, jcol, m.d, m.ng)] = wv;
+            m.WTp[wtp_index(k, jcol, m.d, m.ng)] = wv;
+        } else {
+            const size_t j = i - nw;
+            float wv = m.bW[j], G = m.bWacc[j];
+            sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+            m.bW[j] = wv;
+            m.bWacc[j] = G;
+        }
+    } else {
+        float wv = m.alpha[i], G = m.alpha_acc[i];
+        sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+        m.alpha[i] = wv;
+        m.alpha_acc[i] = G;
+    }
+}
+
+__global__ void repack_lstm_kernel(ModelView m) {
+    const int NGD = m.ng * m.d;
+    const size_t nw = (size_t)2 * m.d * NGD;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const int k = (int)(i / NGD), jcol = (int)(i % NGD);
+    const float wv = m.W[i];
+    m.Wp[wp_index(k, jcol, m.d, m.ng)] = wv;
+    m.WTp[wtp_index(k, jcol, m.d, m.ng)] = wv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 sparse: (row, source) keys -> radix sort -> per-row in-order reduction + Adagrad
+// ------------------------------------------------------------------------------------------------
+struct DevRows {
+    uint32_t rows[16];
+    uint32_t key_base[16];
+};
+
+__global__ void build_keys_kernel(const uint8_t* all_blocks, uint64_t block_bytes, uint64_t rmax, DevRows dr,
+                                  uint64_t* keys) {
+    const int q = blockIdx.y;
+    const uint32_t R = dr.rows[q];
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
+    const uint32_t* in_idx = hdr + 8;
+    const uint32_t* out_idx = in_idx + rmax;
+    const uint32_t* neg = out_idx + rmax;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        const uint64_t src = (uint64_t)q * 3 * rmax + 3ull * r;
+        uint64_t* k = keys + dr.key_base[q] + 3ull * r;
+        k[0] = ((uint64_t)in_idx[r] << 32) | src;
+        k[1] = ((uint64_t)out_idx[r] << 32) | (src + 1);
+        k[2] = ((uint64_t)neg[r] << 32) | (src + 2);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void sparse_apply_kernel(ModelView m, const uint8_t* all_blocks, uint64_t block_bytes,
+                                                           uint64_t rmax, const uint64_t* keys, uint64_t n) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
+        const uint64_t key = keys[p];
+        const uint32_t row = (uint32_t)(key >> 32);
+        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) continue; /* not the head of its segment */
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+        float gb = 0.0f;
+        bool has_b = false, first = true;
+        for (uint64_t e = p; e < n; ++e) {
+            const uint64_t ke = keys[e];
+            if ((uint32_t)(ke >> 32) != row) break;
+            const uint32_t src = (uint32_t)ke;
+            const uint32_t q = (uint32_t)(src / (3 * rmax));
+            const uint32_t rem = (uint32_t)(src % (3 * rmax));
+            const uint32_t r = rem / 3, kind = rem % 3;
+            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
+            const float* coef = reinterpret_cast<const float*>(hdr + 8 + 3 * rmax);
+            const float* H = reinterpret_cast<const float*>(hdr + 8 + 4 * rmax);
+            const float* dX = H + rmax * (uint64_t)D;
+            const float* srcp = (kind == 0 ? dX : H) + (size_t)r * D + 4 * lg;
+            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -coef[r] : coef[r]);
+            const float4 v = ld4(srcp);
+            if (first) {
+                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
+                first = false;
+            } else {
+                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
+                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
+            }
+            if (kind != 0) {
+                gb = has_b ? gb + scale : scale;
+                has_b = true;
+            }
+        }
+        float* wrow = m.E + (size_t)row * D + 4 * lg;
+        float* arow = m.Eacc + (size_t)row * D + 4 * lg;
+        float4 wv = ld4(wrow), av = ld4(arow);
+        sbr_adagrad(&wv.x, &av.x, gs[0], m.lr, m.l2);
+        sbr_adagrad(&wv.y, &av.y, gs[1], m.lr, m.l2);
+        sbr_adagrad(&wv.z, &av.z, gs[2], m.lr, m.l2);
+        sbr_adagrad(&wv.w, &av.w, gs[3], m.lr, m.l2);
+        st4(wrow, wv);
+        st4(arow, av);
+        if (has_b && lg == 0) {
+            float bv = m.b[row], ba = m.bacc[row];
+            sbr_adagrad(&bv, &ba, gb, m.lr, m.l2);
+            m.b[row] = bv;
+            m.bacc[row] = ba;
+        }
+    }
+}
+
+__global__ void accumulate_loss_kernel(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
+                                       unsigned long long* ex_acc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double l = *loss_acc;
+    unsigned long long e = *ex_acc;
+    for (int q = 0; q < ndev; ++q) {
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
+        l += *reinterpret_cast<const double*>(hdr + 4);
+        e += *reinterpret_cast<const unsigned long long*>(hdr + 6);
+    }
+    *loss_acc = l;
+    *ex_acc = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prediction side: bias + chain-order dot (≙ an f32 MFMA accumulation over k)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ float chain_dot(const float* __restrict__ h, const float* __restrict__ e) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < D; k4 += 4) {
+        const float4 v = ld4(e + k4);
+        acc = sbr_fma(h[k4 + 0], v.x, acc);
+        acc = sbr_fma(h[k4 + 1], v.y, acc);
+        acc = sbr_fma(h[k4 + 2], v.z, acc);
+        acc = sbr_fma(h[k4 + 3], v.w, acc);
+    }
+    return acc;
+}
+
+template <int D>
+__global__ void predict_kernel(ModelView m, const float* user, const uint32_t* items, uint64_t n, float* out) {
+    __shared__ float hs[D];
+    for (int k = threadIdx.x; k < D; k += blockDim.x) hs[k] = user[k];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t it = items[i];
+    out[i] = m.b[it] + chain_dot<D>(hs, m.E + (size_t)it * D);
+}
+
+// One workgroup per test user.  rank = #{i : pred_i >= pred_test} with all history items masked
+// to f32::MIN (evaluation.rs:30-41): counted over all items, then corrected for the (unique)
+// history items.
+template <int D>
+__global__ __launch_bounds__(256) void rank_kernel(ModelView m, const float* reps, const int* rep_row, const uint32_t* test_item,
+                                                   const uint32_t* test_in_hist, const uint64_t* hist_ptr,
+                                                   const uint32_t* hist_items, uint32_t* ranks, uint32_t* nonfinite_flag) {
+    __shared__ float hs[D];
+    __shared__ int wave_cnt[4];
+    const int u = blockIdx.x;
+    const float* h = reps + (size_t)rep_row[u] * D;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) hs[k] = h[k];
+    __syncthreads();
+    const uint32_t ti = test_item[u];
+    const float ts = test_in_hist[u] ? SBR_F32_MIN : m.b[ti] + chain_dot<D>(hs, m.E + (size_t)ti * D);
+    int cnt = 0;
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < m.num_items; i += blockDim.x) {
+        const float s = m.b[i] + chain_dot<D>(hs, m.E + (size_t)i * D);
+        if (!(s - s == 0.0f)) bad = true; /* non-finite */
+        if (s >= ts) ++cnt;
+    }
+    for (uint64_t e = hist_ptr[u] + threadIdx.x; e < hist_ptr[u + 1]; e += blockDim.x) {
+        const uint32_t i = hist_items[e];
+        const float s = m.b[i] + chain_dot<D>(hs, m.E + (size_t)i * D);
+        if (s >= ts) --cnt;
+        if (SBR_F32_MIN >= ts) ++cnt;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(nonfinite_flag, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) ranks[u] = (uint32_t)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// numerics self-tests
+// ------------------------------------------------------------------------------------------------
+__global__ void selftest_math_kernel(const float* x, float* e, float* s, float* t, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    e[i] = sbr_expf(x[i]);
+    s[i] = sbr_sigmoidf(x[i]);
+    t[i] = sbr_tanhf(x[i]);
+}
+template <int D>
+__global__ void selftest_dot_tree_kernel(const float* x, const float* y, uint64_t nrows, float* out) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t r = wave * GPW + grp;
+    const uint64_t rr = r < nrows ? r : nrows - 1;
+    const float v = group_allreduce<L>(dot4(ld4(x + rr * D + 4 * lg), ld4(y + rr * D + 4 * lg)));
+    if (r < nrows && lg == 0) out[r] = v;
+}
+// C[16][16] = c0 + A[16][K] B[K][16] by one wave on v_mfma_f32_16x16x4_f32
+__global__ void selftest_mfma_chain_kernel(const float* a, const float* b, const float* c0, int K, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, kq = lane >> 4;
+    f32x4 acc;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) acc[reg] = c0[(kq * 4 + reg) * 16 + j];
+    for (int k0 = 0; k0 < K; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j * K + k0 + kq], b[(k0 + kq) * 16 + j], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(kq * 4 + reg) * 16 + j] = acc[reg];
+}
+// C[32][32] = A[32][K] B[K][32] by one wave on v_mfma_f32_32x32x2_f32 (rows of `out` follow the
+// dense-gradient kernel's register map)
+__global__ void selftest_mfma32_chain_kernel(const float* a, const float* b, int K, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int l31 = lane & 31, hh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[l31 * K + k0 + hh], b[(k0 + hh) * 32 + l31], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((q & 3) + 8 * (q >> 2) + 4 * hh) * 32 + l31] = acc[q];
+}
+
+// ================================================================================================
+// launchers
+// ================================================================================================
+#define DISPATCH_D(d, CALL)                  \
+    switch (d) {                             \
+        case 16: { constexpr int DD = 16; CALL; } break;   \
+        case 32: { constexpr int DD = 32; CALL; } break;   \
+        case 64: { constexpr int DD = 64; CALL; } break;   \
+        case 128: { constexpr int DD = 128; CALL; } break; \
+        case 256: { constexpr int DD = 256; CALL; } break; \
+        default: break;                      \
+    }
+
+static inline int grid_for_groups(long long groups, int groups_per_block) {
+    long long g = (groups + groups_per_block - 1) / groups_per_block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
+                              const int* off_host, hipStream_t s) {
+    if (mb.R == 0) return;
+    if (m.ng == 0) {
+        DISPATCH_D(m.d, {
+            const int gpb = 4 * (64 / (DD / 4));
+            hipLaunchKernelGGL((ewma_forward_kernel<DD>), dim3(grid_for_groups(mb.B, gpb)), dim3(256), 0, s, m, mb, H);
+        });
+        return;
+    }
+    for (int t = 0; t < tm_host; ++t) {
+        DISPATCH_D(m.d, {
+            const int nblk = (off_host[t + 1] - off_host[t] + 15) / 16; /* sequences alive at step t */
+            if (m.ng == 4)
+                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 4>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, H, w);
+            else
+                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 3>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, H, w);
+        });
+    }
+}
+
+void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                  int rows_host, hipStream_t s) {
+    hipLaunchKernelGGL(block_header_init, dim3(1), dim3(1), 0, s, blk.header, rows_host);
+    if (rows_host == 0) return;
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((score_kernel<DD>), dim3(grid_for_groups(rows_host, gpb)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+    });
+}
+
+void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                               int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s) {
+    if (rows_host == 0) {
+        const size_t n = m.ng ? (size_t)(2 * m.d + 1) * m.ng * m.d : (size_t)m.d;
+        (void)hipMemsetAsync(blk.dense, 0, n * sizeof(float), s);
+        return;
+    }
+    if (m.ng == 0) {
+        DISPATCH_D(m.d, {
+            const int gpb = 4 * (64 / (DD / 4));
+            hipLaunchKernelGGL((ewma_backward_kernel<DD>), dim3(grid_for_groups(b_host, gpb)), dim3(256), 0, s, m, mb, blk, w);
+        });
+        const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
+        hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w.dab, b_host, m.d, w.partials);
+        hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w.partials, nch, m.d, m.alpha, blk.dense);
+        return;
+    }
+    for (int t = tm_host - 1; t >= 0; --t) {
+        DISPATCH_D(m.d, {
+            const int nblk = (off_host[t + 1] - off_host[t] + 15) / 16;
+            if (m.ng == 4)
+                hipLaunchKernelGGL((lstm_bwd_step_kernel<DD, 4>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, blk, w);
+            else
+                hipLaunchKernelGGL((lstm_bwd_step_kernel<DD, 3>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, blk, w);
+        });
+    }
+    const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
+    const int K2 = 2 * m.d, NGD = m.ng * m.d;
+    const int tiles = ((K2 + 63) / 64) * ((NGD + 63) / 64);
+    DISPATCH_D(m.d, {
+        if (m.ng == 4)
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3((tiles + 3) / 4, nch), dim3(256), 0, s, m, mb, blk, w);
+        else
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3((tiles + 3) / 4, nch), dim3(256), 0, s, m, mb, blk, w);
+    });
+    hipLaunchKernelGGL(lstm_dbias_kernel, dim3(nch), dim3(256), 0, s, mb, w.dZ, K2, NGD, w.partials);
+    const size_t n = (size_t)(K2 + 1) * NGD;
+    hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
+}
+
+void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
+                        int ndev, hipStream_t s) {
+    const size_t n = m.ng ? (size_t)(2 * m.d + 1) * m.ng * m.d : (size_t)m.d;
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, all_blocks, block_bytes, dense_off, ndev, n);
+}
+
+void launch_repack_lstm(const ModelView& m, hipStream_t s) {
+    if (!m.ng) return;
+    const size_t nw = (size_t)2 * m.d * m.ng * m.d;
+    hipLaunchKernelGGL(repack_lstm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, m);
+}
+
+size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(nullptr, bytes, nullptr, nullptr, max_entries, 0, key_bits, 0, false);
+    return bytes;
+}
+
+void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                         size_t sort_temp_bytes, int key_bits, hipStream_t s) {
+    DevRows dr;
+    uint64_t total = 0;
+    uint32_t maxr = 0;
+    for (int q = 0; q < 16; ++q) { dr.rows[q] = 0; dr.key_base[q] = 0; }
+    for (int q = 0; q < ndev; ++q) {
+        dr.rows[q] = rows_of_device_host[q];
+        dr.key_base[q] = (uint32_t)total;
+        total += 3ull * rows_of_device_host[q];
+        if (rows_of_device_host[q] > maxr) maxr = rows_of_device_host[q];
+    }
+    if (total == 0) return;
+    hipLaunchKernelGGL(build_keys_kernel, dim3(grid_for_groups(maxr, 256), ndev), dim3(256), 0, s, all_blocks, block_bytes, rmax, dr, keys);
+    (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((sparse_apply_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, m, all_blocks, block_bytes, rmax, keys_sorted, total);
+    });
+}
+
+void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
+                            unsigned long long* ex_acc, hipStream_t s) {
+    hipLaunchKernelGGL(accumulate_loss_kernel, dim3(1), dim3(64), 0, s, all_blocks, block_bytes, ndev, loss_acc, ex_acc);
+}
+
+void launch_predict(const ModelView& m, const float* user, const uint32_t* items, uint64_t n, float* out, hipStream_t s) {
+    if (n == 0) return;
+    DISPATCH_D(m.d, { hipLaunchKernelGGL((predict_kernel<DD>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, user, items, n, out); });
+}
+
+void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint32_t num_users, const uint32_t* test_item,
+                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, uint32_t* ranks,
+                 uint32_t* nonfinite_flag, hipStream_t s) {
+    if (num_users == 0) return;
+    DISPATCH_D(m.d, {
+        hipLaunchKernelGGL((rank_kernel<DD>), dim3(num_users), dim3(256), 0, s, m, reps, rep_row, test_item, test_in_hist, hist_ptr, hist_items, ranks, nonfinite_flag);
+    });
+}
+
+void launch_selftest_math(const float* x, float* out_exp, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out_exp, out_sig, out_tanh, n);
+}
+void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s) {
+    DISPATCH_D(d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((selftest_dot_tree_kernel<DD>), dim3((unsigned)((nrows + gpb - 1) / gpb)), dim3(256), 0, s, x, y, nrows, out);
+    });
+}
+void launch_selftest_mfma_chain(const float* a, const float* b, const float* c0, int k, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(selftest_mfma_chain_kernel, dim3(1), dim3(64), 0, s, a, b, c0, k, out);
+}
+void launch_selftest_mfma32_chain(const float* a, const float* b, int k, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(selftest_mfma32_chain_kernel, dim3(1), dim3(64), 0, s, a, b, k, out);
+}
+
+}  // namespace sbr

@@ -209,7 +209,7 @@ SBR_HD void sbr_lstm_cell_bwd(float dh, float dc_in, float i, float f, float g, 
 }
 
 /* ---- host-side index generators (never run on the device) ----------------------------------- */
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if 1
 /* Marsaglia xorshift128 — the algorithm of rand 0.5's XorShiftRng as recalled in SURVEY.md
  * App. C (seed = 16 bytes little endian, all-zero seed replaced).  The reference's exact
  * streams are unpinned (no rand source here), so this is the engine's own documented generator. */

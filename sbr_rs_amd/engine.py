@@ -1,0 +1,200 @@
+"""Thin object layer over the C-ABI (include/sbr_hip.h).  Mirrors oracle/oracle.py's shape so
+parity tests read symmetrically, but talks only to libsbr_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._abi import NUM_KERNEL_FAMILIES, KernelFamily, SbrHparams, Status
+from .errors import EngineError, FittingError, PredictionError
+
+
+def _check(st: int):
+    if st == Status.OK:
+        return
+    msg = _lib.load().sbr_status_string(st).decode()
+    if st == Status.NO_INTERACTIONS:
+        raise FittingError.NoInteractions(msg)
+    if st == Status.INVALID_PREDICTION:
+        raise PredictionError.InvalidPredictionValue(msg)
+    raise EngineError(Status(st), msg)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_info():
+    L = _lib.load()
+    name = C.create_string_buffer(64)
+    cus, hbm = C.c_uint32(), C.c_uint64()
+    _check(L.sbr_device_info(name, 64, C.byref(cus), C.byref(hbm)))
+    return name.value.decode(), cus.value, hbm.value
+
+
+def set_device(ordinal: int):
+    _check(_lib.load().sbr_set_device(int(ordinal)))
+
+
+_DBG_U32 = {1, 7, 8, 9}
+
+
+class FitPlan:
+    def __init__(self, model: "Model", user_ptr, item_ids):
+        self.model = model
+        self._L = _lib.load()
+        self._up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        self._it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(self._L.sbr_fit_begin(model._h, _ptr(self._up), _ptr(self._it), len(self._up) - 1, C.byref(h)))
+        self._h = h
+
+    def epoch_prepare(self) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_fit_epoch_prepare(self._h, C.byref(n)))
+        return n.value
+
+    def minibatch_rows(self, mb: int) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_fit_minibatch_rows(self._h, mb, C.byref(n)))
+        return n.value
+
+    def step(self, mb: int):
+        _check(self._L.sbr_fit_step(self._h, mb))
+
+    def exchange_bytes(self) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_fit_exchange_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def step_local(self, mb: int, device_ptr: int = 0):
+        _check(self._L.sbr_fit_step_local(self._h, mb, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def step_apply(self, mb: int, device_ptr_all: int = 0):
+        _check(self._L.sbr_fit_step_apply(self._h, mb, C.c_void_p(device_ptr_all) if device_ptr_all else None))
+
+    def end(self):
+        loss, ex = C.c_float(), C.c_uint64()
+        _check(self._L.sbr_fit_end(self._h, C.byref(loss), C.byref(ex)))
+        return loss.value, ex.value
+
+    def debug_fetch(self, which: int, rows: int) -> np.ndarray:
+        d = self.model.dim
+        which = int(which)
+        if which in (0, 4, 5):
+            out = np.zeros((rows, d), dtype=np.float32)
+        elif which == 6:
+            out = np.zeros(self.model.dense_count(), dtype=np.float32)
+        else:
+            out = np.zeros(rows, dtype=np.uint32 if which in _DBG_U32 else np.float32)
+        _check(self._L.sbr_fit_debug_fetch(self._h, which, _ptr(out), out.nbytes))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sbr_fit_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Model:
+    """Owns one sbr_model handle (device-resident parameters)."""
+
+    def __init__(self, hp: SbrHparams):
+        self._L = _lib.load()
+        self.hp = hp
+        self.dim = int(hp.embedding_dim)
+        h = C.c_void_p()
+        _check(self._L.sbr_model_create(C.byref(hp), C.byref(h)))
+        self._h = h
+
+    def dense_count(self) -> int:
+        d = self.dim
+        ng = {0: 4, 1: 3, 2: 0}[int(self.hp.model)]
+        return (2 * d + 1) * ng * d if ng else d
+
+    def param_count(self, which: int) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_model_param_count(self._h, int(which), C.byref(n)))
+        return n.value
+
+    def get_param(self, which: int) -> np.ndarray:
+        out = np.zeros(self.param_count(which), dtype=np.float32)
+        if out.size:
+            _check(self._L.sbr_model_get_param(self._h, int(which), _ptr(out), out.size))
+        return out
+
+    def set_param(self, which: int, values):
+        values = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        _check(self._L.sbr_model_set_param(self._h, int(which), _ptr(values), values.size))
+
+    def global_epoch(self) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_model_get_epoch(self._h, C.byref(n)))
+        return n.value
+
+    def set_stream(self, hip_stream_ptr: int):
+        _check(self._L.sbr_model_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        _check(self._L.sbr_model_synchronize(self._h))
+
+    def timing_enable(self, on: bool = True):
+        _check(self._L.sbr_model_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms = (C.c_double * NUM_KERNEL_FAMILIES)()
+        n = (C.c_uint64 * NUM_KERNEL_FAMILIES)()
+        _check(self._L.sbr_model_timing_read(self._h, ms, n))
+        return {KernelFamily(i).name: (ms[i], n[i]) for i in range(NUM_KERNEL_FAMILIES)}
+
+    def fit(self, user_ptr, item_ids) -> float:
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        loss = C.c_float()
+        _check(self._L.sbr_model_fit(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
+        return loss.value
+
+    def fit_begin(self, user_ptr, item_ids) -> FitPlan:
+        return FitPlan(self, user_ptr, item_ids)
+
+    def user_representation(self, item_ids) -> np.ndarray:
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        out = np.zeros(self.dim, dtype=np.float32)
+        _check(self._L.sbr_user_representation(self._h, _ptr(it), it.size, _ptr(out)))
+        return out
+
+    def predict(self, user, item_ids) -> np.ndarray:
+        user = np.ascontiguousarray(user, dtype=np.float32)
+        if user.size != self.dim:
+            raise ValueError("user representation has the wrong dimension")
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        out = np.zeros(it.size, dtype=np.float32)
+        _check(self._L.sbr_predict(self._h, _ptr(user), _ptr(it), it.size, _ptr(out)))
+        return out
+
+    def mrr_score(self, user_ptr, item_ids):
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        ranks = np.zeros(max(len(up) - 1, 1), dtype=np.uint32)
+        mrr, n = C.c_float(), C.c_uint64()
+        _check(self._L.sbr_mrr_score(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(mrr), _ptr(ranks), C.byref(n)))
+        return mrr.value, ranks[: n.value].copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sbr_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,69 @@
+"""GPU: the numerics contract (sbr_rs_amd/csrc/sbr_numerics.h) evaluates to the same bits on the
+gfx950 device as in the CPU oracle.  These are the premises every parity claim rests on:
+IEEE +,*,/,sqrt,fma on both sides; the wave butterfly equals the oracle's tree; an f32 MFMA
+accumulation equals a k-ascending fmaf chain."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from sbr_rs_amd import _lib
+
+    return _lib.load()
+
+
+def test_math_bitwise(L, oracle_lib):
+    rs = np.random.RandomState(1)
+    x = np.concatenate([
+        rs.uniform(-100, 100, 200000), rs.uniform(-1, 1, 200000), rs.normal(0, 1e-3, 50000),
+        np.array([0.0, -0.0, 0.625, -0.625, 0.6249999, 88.0, -87.0, 1e-30, -1e-30, 1e30, -1e30, 87.9999, -86.9999]),
+    ]).astype(np.float32)
+    n = x.size
+    e, s, t = (np.zeros(n, np.float32) for _ in range(3))
+    assert L.sbr_selftest_math(_p(x), n, _p(e), _p(s), _p(t)) == 0
+    ce = np.array([oracle_lib.orc_expf(float(v)) for v in x], dtype=np.float32)
+    cs = np.array([oracle_lib.orc_sigmoidf(float(v)) for v in x], dtype=np.float32)
+    ct = np.array([oracle_lib.orc_tanhf(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(e.view(np.uint32), ce.view(np.uint32))
+    assert np.array_equal(s.view(np.uint32), cs.view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), ct.view(np.uint32))
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128, 256])
+def test_dot_tree_bitwise(L, oracle_lib, d):
+    rs = np.random.RandomState(d)
+    n = 1000 + d  # not a multiple of the rows-per-wave
+    x = rs.normal(0, 1, (n, d)).astype(np.float32)
+    y = rs.normal(0, 1, (n, d)).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    assert L.sbr_selftest_dot_tree(_p(x), _p(y), d, n, _p(out)) == 0
+    ref = np.array([oracle_lib.orc_dot_tree(_p(x[i]), _p(y[i]), d) for i in range(n)], dtype=np.float32)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [4, 64, 512, 2048])
+def test_mfma_is_fma_chain(L, k):
+    rs = np.random.RandomState(k)
+    a = rs.normal(0, 1, (16, k)).astype(np.float32)
+    b = rs.normal(0, 1, (k, 16)).astype(np.float32)  # asymmetric on purpose
+    c0 = rs.normal(0, 1, (16, 16)).astype(np.float32)
+    a32 = rs.normal(0, 1, (32, k)).astype(np.float32)
+    b32 = rs.normal(0, 1, (k, 32)).astype(np.float32)
+    out = np.zeros((16, 16), np.float32)
+    out32 = np.zeros((32, 32), np.float32)
+    assert L.sbr_selftest_mfma(_p(a), _p(b), _p(c0), k, _p(out), _p(a32), _p(b32), _p(out32)) == 0
+    ref = oracle.fma_chain_gemm(a, b, c0)
+    ref32 = oracle.fma_chain_gemm(a32, b32)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(out32.view(np.uint32), ref32.view(np.uint32))

@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py — train interactions/sec of the sequence-recommender hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver through torch.distributed.run, one rank per GPU)
+
+A *step* is one optimiser step of the hot path: one minibatch of `--batch-sequences` synthetic
+subsequences per GPU through forward (embedding gather + LSTM), WARP negative sampling + loss,
+BPTT and the Adagrad dense + sparse update (fit_sequence_model's inner loop,
+/root/reference/src/models/sequence_model.rs:111-169).  An *interaction* is one (input, target)
+pair = one loss term (`examples += n-1`, sequence_model.rs:158).
+
+Workload (default): BASELINE.json configs[2] — synthetic 100K users x 1M items, seq_len <= 64,
+embedding_dim 128, LSTM(Normal) + WARP + Adagrad, the largest single-GPU configuration and the one
+the north-star HBM-roofline target is quoted on.  (configs[1], MovieLens-100K, is 1.3K
+subsequences — a parity/MRR case, run here untimed for the `test_mrr` field and in
+tests/test_parity_gpu.py.)  With N GPUs the user count scales with N (weak scaling): users are
+sharded, every GPU runs its own partition, and one all-gather per step (RCCL) exchanges the
+devices' blocks.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the gather + WARP-score kernel against the
+HBM roofline; `kernels` lists every kernel family's measured time; `cpu_baseline` is the CPU
+oracle (a scalar C port of the same algorithm; the Rust reference cannot be built here) timed on
+the host, on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling 6290
+FP32_MFMA_PEAK_TF = 157.3  # dense f32-input MFMA peak
+
+
+def synthetic_csr(num_users: int, num_items: int, max_len: int, seed: int = 42):
+    """BASELINE.md §3 generator: len_u ~ U{3..max_len}, items ~ U[0, num_items) (pure-roofline
+    variant: no cache reuse), timestamps = position."""
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(3, max_len + 1, size=num_users).astype(np.uint64)
+    ptr = np.zeros(num_users + 1, dtype=np.uint64)
+    ptr[1:] = np.cumsum(lens)
+    items = rs.randint(0, num_items, size=int(ptr[-1])).astype(np.uint32)
+    return ptr, items
+
+
+def make_hp(args, world, rank, model_kind, loss, num_items, epochs=1, batch=None, dim=None, max_len=None):
+    from sbr_rs_amd._abi import make_hparams
+
+    return make_hparams(num_items, max_len or args.max_len, dim or args.dim, 0.16, 0.0004, model_kind, loss, 0, 1,
+                        bytes([42] * 16), epochs, world, rank, batch or args.batch_sequences)
+
+
+def cpu_baseline(args):
+    """The oracle (kind "port") on a bounded sample: one minibatch worth of users of the same
+    generator, same model/hyper-parameters, one epoch; fit time only."""
+    from oracle.oracle import OracleModel
+
+    users = min(args.cpu_users, args.users)
+    ptr, items = synthetic_csr(users, args.items, args.max_len, seed=43)
+    hp = make_hp(args, 1, 0, 0, 2, args.items, epochs=1, batch=min(args.batch_sequences, users))
+    m = OracleModel(hp)
+    plan = m.fit_begin(ptr, items)
+    nmb = plan.epoch_prepare()
+    rows = sum(plan.minibatch_rows(mb) for mb in range(nmb))
+    t0 = time.perf_counter()
+    for mb in range(nmb):
+        plan.step(mb)
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt, "unit": "interactions/s", "cores": 1, "kind": "port",
+            "sample": f"{users} users of the same generator ({rows} interactions, {nmb} minibatch(es)), "
+                      f"LSTM+WARP dim {args.dim}, 1 epoch, single-thread C oracle, {dt:.1f} s",
+            "host_cores_available": os.cpu_count()}
+
+
+def movielens_mrr():
+    """BASELINE.json configs[1] (untimed): MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad,
+    10 epochs under the reference protocol (lstm.rs:427-448, 498-520)."""
+    from helpers import movielens_protocol
+    from sbr_rs_amd._abi import make_hparams
+    from sbr_rs_amd.engine import Model
+
+    data, train, test, rng = movielens_protocol()
+    hp = make_hparams(data.num_items(), 128, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, 16)
+    m = Model(hp)
+    t0 = time.perf_counter()
+    loss = m.fit(train.user_pointers, train.item_ids)
+    dt = time.perf_counter() - t0
+    mrr, ranks = m.mrr_score(test.user_pointers, test.item_ids)
+    return {"config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, batch_sequences 16",
+            "test_mrr": mrr, "test_users": int(len(ranks)), "fit_loss": loss, "fit_seconds": dt,
+            "train_interactions_per_s": 10 * (len(train.item_ids)) / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--users", type=int, default=100_000, help="users per GPU")
+    ap.add_argument("--items", type=int, default=1_000_000)
+    ap.add_argument("--max-len", type=int, default=64)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch-sequences", type=int, default=4096)
+    ap.add_argument("--model", choices=["lstm", "lstm-coupled", "ewma"], default="lstm")
+    ap.add_argument("--loss", choices=["bpr", "hinge", "warp"], default="warp")
+    ap.add_argument("--cpu-users", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mrr", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    from sbr_rs_amd import engine
+    from sbr_rs_amd._abi import Debug
+    from sbr_rs_amd.distributed import HipBackend
+
+    engine.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    model_kind = {"lstm": 0, "lstm-coupled": 1, "ewma": 2}[args.model]
+    loss_kind = {"bpr": 0, "hinge": 1, "warp": 2}[args.loss]
+    total_users = args.users * world
+    ptr, items = synthetic_csr(total_users, args.items, args.max_len)
+    hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
+    model = engine.Model(hp)
+    backend = HipBackend(model, (ptr, items))
+    plan = backend.plan
+    gathered = backend.gathered_buffer(world) if world > 1 else None
+
+    state = {"nmb": backend.epoch_prepare(), "mb": 0, "reprepared_in_timed_region": 0}
+
+    def one_step(timed: bool) -> int:
+        if state["mb"] >= state["nmb"]:
+            state["nmb"] = backend.epoch_prepare()  # next epoch: reshuffle + repack + upload
+            state["mb"] = 0
+            if timed:
+                state["reprepared_in_timed_region"] += 1
+        mb = state["mb"]
+        rows = plan.minibatch_rows(mb)
+        local = backend.local_block(mb)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, local)
+            backend.apply(mb, gathered)
+        else:
+            backend.apply(mb, local)
+        state["mb"] += 1
+        return rows
+
+    def sync():
+        model.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    sync()
+    model.timing_enable(True)
+    model.timing_read()  # reset
+    rows_timed = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows_timed += one_step(True)
+    model.synchronize()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rows_timed], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rows_total = int(r.item())
+        dist.barrier()
+    else:
+        rows_total = rows_timed
+    timing = model.timing_read()
+    model.timing_enable(False)
+
+    if rank == 0:
+        d, ng = args.dim, {0: 4, 1: 3, 2: 0}[model_kind]
+        last_rows = plan.minibatch_rows(state["mb"] - 1)
+        tries = plan.debug_fetch(Debug.TRIES, last_rows)
+        k_mean = float(tries.mean()) if last_rows else 1.0
+        rows_per_launch = rows_timed / max(args.steps, 1)
+        kernels = {}
+        for name, (ms, n) in timing.items():
+            if n:
+                kernels[name] = {"ms_total": ms, "launches": int(n), "ms_per_launch": ms / n}
+        # roofline of the gather + WARP-score kernel: algorithmic bytes per packed row:
+        # (2+k)*4d for h, the positive row and k negative rows, (1+k)*4 for their biases
+        score = kernels.get("SCORE")
+        roofline = None
+        if score:
+            bytes_per_row = (2 + k_mean) * 4 * d + (1 + k_mean) * 4
+            bytes_per_launch = bytes_per_row * rows_per_launch
+            achieved = bytes_per_launch / (score["ms_per_launch"] * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)", "bound": "hbm",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
+                        "avg_launch_ms": score["ms_per_launch"]}
+        mfma = []
+        if ng:
+            for fam, flops_per_row in (("RECURRENT_FWD", 2 * 2 * d * ng * d), ("RECURRENT_BWD", 2 * 2 * (2 * d * ng * d))):
+                if fam in kernels:
+                    tf = flops_per_row * rows_timed / (kernels[fam]["ms_total"] * 1e-3) / 1e12
+                    mfma.append({"kernel": fam, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
+                                 "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+                                 "note": "BWD = BPTT step GEMMs + dense-gradient GEMM; includes inter-launch gaps"})
+        out = {
+            "metric": "train interactions/sec", "value": rows_total / elapsed, "unit": "interactions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[2]: synthetic {args.users} users/GPU x {args.items} items, "
+                                   f"seq_len<={args.max_len}, dim {args.dim}, {args.model}+{args.loss}, Adagrad lr 0.16 l2 4e-4",
+                       "users_per_gpu": args.users, "items": args.items, "max_len": args.max_len, "dim": args.dim,
+                       "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": "uniform",
+                       "parallelism": f"user-sharded dp{world}" if world > 1 else "single device"},
+            "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
+            "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_mrr:
+            try:
+                out["test_mrr"] = movielens_mrr()
+            except Exception as e:  # the throughput line must survive a fixture problem
+                out["test_mrr"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    backend.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/sbr_hip.h declares; without a GPU
+the engine refuses to run (no CPU fallback) instead of computing anything."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import LOSS_HINGE, hparams
+from sbr_rs_amd import _lib
+from sbr_rs_amd._abi import ModelKind, SbrHparams, Status
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_in_header():
+    text = open(os.path.join(ROOT, "include", "sbr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sbr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from sbr_rs_amd import build
+
+        build.build(verbose=False)
+    L = _lib.load()
+    declared = _declared_in_header()
+    assert len(declared) >= 30
+    assert sorted(_lib.DECLARED_SYMBOLS) == declared, "loader table and header disagree"
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sbr_abi_version() == 1
+    assert b"No interactions" in L.sbr_status_string(int(Status.NO_INTERACTIONS))
+
+
+def test_hparams_struct_layout_matches_header():
+    assert C.sizeof(SbrHparams) == 68
+    assert SbrHparams.seed.offset == 36 and SbrHparams.batch_sequences.offset == 64
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly():
+    from sbr_rs_amd.engine import Model
+    from sbr_rs_amd.errors import EngineError
+
+    with pytest.raises(EngineError) as e:
+        Model(hparams(10, 8, 16, int(ModelKind.EWMA), LOSS_HINGE))
+    assert e.value.status == Status.NO_DEVICE
+    x = np.zeros(4, np.float32)
+    assert _lib.load().sbr_selftest_math(x.ctypes.data_as(C.c_void_p), 4, None, None, None) == Status.NO_DEVICE
+
+
+def test_python_surface_mirrors_reference_names():
+    import sbr_rs_amd as sbr
+
+    h = sbr.lstm.Hyperparameters.new(100, 32)
+    for setter in ("learning_rate", "l2_penalty", "embedding_dim", "num_epochs", "loss", "lstm_variant", "num_threads",
+                   "parallelism", "rng", "from_seed", "optimizer", "build"):
+        assert callable(getattr(h, setter)), setter
+    assert callable(sbr.lstm.Hyperparameters.random) and callable(sbr.ewma.Hyperparameters.random)
+    assert not hasattr(sbr.ewma.Hyperparameters.new(10, 8), "lstm_variant")
+    for name in ("user_based_split", "train_test_split", "Interaction", "Interactions", "CompressedInteractions"):
+        assert hasattr(sbr.data, name)
+    assert callable(sbr.evaluation.mrr_score)
+    assert issubclass(sbr.FittingError.NoInteractions, sbr.FittingError)
+    assert issubclass(sbr.PredictionError.InvalidPredictionValue, sbr.PredictionError)
+    r = sbr.lstm.Hyperparameters.random(50, sbr.XorShiftRng.from_seed(bytes([1] * 16)))
+    assert 16 <= r._item_embedding_dim <= 128 and 16 <= r._max_sequence_length <= 128

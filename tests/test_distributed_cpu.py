@@ -1,0 +1,101 @@
+"""World-size-2 test of the multi-device path on CPU (gloo): the distributed driver
+(sbr_rs_amd/distributed.run_fit) is run by two processes, the oracle computing each device's
+local half-step; the replicas must end bit-identical to each other and to the single-process
+oracle emulating both devices (≙ Parallelism::Synchronous with num_threads = 2,
+/root/reference/src/models/sequence_model.rs:91-98, 163-166; reference test lstm.rs:474-496)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import LOSS_HINGE, LOSS_WARP, hparams, synthetic_interactions
+from oracle.oracle import OracleModel
+from sbr_rs_amd._abi import ModelKind, Param
+from sbr_rs_amd.distributed import run_fit
+
+
+class OracleBackend:
+    def __init__(self, model: OracleModel, rank: int, ptr, items):
+        self.rank = rank
+        self.plan = model.fit_begin(ptr, items)
+        self.block_bytes = self.plan.exchange_bytes()
+
+    def epoch_prepare(self):
+        return self.plan.epoch_prepare()
+
+    def local_block(self, mb):
+        return torch.from_numpy(self.plan.step_local(mb, device=self.rank))
+
+    def gathered_buffer(self, world):
+        return torch.zeros(world * self.block_bytes, dtype=torch.uint8)
+
+    def apply(self, mb, gathered):
+        self.plan.step_apply(gathered.numpy())
+
+    def end(self):
+        return self.plan.end()
+
+
+PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.EWMA_ALPHA],
+          0: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B]}
+
+
+def _worker(rank, world, port, kind, loss, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
+        hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank)
+        m = OracleModel(hp)
+        loss_v, ex = run_fit(OracleBackend(m, rank, ptr, items), 2, world)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v, ex=ex,
+                 **{p.name: m.get_param(p) for p in PARAMS[kind]})
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("kind,loss", [(int(ModelKind.EWMA), LOSS_WARP), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE)])
+def test_two_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # single process, both devices emulated
+    ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
+    hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=0)
+    ref = OracleModel(hp)
+    ref_loss = ref.fit(ptr, items)
+    for p in PARAMS[kind]:
+        a, b, c = r0[p.name], r1[p.name], ref.get_param(p)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"replicas diverged on {p.name}"
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"distributed != single-process on {p.name}"
+    assert float(r0["loss"]) == float(r1["loss"]) == pytest.approx(ref_loss, rel=1e-6)
+    assert int(r0["ex"]) == int(r1["ex"]) > 0
+
+
+def test_partitioning_drops_remainder_and_shards_disjointly(oracle_lib):
+    """sequence_model.rs:91-98: len / num_threads per partition, remainder never trained."""
+    ptr, items = synthetic_interactions(41, 60, 9, seed=2)
+    nseq1 = None
+    rows = {}
+    for ndev in (1, 2, 3):
+        hp = hparams(60, 9, 16, int(ModelKind.EWMA), LOSS_HINGE, epochs=1, B=1000, ndev=ndev)
+        m = OracleModel(hp)
+        plan = m.fit_begin(ptr, items)
+        assert plan.epoch_prepare() == 1
+        rows[ndev] = [plan.minibatch_rows(0, device=q) for q in range(ndev)]
+    # B=1000 => one minibatch per device holding its whole partition; partitions are equal-sized
+    # in sequences, so total rows can only shrink when the remainder is dropped
+    assert sum(rows[2]) <= rows[1][0] and sum(rows[3]) <= rows[1][0]
+    assert all(r > 0 for r in rows[3])

@@ -86,8 +86,9 @@ def test_one_minibatch_intermediates(kind, loss, d, items, users, T, B):
         m.set_param(Param.ITEM_EMBEDDING, E)
         m.set_param(Param.ITEM_BIAS, bias)
     pg, po = g.fit_begin(ptr, it), o.fit_begin(ptr, it)
-    assert pg.epoch_prepare() == po.epoch_prepare()
-    for mb in (0, 1):
+    nmb = po.epoch_prepare()
+    assert pg.epoch_prepare() == nmb
+    for mb in range(min(2, nmb)):
         R = po.minibatch_rows(mb)
         assert pg.minibatch_rows(mb) == R
         pg.step_local(mb)
@@ -95,11 +96,35 @@ def test_one_minibatch_intermediates(kind, loss, d, items, users, T, B):
         for which in (Debug.IN_IDX, Debug.OUT_IDX, Debug.HIDDEN, Debug.NEGATIVES, Debug.TRIES, Debug.COEF, Debug.LOSS,
                       Debug.DHIDDEN, Debug.DINPUT, Debug.DENSE_GRAD):
             assert_same_bits(pg.debug_fetch(which, R), po.debug_fetch(which, R), f"mb{mb} {which.name}")
-        if loss == LOSS_WARP and mb == 0:
-            assert po.debug_fetch(Debug.TRIES, R).max() > 1, "test data should exercise the WARP retry loop"
         pg.step_apply(mb)
-        po.step_apply(po.step_local(mb) if False else _export(po))
+        po.step_apply(_export(po))
         assert_params_equal(g, o, kind, f"after mb{mb}")
+
+
+def test_warp_retry_loop_all_trip_counts():
+    """sample_warp_negative (sequence_model.rs:47-68): every trip count 1..5 occurs, including
+    rows where no candidate violates and the 5th draw is used anyway."""
+    items, d, T = 400, 64, 24
+    ptr, it = synthetic_interactions(80, items, T, seed=31)
+    for kind in (ModelKind.EWMA, ModelKind.LSTM_NORMAL):
+        hp = hparams(items, T, d, int(kind), LOSS_WARP, B=64)
+        g, o = make_pair(hp)
+        rs = np.random.RandomState(6)
+        E = (rs.randn(items, d) * (0.45 if kind == ModelKind.EWMA else 1.2)).astype(np.float32)
+        bias = (rs.randn(items) * 1.0).astype(np.float32)
+        for m in (g, o):
+            m.set_param(Param.ITEM_EMBEDDING, E)
+            m.set_param(Param.ITEM_BIAS, bias)
+        pg, po = g.fit_begin(ptr, it), o.fit_begin(ptr, it)
+        pg.epoch_prepare(), po.epoch_prepare()
+        R = po.minibatch_rows(0)
+        pg.step_local(0), po.step_local(0)
+        tries = po.debug_fetch(Debug.TRIES, R)
+        coef = po.debug_fetch(Debug.COEF, R)
+        assert set(np.unique(tries)) == {1, 2, 3, 4, 5}, np.bincount(tries)
+        assert np.any((tries == 5) & (coef == 0.0)), "no row exhausted the 5 tries without a violation"
+        for which in (Debug.NEGATIVES, Debug.TRIES, Debug.COEF, Debug.LOSS, Debug.DHIDDEN):
+            assert_same_bits(pg.debug_fetch(which, R), po.debug_fetch(which, R), f"{kind.name} {which.name}")
 
 
 def _export(po):

@@ -710,6 +710,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_
         ScopedTimer t(m, SBR_K_SCORE, 1);
         sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], p->epoch_key_epoch), mb.R, m->stream);
     }
+    sbr::launch_block_header(bv, p->wb.v, mb.R, m->stream);
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng ? (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);

@@ -53,11 +53,24 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // K1+K3+K4: gather + negative sampling + loss + dloss/dh  (the HBM-roofline kernel)
 // One d/4-lane group per packed row; 16 B per lane per gathered embedding row.
 // ------------------------------------------------------------------------------------------------
-__global__ void block_header_init(uint32_t* header, int R) {
-    header[0] = (uint32_t)R;
-    header[1] = header[2] = header[3] = 0;
-    *reinterpret_cast<double*>(header + 4) = 0.0;
-    *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
+// header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction,
+// compared with a tolerance) and example count
+__global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, int R, const float* loss) {
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < R; r += 1024) acc += (double)loss[r];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 16; ++i) tot += part[i];
+        header[0] = (uint32_t)R;
+        header[1] = header[2] = header[3] = 0;
+        *reinterpret_cast<double*>(header + 4) = tot;
+        *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
+    }
 }
 
 template <int D>
@@ -71,7 +84,6 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
-    double wave_loss = 0.0;
     for (int base = wave * GPW; base < mb.R; base += nwaves * GPW) {
         const int r = base + grp;
         const bool valid = r < mb.R;
@@ -125,14 +137,9 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
                 blk.out_idx[r] = pi;
                 w.loss[r] = l;
                 w.tries[r] = tries;
-                wave_loss += (double)l;
             }
         }
     }
-    // loss is reporting only (tolerance parity): order-free f64 accumulation
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) wave_loss += __shfl_xor(wave_loss, off, 64);
-    if (lane == 0 && wave_loss != 0.0) atomicAdd(reinterpret_cast<double*>(blk.header + 4), wave_loss);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,184 +252,299 @@ __global__ void ewma_dense_final_kernel(const float* partials, int nchunks, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: LSTM step, forward.  One workgroup = 16 packed rows of step t; z = [x_t ; h_{t-1}] Wp + b on
-// v_mfma_f32_16x16x4_f32 (accumulator seeded with the bias, k ascending), cell fused in the
-// epilogue.  A tile (16 x 2D) staged through LDS; weights read in the MFMA-fragment packing Wp.
+// K2: LSTM step, forward.  Grid = (32-row tiles of step t) x (16-unit tiles); one wave per gate.
+// Wave g computes z_g = [x_t ; h_{t-1}] Wp_g + b_g for the workgroup's 32 rows x 16 units on
+// v_mfma_f32_16x16x4_f32 (accumulator seeded with the bias, k ascending).  Its whole weight
+// fragment column (2D x 16 floats) is requested from L2 before the A tile is staged, so the two
+// latencies overlap; the A tile ([E[in] ; h_prev], 32 x 2D) goes through LDS; the four gates meet
+// in LDS and the cell is applied by all threads.  Many small workgroups per CU overlap each
+// other's staging, MFMA and epilogue phases.
 // ------------------------------------------------------------------------------------------------
-template <int D>
-struct LstmCfg {
-    static constexpr int UT = D / 16;                 // 16-unit tiles
-    static constexpr int NW = UT < 8 ? UT : 8;        // waves per workgroup
-};
-
 template <int D, int NG>
-__global__ __launch_bounds__(LstmCfg<D>::NW * 64) void lstm_fwd_step_kernel(ModelView m, MbView mb, int t, float* H,
-                                                                            WorkView w) {
+__global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbView mb, int t, float* H, WorkView w) {
     constexpr int K2 = 2 * D;
     constexpr int LDA = K2 + 2;
-    constexpr int NW = LstmCfg<D>::NW;
-    __shared__ float As[16 * LDA];
+    constexpr int NS = K2 / 16;
+    constexpr int RT = 2;             // 16-row tiles per workgroup
+    constexpr int ROWS = 16 * RT;
+    constexpr int NT = NG * 64;
+    constexpr int LDZ = NG * 16 + 1;
+    constexpr int PF = NS < 16 ? NS : 16;  // weight k-blocks held in registers at once
+    __shared__ float As[ROWS * LDA];
+    __shared__ float Zs[ROWS * LDZ];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j16 = lane & 15;
+    const int kq = lane >> 4;
+    const int ut = blockIdx.y;
     const int row_begin = mb.off[t];
     const int bt = mb.off[t + 1] - row_begin;
-    const int b0 = blockIdx.x * 16;
-    const int nrows = bt - b0 < 16 ? bt - b0 : 16;
+    const int b0 = blockIdx.x * ROWS;
+    const int nrows = bt - b0 < ROWS ? bt - b0 : ROWS;
     const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
-    // stage A = [E[in_idx[row]] ; H[prev row]] for the 16 rows
-    for (int idx = tid; idx < 16 * (K2 / 4); idx += NW * 64) {
+    // 1. weight fragments of this wave's gate: request the first PF k-blocks now
+    const float* wp = m.Wp + (((size_t)(ut * NG + g) * NS) * 64 + lane) * 4;
+    float4 bf[PF];
+#pragma unroll
+    for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)S * 256);
+    const float bias = m.bW[g * D + ut * 16 + j16];
+    // 2. stage A: all gathers of the tile in flight together
+    constexpr int NV = ROWS * (K2 / 4);  // float4 slots in the tile
+    constexpr int ITER = (NV + NT - 1) / NT;
+    float4 av[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * NT;
         const int i = idx / (K2 / 4);
         const int c4 = (idx % (K2 / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nrows) {
+        if (idx < NV && i < nrows) {
             if (c4 < D) v = ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4);
             else if (t > 0) v = ld4(H + (size_t)(prev_begin + b0 + i) * D + (c4 - D));
         }
-        float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
-        dst[0] = make_float2(v.x, v.y);
-        dst[1] = make_float2(v.z, v.w);
+        av[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < NV) {
+            const int i = idx / (K2 / 4);
+            const int c4 = (idx % (K2 / 4)) * 4;
+            float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
+            dst[0] = make_float2(av[it].x, av[it].y);
+            dst[1] = make_float2(av[it].z, av[it].w);
+        }
     }
     __syncthreads();
-    const int j16 = lane & 15;
-    const int kq = lane >> 4;
-    for (int ut = wave; ut < D / 16; ut += NW) {
-        f32x4 acc[NG];
+    // 3. MFMA
+    f32x4 acc[RT];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float bv = m.bW[g * D + ut * 16 + j16];
-            acc[g] = (f32x4){bv, bv, bv, bv};
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){bias, bias, bias, bias};
+#pragma unroll
+    for (int S0 = 0; S0 < NS; S0 += PF) {
+        if (S0 > 0) {
+#pragma unroll
+            for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(S0 + S) * 256);
         }
-        const float* arow = &As[j16 * LDA + kq];
-        const float* wp = m.Wp + ((size_t)(ut * NG) * (K2 / 16) * 64 + lane) * 4;
-#pragma unroll 2
-        for (int S = 0; S < K2 / 16; ++S) {
-            float4 bf[NG];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) bf[g] = ld4(wp + ((size_t)g * (K2 / 16) + S) * 256);
-            const float a0 = arow[16 * S + 0], a1 = arow[16 * S + 4], a2 = arow[16 * S + 8], a3 = arow[16 * S + 12];
+        for (int S = 0; S < PF; ++S) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[g].x, acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[g].y, acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[g].z, acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[g].w, acc[g], 0, 0, 0);
-        }
-        // epilogue: lane holds rows i = kq*4 + reg, unit u
-        const int u = ut * 16 + j16;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int i = kq * 4 + reg;
-            if (i < nrows) {
-                const size_t r = (size_t)(row_begin + b0 + i);
-                const float cprev = t > 0 ? w.C[(size_t)(prev_begin + b0 + i) * D + u] : 0.0f;
-                float zi, zf, zg, zo;
-                if (NG == 4) { zi = acc[0][reg]; zf = acc[1][reg]; zg = acc[2][reg]; zo = acc[NG - 1][reg]; }
-                else { zi = 0.0f; zf = acc[0][reg]; zg = acc[1][reg]; zo = acc[2][reg]; }
-                float gi, gf, gg, go, cc, hh;
-                sbr_lstm_cell_fwd(zi, zf, zg, zo, cprev, NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
-                float* G = w.G + r * 4 * D;
-                G[u] = gi; G[D + u] = gf; G[2 * D + u] = gg; G[3 * D + u] = go;
-                w.C[r * D + u] = cc;
-                H[r * D + u] = hh;
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* arow = &As[(rt * 16 + j16) * LDA + 16 * (S0 + S) + kq];
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], bf[S].x, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], bf[S].y, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], bf[S].z, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], bf[S].w, acc[rt], 0, 0, 0);
             }
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Zs[(rt * 16 + kq * 4 + reg) * LDZ + g * 16 + j16] = acc[rt][reg];
+    __syncthreads();
+    // 4. cell: (row, unit) pairs over all threads
+    for (int e = tid; e < ROWS * 16; e += NT) {
+        const int i = e >> 4;
+        const int uu = e & 15;
+        if (i < nrows) {
+            const int u = ut * 16 + uu;
+            const size_t r = (size_t)(row_begin + b0 + i);
+            const float cprev = t > 0 ? w.C[(size_t)(prev_begin + b0 + i) * D + u] : 0.0f;
+            const float* z = &Zs[i * LDZ + uu];
+            float zi, zf, zg, zo;
+            if (NG == 4) { zi = z[0]; zf = z[16]; zg = z[32]; zo = z[(NG - 1) * 16]; }
+            else { zi = 0.0f; zf = z[0]; zg = z[16]; zo = z[32]; }
+            float gi, gf, gg, go, cc, hh;
+            sbr_lstm_cell_fwd(zi, zf, zg, zo, cprev, NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
+            float* G = w.G + r * 4 * D;
+            G[u] = gi; G[D + u] = gf; G[2 * D + u] = gg; G[3 * D + u] = go;
+            w.C[r * D + u] = cc;
+            H[r * D + u] = hh;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: LSTM step, backward.  Phase A: cell backward for the 16 rows (all units) -> dz tile in LDS
-// (and in HBM for the dense-gradient GEMM).  Phase B: dxh = dz * W^T on MFMA (accumulator from 0,
-// j ascending); columns < D are dX of this row, columns >= D the recurrent dh for step t-1.
+// K5: LSTM step, backward = two launches per step.
+// (a) cell backward, elementwise over (row of step t, 4 units): dz_t and the dc carry.
+// (b) dxh = dz_t * W^T on MFMA (accumulator from 0, j ascending): columns < D are dX of the row,
+//     columns >= D the recurrent dh consumed by (a) of step t-1.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG>
-__global__ __launch_bounds__(LstmCfg<D>::NW * 64) void lstm_bwd_step_kernel(ModelView m, MbView mb, int t,
-                                                                            BlockView blk, WorkView w) {
-    constexpr int K2 = 2 * D;
+__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(MbView mb, int t, WorkView w) {
     constexpr int NGD = NG * D;
-    constexpr int LDZ = NGD + 2;
-    constexpr int NW = LstmCfg<D>::NW;
-    __shared__ float Zs[16 * LDZ];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int Q = D / 4;
     const int row_begin = mb.off[t];
     const int bt = mb.off[t + 1] - row_begin;
     const int bnext = t + 1 < mb.Tm ? mb.off[t + 2] - mb.off[t + 1] : 0;
-    const int b0 = blockIdx.x * 16;
-    const int nrows = bt - b0 < 16 ? bt - b0 : 16;
     const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
-    for (int idx = tid; idx < 16 * D; idx += NW * 64) {
-        const int i = idx / D;
-        const int u = idx % D;
-        float dz[4] = {0.f, 0.f, 0.f, 0.f};
-        if (i < nrows) {
-            const int b = b0 + i;
-            const size_t r = (size_t)(row_begin + b);
-            const bool last = b >= bnext;
-            const float dh = w.dH[r * D + u] + (last ? 0.0f : w.dHrec[(size_t)b * D + u]);
-            const float dc_in = last ? 0.0f : w.dCrec[(size_t)b * D + u];
-            const float* G = w.G + r * 4 * D;
-            const float cprev = t > 0 ? w.C[(size_t)(prev_begin + b) * D + u] : 0.0f;
-            float dco;
-            sbr_lstm_cell_bwd(dh, dc_in, G[u], G[D + u], G[2 * D + u], G[3 * D + u], w.C[r * D + u], cprev, NG == 3,
-                              &dz[0], &dz[1], &dz[2], &dz[3], &dco);
-            w.dCrec[(size_t)b * D + u] = dco;
-            float* dZ = w.dZ + r * NGD;
-            if (NG == 4) { dZ[u] = dz[0]; dZ[D + u] = dz[1]; dZ[2 * D + u] = dz[2]; dZ[3 * D + u] = dz[3]; }
-            else { dZ[u] = dz[1]; dZ[D + u] = dz[2]; dZ[2 * D + u] = dz[3]; }
-        }
-        if (NG == 4) { Zs[i * LDZ + u] = dz[0]; Zs[i * LDZ + D + u] = dz[1]; Zs[i * LDZ + 2 * D + u] = dz[2]; Zs[i * LDZ + 3 * D + u] = dz[3]; }
-        else { Zs[i * LDZ + u] = dz[1]; Zs[i * LDZ + D + u] = dz[2]; Zs[i * LDZ + 2 * D + u] = dz[3]; }
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int b = idx / Q;
+    if (b >= bt) return;
+    const int u = (idx % Q) * 4;
+    const size_t r = (size_t)(row_begin + b);
+    const bool last = b >= bnext;
+    const float4 dh0 = ld4(w.dH + r * D + u);
+    const float* G = w.G + r * 4 * D;
+    const float4 gi = ld4(G + u), gf = ld4(G + D + u), gg = ld4(G + 2 * D + u), go = ld4(G + 3 * D + u);
+    const float4 cc = ld4(w.C + r * D + u);
+    float4 cp = make_float4(0.f, 0.f, 0.f, 0.f), dhr = cp, dcr = cp;
+    if (t > 0) cp = ld4(w.C + (size_t)(prev_begin + b) * D + u);
+    if (!last) {
+        dhr = ld4(w.dHrec + (size_t)b * D + u);
+        dcr = ld4(w.dCrec + (size_t)b * D + u);
     }
-    __syncthreads();
-    const int c16 = lane & 15;
-    const int kq = lane >> 4;
-    for (int ct = wave; ct < K2 / 16; ct += NW) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* arow = &Zs[c16 * LDZ + kq];
-        const float* wp = m.WTp + ((size_t)ct * (NGD / 16) * 64 + lane) * 4;
-#pragma unroll 4
-        for (int S = 0; S < NGD / 16; ++S) {
-            const float4 bf = ld4(wp + (size_t)S * 256);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 0], bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 4], bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 8], bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * S + 12], bf.w, acc, 0, 0, 0);
-        }
-        const int col = ct * 16 + c16;
+    const float dh_[4] = {dh0.x, dh0.y, dh0.z, dh0.w}, dhr_[4] = {dhr.x, dhr.y, dhr.z, dhr.w}, dcr_[4] = {dcr.x, dcr.y, dcr.z, dcr.w};
+    const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w}, gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+    const float cc_[4] = {cc.x, cc.y, cc.z, cc.w}, cp_[4] = {cp.x, cp.y, cp.z, cp.w};
+    float dz[4][4], dco[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int i = kq * 4 + reg;
-            if (i < nrows) {
-                const int b = b0 + i;
-                if (col < D) blk.dX[(size_t)(row_begin + b) * D + col] = acc[reg];
-                else w.dHrec[(size_t)b * D + (col - D)] = acc[reg];
-            }
-        }
+    for (int j = 0; j < 4; ++j) {
+        const float dh = dh_[j] + (last ? 0.0f : dhr_[j]);
+        sbr_lstm_cell_bwd(dh, last ? 0.0f : dcr_[j], gi_[j], gf_[j], gg_[j], go_[j], cc_[j], cp_[j], NG == 3, &dz[0][j],
+                          &dz[1][j], &dz[2][j], &dz[3][j], &dco[j]);
+    }
+    st4(w.dCrec + (size_t)b * D + u, make_float4(dco[0], dco[1], dco[2], dco[3]));
+    float* dZ = w.dZ + r * NGD;
+    if (NG == 4) {
+        st4(dZ + u, make_float4(dz[0][0], dz[0][1], dz[0][2], dz[0][3]));
+        st4(dZ + D + u, make_float4(dz[1][0], dz[1][1], dz[1][2], dz[1][3]));
+        st4(dZ + 2 * D + u, make_float4(dz[2][0], dz[2][1], dz[2][2], dz[2][3]));
+        st4(dZ + 3 * D + u, make_float4(dz[3][0], dz[3][1], dz[3][2], dz[3][3]));
+    } else {
+        st4(dZ + u, make_float4(dz[1][0], dz[1][1], dz[1][2], dz[1][3]));
+        st4(dZ + D + u, make_float4(dz[2][0], dz[2][1], dz[2][2], dz[2][3]));
+        st4(dZ + 2 * D + u, make_float4(dz[3][0], dz[3][1], dz[3][2], dz[3][3]));
     }
 }
 
+template <int D, int NG>
+struct BwdCfg {
+    static constexpr int NGD = NG * D;
+    static constexpr int RT = NGD <= 512 ? 2 : 1;  // keep the dz tile <= 64 KiB of LDS
+};
+
+template <int D, int NG>
+__global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView mb, int t, BlockView blk, WorkView w) {
+    constexpr int K2 = 2 * D;
+    constexpr int NGD = NG * D;
+    constexpr int LDZ = NGD + 2;
+    constexpr int NS = NGD / 16;
+    constexpr int RT = BwdCfg<D, NG>::RT;
+    constexpr int ROWS = 16 * RT;
+    constexpr int CTW = K2 / 16 < 4 ? K2 / 16 : 4;  // column tiles (= busy waves) per workgroup
+    constexpr int PF = NS % 8 == 0 ? 8 : (NS % 6 == 0 ? 6 : (NS % 4 == 0 ? 4 : (NS % 3 == 0 ? 3 : (NS % 2 == 0 ? 2 : 1))));
+    extern __shared__ __attribute__((aligned(16))) float Zs[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15;
+    const int kq = lane >> 4;
+    const int row_begin = mb.off[t];
+    const int bt = mb.off[t + 1] - row_begin;
+    const int b0 = blockIdx.x * ROWS;
+    const int nrows = bt - b0 < ROWS ? bt - b0 : ROWS;
+    const int ct = blockIdx.y * CTW + wave;
+    const bool busy = wave < CTW;
+    const float* wp = m.WTp + ((size_t)(busy ? ct : 0) * NS * 64 + lane) * 4;
+    float4 bf[PF];
+#pragma unroll
+    for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)S * 256);
+    constexpr int NV = ROWS * (NGD / 4);
+    constexpr int ITER = (NV + 255) / 256;
+    float4 zv[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * 256;
+        const int i = idx / (NGD / 4);
+        const int c4 = (idx % (NGD / 4)) * 4;
+        zv[it] = (idx < NV && i < nrows) ? ld4(w.dZ + (size_t)(row_begin + b0 + i) * NGD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < NV) {
+            const int i = idx / (NGD / 4);
+            const int c4 = (idx % (NGD / 4)) * 4;
+            float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + c4]);
+            dst[0] = make_float2(zv[it].x, zv[it].y);
+            dst[1] = make_float2(zv[it].z, zv[it].w);
+        }
+    }
+    __syncthreads();
+    if (!busy) return;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int S0 = 0; S0 < NS; S0 += PF) {
+        float4 cur[PF];
+#pragma unroll
+        for (int S = 0; S < PF; ++S) cur[S] = bf[S];
+        if (S0 + PF < NS) {
+#pragma unroll
+            for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(S0 + PF + S) * 256);
+        }
+#pragma unroll
+        for (int S = 0; S < PF; ++S) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * (S0 + S) + kq];
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+            }
+        }
+    }
+    const int col = ct * 16 + c16;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = rt * 16 + kq * 4 + reg;
+            if (i < nrows) {
+                const int b = b0 + i;
+                if (col < D) blk.dX[(size_t)(row_begin + b) * D + col] = acc[rt][reg];
+                else w.dHrec[(size_t)b * D + (col - D)] = acc[rt][reg];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Dense gradient dW[k][j] = sum_r xh[r][k] dz[r][j] : v_mfma_f32_32x32x2_f32, one wave per 64x64
-// output tile and 1024-row chunk (chain over rows inside the chunk, accumulator from 0).
+// Dense gradient dW[k][j] = sum_r xh[r][k] dz[r][j] : v_mfma_f32_32x32x2_f32.  One workgroup (4
+// waves, 2x2) per 128x128 output tile and 1024-row chunk; every wave keeps a 64x64 sub-tile (2x2
+// accumulators, from 0, rows ascending).  32-row slabs of xh (gathered: E rows / previous hidden
+// rows) and dz are staged through LDS with 16-byte loads; the next slab's loads are in flight
+// while the current one feeds the MFMAs.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG>
 __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
     constexpr int K2 = 2 * D;
     constexpr int NGD = NG * D;
-    constexpr int TK = (K2 + 63) / 64;
-    constexpr int TJ = (NGD + 63) / 64;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= TK * TJ) return;
-    const int tk = tile / TJ, tj = tile % TJ;
+    constexpr int TJ = (NGD + 127) / 128;
+    constexpr int SLAB = 32;
+    __shared__ float Xs[SLAB * 128];
+    __shared__ float Zs[SLAB * 128];
+    __shared__ int s_in[SBR_DW_CHUNK_ROWS];
+    __shared__ int s_prev[SBR_DW_CHUNK_ROWS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wj = wave & 1;
+    const int tk = blockIdx.x / TJ, tj = blockIdx.x % TJ;
     const int c = blockIdx.y;
     const int r0 = c * SBR_DW_CHUNK_ROWS;
     int r1 = r0 + SBR_DW_CHUNK_ROWS;
     if (r1 > mb.R) r1 = mb.R;
+    const int nr = r1 - r0;
+    for (int i = tid; i < nr; i += 256) {
+        s_in[i] = (int)mb.in_idx[r0 + i];
+        s_prev[i] = mb.prev_row[r0 + i];
+    }
+    __syncthreads();
     const int l31 = lane & 31;
     const int hh = lane >> 5;
     f32x16 acc[2][2];
@@ -432,56 +554,86 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
-    const int ka[2] = {tk * 64 + l31, tk * 64 + 32 + l31};
-    const int jb[2] = {tj * 64 + l31, tj * 64 + 32 + l31};
-    for (int r = r0; r < r1; r += 2) {
-        const int rr = r + hh;
-        const bool rv = rr < r1;
-        float av[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
-        if (rv) {
-            const uint32_t it = mb.in_idx[rr];
-            const int pr = mb.prev_row[rr];
+    // staging map: thread owns column quad c4 of rows (tid/32) + 8*i, i = 0..3
+    const int c4 = (tid & 31) * 4;
+    const int srow = tid >> 5;
+    const int kcol = tk * 128 + c4;
+    const int jcol = tj * 128 + c4;
+    float4 xr[4], zr[4];
+    auto fetch = [&](int slab) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int k = ka[a];
-                if (k < D) av[a] = m.E[(size_t)it * D + k];
-                else if (k < K2 && pr >= 0) av[a] = blk.H[(size_t)pr * D + (k - D)];
+        for (int i = 0; i < 4; ++i) {
+            const int lr = slab * SLAB + srow + 8 * i;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), zv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lr < nr) {
+                if (kcol < D) xv = ld4(m.E + (size_t)s_in[lr] * D + kcol);
+                else if (kcol < K2) {
+                    const int pr = s_prev[lr];
+                    if (pr >= 0) xv = ld4(blk.H + (size_t)pr * D + (kcol - D));
+                }
+                if (jcol < NGD) zv = ld4(w.dZ + (size_t)(r0 + lr) * NGD + jcol);
             }
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                if (jb[b] < NGD) bv[b] = w.dZ[(size_t)rr * NGD + jb[b]];
+            xr[i] = xv;
+            zr[i] = zv;
         }
+    };
+    const int nslabs = (nr + SLAB - 1) / SLAB;
+    fetch(0);
+    for (int slab = 0; slab < nslabs; ++slab) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            st4(&Xs[(srow + 8 * i) * 128 + c4], xr[i]);
+            st4(&Zs[(srow + 8 * i) * 128 + c4], zr[i]);
+        }
+        __syncthreads();
+        if (slab + 1 < nslabs) fetch(slab + 1);
+        const float* xa = &Xs[hh * 128 + wk * 64 + l31];
+        const float* zb = &Zs[hh * 128 + wj * 64 + l31];
+#pragma unroll 4
+        for (int s = 0; s < SLAB / 2; ++s) {
+            const float a0 = xa[s * 256], a1 = xa[s * 256 + 32];
+            const float b0 = zb[s * 256], b1 = zb[s * 256 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
     }
     float* part = w.partials + (size_t)c * (K2 + 1) * NGD;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int j = tj * 64 + b * 32 + l31;
+            const int j = tj * 128 + wj * 64 + b * 32 + l31;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int k = tk * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                const int k = tk * 128 + wk * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
                 if (k < K2 && j < NGD) part[(size_t)k * NGD + j] = acc[a][b][q];
             }
         }
 }
 
-// bias-gradient row of the partials: chain of plain adds over the rows of the chunk
-__global__ void lstm_dbias_kernel(MbView mb, const float* dZ, int K2, int NGD, float* partials) {
+// bias-gradient row of the partials: chain of plain adds over the rows of the chunk (loads are
+// issued eight rows ahead of the dependent add chain)
+__global__ __launch_bounds__(256) void lstm_dbias_kernel(MbView mb, const float* dZ, int K2, int NGD, float* partials) {
     const int c = blockIdx.x;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= NGD) return;
     const int r0 = c * SBR_DW_CHUNK_ROWS;
     int r1 = r0 + SBR_DW_CHUNK_ROWS;
     if (r1 > mb.R) r1 = mb.R;
-    for (int j = threadIdx.x; j < NGD; j += blockDim.x) {
-        float acc = 0.0f;
-        for (int r = r0; r < r1; ++r) acc = acc + dZ[(size_t)r * NGD + j];
-        partials[((size_t)c * (K2 + 1) + K2) * NGD + j] = acc;
+    float acc = 0.0f;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = dZ[(size_t)(r + i) * NGD + j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = acc + v[i];
     }
+    for (; r < r1; ++r) acc = acc + dZ[(size_t)r * NGD + j];
+    partials[((size_t)c * (K2 + 1) + K2) * NGD + j] = acc;
 }
 
 __global__ void dense_reduce_local_kernel(const float* partials, int nchunks, size_t n, float* dense) {
@@ -767,14 +919,14 @@ __global__ void selftest_mfma32_chain_kernel(const float* a, const float* b, int
 // ================================================================================================
 // launchers
 // ================================================================================================
-#define DISPATCH_D(d, CALL)                  \
-    switch (d) {                             \
-        case 16: { constexpr int DD = 16; CALL; } break;   \
-        case 32: { constexpr int DD = 32; CALL; } break;   \
-        case 64: { constexpr int DD = 64; CALL; } break;   \
-        case 128: { constexpr int DD = 128; CALL; } break; \
-        case 256: { constexpr int DD = 256; CALL; } break; \
-        default: break;                      \
+#define DISPATCH_D(d, ...)                                         \
+    switch (d) {                                                   \
+        case 16: { constexpr int DD = 16; __VA_ARGS__; } break;    \
+        case 32: { constexpr int DD = 32; __VA_ARGS__; } break;    \
+        case 64: { constexpr int DD = 64; __VA_ARGS__; } break;    \
+        case 128: { constexpr int DD = 128; __VA_ARGS__; } break;  \
+        case 256: { constexpr int DD = 256; __VA_ARGS__; } break;  \
+        default: break;                                            \
     }
 
 static inline int grid_for_groups(long long groups, int groups_per_block) {
@@ -795,24 +947,28 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         return;
     }
     for (int t = 0; t < tm_host; ++t) {
+        const int nblk = (off_host[t + 1] - off_host[t] + 31) / 32; /* 32-row tiles alive at step t */
         DISPATCH_D(m.d, {
-            const int nblk = (off_host[t + 1] - off_host[t] + 15) / 16; /* sequences alive at step t */
             if (m.ng == 4)
-                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 4>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, H, w);
+                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 4>), dim3(nblk, DD / 16), dim3(256), 0, s, m, mb, t, H, w);
             else
-                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 3>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, H, w);
+                hipLaunchKernelGGL((lstm_fwd_step_kernel<DD, 3>), dim3(nblk, DD / 16), dim3(192), 0, s, m, mb, t, H, w);
         });
     }
 }
 
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s) {
-    hipLaunchKernelGGL(block_header_init, dim3(1), dim3(1), 0, s, blk.header, rows_host);
-    if (rows_host == 0) return;
-    DISPATCH_D(m.d, {
-        const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((score_kernel<DD>), dim3(grid_for_groups(rows_host, gpb)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-    });
+    if (rows_host > 0) {
+        DISPATCH_D(m.d, {
+            const int gpb = 4 * (64 / (DD / 4));
+            hipLaunchKernelGGL((score_kernel<DD>), dim3(grid_for_groups(rows_host, gpb)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+        });
+    }
+}
+
+void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(1024), 0, s, blk.header, rows_host, w.loss);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
@@ -833,24 +989,43 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         return;
     }
     for (int t = tm_host - 1; t >= 0; --t) {
+        const int bt = off_host[t + 1] - off_host[t];
         DISPATCH_D(m.d, {
-            const int nblk = (off_host[t + 1] - off_host[t] + 15) / 16;
-            if (m.ng == 4)
-                hipLaunchKernelGGL((lstm_bwd_step_kernel<DD, 4>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, blk, w);
-            else
-                hipLaunchKernelGGL((lstm_bwd_step_kernel<DD, 3>), dim3(nblk), dim3(LstmCfg<DD>::NW * 64), 0, s, m, mb, t, blk, w);
+            const int cell_blocks = (bt * (DD / 4) + 255) / 256;
+            constexpr int CTW = 2 * DD / 16 < 4 ? 2 * DD / 16 : 4;
+            if (m.ng == 4) {
+                constexpr int ROWS = 16 * BwdCfg<DD, 4>::RT;
+                constexpr size_t lds = (size_t)ROWS * (4 * DD + 2) * sizeof(float);
+                static bool attr_set_4 = false; /* dynamic LDS above 64 KiB needs the opt-in */
+                if (!attr_set_4) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    attr_set_4 = true;
+                }
+                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 4>), dim3(cell_blocks), dim3(256), 0, s, mb, t, w);
+                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 4>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
+            } else {
+                constexpr int ROWS = 16 * BwdCfg<DD, 3>::RT;
+                constexpr size_t lds = (size_t)ROWS * (3 * DD + 2) * sizeof(float);
+                static bool attr_set_3 = false; /* dynamic LDS above 64 KiB needs the opt-in */
+                if (!attr_set_3) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    attr_set_3 = true;
+                }
+                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 3>), dim3(cell_blocks), dim3(256), 0, s, mb, t, w);
+                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 3>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
+            }
         });
     }
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
-    const int tiles = ((K2 + 63) / 64) * ((NGD + 63) / 64);
+    const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
     DISPATCH_D(m.d, {
         if (m.ng == 4)
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3((tiles + 3) / 4, nch), dim3(256), 0, s, m, mb, blk, w);
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(tiles, nch), dim3(256), 0, s, m, mb, blk, w);
         else
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3((tiles + 3) / 4, nch), dim3(256), 0, s, m, mb, blk, w);
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(tiles, nch), dim3(256), 0, s, m, mb, blk, w);
     });
-    hipLaunchKernelGGL(lstm_dbias_kernel, dim3(nch), dim3(256), 0, s, mb, w.dZ, K2, NGD, w.partials);
+    hipLaunchKernelGGL(lstm_dbias_kernel, dim3(nch, (NGD + 255) / 256), dim3(256), 0, s, mb, w.dZ, K2, NGD, w.partials);
     const size_t n = (size_t)(K2 + 1) * NGD;
     hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
 }

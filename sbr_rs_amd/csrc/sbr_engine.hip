@@ -794,7 +794,11 @@ sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, u
         case SBR_DBG_NEGATIVES: src = bv.neg; n = R * 4; break;
         case SBR_DBG_COEF: src = bv.coef; n = R * 4; break;
         case SBR_DBG_LOSS: src = p->wb.v.loss; n = R * 4; break;
-        case SBR_DBG_DHIDDEN: src = p->wb.v.dH; n = R * d * 4; break;
+        case SBR_DBG_DHIDDEN:
+            /* only defined before the optimiser step of the same minibatch has been applied */
+            sbr::launch_materialize_dh(m->mv, bv, p->last_R, p->wb.v.dH, m->stream);
+            HIPCHK(hipStreamSynchronize(m->stream));
+            src = p->wb.v.dH; n = R * d * 4; break;
         case SBR_DBG_DINPUT: src = bv.dX; n = R * d * 4; break;
         case SBR_DBG_DENSE_GRAD: src = bv.dense; n = dense_count(m) * 4; break;
         case SBR_DBG_IN_IDX: src = bv.in_idx; n = R * 4; break;

@@ -60,6 +60,8 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
 /* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s);
+/* debug only: dloss/dh of every packed row (the training path never materialises it) */
+void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
 void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s);
 /* BPTT + dense gradient into blk.dense */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

@@ -101,7 +101,6 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
         bool done = false;
         uint32_t nj = 0, tries = 0;
         float neg = 0.0f;
-        float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < max_tries; ++k) {
             if (k > 0) {
                 if (__all(done)) break;
@@ -115,7 +114,6 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
             if (!done) {
                 nj = cand;
                 neg = s;
-                en = ec;
                 ++tries;
                 if (sbr_warp_violates(pos, s)) done = true;
             }
@@ -124,12 +122,8 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
         if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
         else l = sbr_loss_hinge(pos, neg, &g);
         if (valid) {
-            float4 dh;
-            dh.x = g * en.x - g * ep.x;
-            dh.y = g * en.y - g * ep.y;
-            dh.z = g * en.z - g * ep.z;
-            dh.w = g * en.w - g * ep.w;
-            st4(w.dH + (size_t)r * D + 4 * lg, dh);
+            // dloss/dh = g (E[neg] - E[pos]) is not written here: the backward kernels re-form it
+            // from (neg, coef) with two row gathers, which keeps this kernel read-only on the table
             if (lg == 0) {
                 blk.neg[r] = nj;
                 blk.coef[r] = g;
@@ -140,6 +134,29 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
             }
         }
     }
+}
+
+// dloss/dh of packed row r, elements u..u+3:  g*E[neg] - g*E[pos]  (two rounded products, one
+// subtraction — the oracle's order)
+__device__ __forceinline__ float4 dh_loss4(const ModelView& m, const BlockView& blk, size_t r, int u, int D) {
+    const float g = blk.coef[r];
+    const float4 en = ld4(m.E + (size_t)blk.neg[r] * D + u);
+    const float4 ep = ld4(m.E + (size_t)blk.out_idx[r] * D + u);
+    float4 dh;
+    dh.x = g * en.x - g * ep.x;
+    dh.y = g * en.y - g * ep.y;
+    dh.z = g * en.z - g * ep.z;
+    dh.w = g * en.w - g * ep.w;
+    return dh;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void materialize_dh_kernel(ModelView m, BlockView blk, int R, float* dH) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int r = idx / (D / 4);
+    if (r >= R) return;
+    const int u = (idx % (D / 4)) * 4;
+    st4(dH + (size_t)r * D + u, dh_loss4(m, blk, (size_t)r, u, D));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView 
         float da[4] = {0.f, 0.f, 0.f, 0.f};
         for (int t = n - 1; t >= 0; --t) {
             const int r = mb.off[t] + b;
-            const float4 dh = ld4(w.dH + (size_t)r * D + 4 * lg);
+            const float4 dh = dh_loss4(m, blk, (size_t)r, 4 * lg, D);
             float ds[4] = {dh.x, dh.y, dh.z, dh.w};
             if (t != n - 1) {
 #pragma unroll
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
 //     columns >= D the recurrent dh consumed by (a) of step t-1.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG>
-__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(MbView mb, int t, WorkView w) {
+__global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(ModelView m, MbView mb, int t, BlockView blk, WorkView w) {
     constexpr int NGD = NG * D;
     constexpr int Q = D / 4;
     const int row_begin = mb.off[t];
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(MbView mb, int t, Wo
     const int u = (idx % Q) * 4;
     const size_t r = (size_t)(row_begin + b);
     const bool last = b >= bnext;
-    const float4 dh0 = ld4(w.dH + r * D + u);
+    const float4 dh0 = dh_loss4(m, blk, r, u, D);
     const float* G = w.G + r * 4 * D;
     const float4 gi = ld4(G + u), gf = ld4(G + D + u), gg = ld4(G + 2 * D + u), go = ld4(G + 3 * D + u);
     const float4 cc = ld4(w.C + r * D + u);
@@ -967,6 +984,13 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
     }
 }
 
+void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s) {
+    if (rows_host == 0) return;
+    DISPATCH_D(m.d, {
+        hipLaunchKernelGGL((materialize_dh_kernel<DD>), dim3((rows_host * (DD / 4) + 255) / 256), dim3(256), 0, s, m, blk, rows_host, dH);
+    });
+}
+
 void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
     hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(1024), 0, s, blk.header, rows_host, w.loss);
 }
@@ -1001,7 +1025,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     attr_set_4 = true;
                 }
-                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 4>), dim3(cell_blocks), dim3(256), 0, s, mb, t, w);
+                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 4>), dim3(cell_blocks), dim3(256), 0, s, m, mb, t, blk, w);
                 hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 4>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
             } else {
                 constexpr int ROWS = 16 * BwdCfg<DD, 3>::RT;
@@ -1011,7 +1035,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                     attr_set_3 = true;
                 }
-                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 3>), dim3(cell_blocks), dim3(256), 0, s, mb, t, w);
+                hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 3>), dim3(cell_blocks), dim3(256), 0, s, m, mb, t, blk, w);
                 hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 3>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
             }
         });

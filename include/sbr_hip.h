@@ -119,9 +119,16 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
 sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids,
                          uint64_t num_users, sbr_fit_plan** out);
 sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches);
+/* Optional: start shuffling/packing/uploading the NEXT epoch on a host thread while the device works
+ * on the current one; the following sbr_fit_epoch_prepare consumes it.  Call only if another epoch
+ * follows (the shuffle advances the partition RNGs and the epoch counter). */
+sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p);
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
 sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows);
 sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples);
+/* Running totals of the plan, all devices: loss terms processed and negatives scored by the WARP
+ * search (the k of BASELINE.md §4's bytes-per-interaction formula). */
+sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored);
 void sbr_fit_plan_destroy(sbr_fit_plan* p);
 
 /* Multi-device halves of a step (user-sharded data parallelism, one process per GPU).

@@ -31,9 +31,11 @@ def load():
         "sbr_model_fit": [vp, vp, vp, C.c_uint64, fp],
         "sbr_fit_begin": [vp, vp, vp, C.c_uint64, C.POINTER(vp)],
         "sbr_fit_epoch_prepare": [vp, u64p],
+        "sbr_fit_epoch_prefetch": [vp],
         "sbr_fit_step": [vp, C.c_uint64],
         "sbr_fit_minibatch_rows": [vp, C.c_uint64, u64p],
         "sbr_fit_end": [vp, fp, u64p],
+        "sbr_fit_counters": [vp, u64p, u64p],
         "sbr_fit_exchange_bytes": [vp, u64p],
         "sbr_fit_step_local": [vp, C.c_uint64, vp],
         "sbr_fit_step_apply": [vp, C.c_uint64, vp],
@@ -76,7 +78,8 @@ def load():
 # every symbol include/sbr_hip.h declares (tests/test_abi.py checks the export table)
 DECLARED_SYMBOLS = [
     "sbr_model_create", "sbr_model_destroy", "sbr_model_fit", "sbr_fit_begin", "sbr_fit_epoch_prepare",
-    "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_plan_destroy", "sbr_fit_exchange_bytes",
+    "sbr_fit_epoch_prefetch",
+    "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_counters", "sbr_fit_plan_destroy", "sbr_fit_exchange_bytes",
     "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_model_set_stream", "sbr_model_synchronize",
     "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
     "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_device_info", "sbr_status_string",

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/sbr_hip.h"
@@ -243,15 +244,25 @@ struct sbr_fit_plan {
     std::vector<uint64_t> fit_seed;
     std::vector<uint32_t> items; /* host copy of the CSR item ids */
     uint64_t rmax = 0, bmax = 0;
-    /* current epoch */
-    uint64_t epoch_key_epoch = 0;
-    uint64_t num_mb = 0;
+    /* epoch data is double-buffered: the GPU consumes ep[cur] while a host thread may already
+     * shuffle, pack and upload the next epoch into ep[cur ^ 1] (sbr_fit_epoch_prefetch) */
     struct Mb { int R, B, Tm; uint64_t row_base, off_base, seq_base; };
-    std::vector<Mb> mbs;
-    std::vector<int> off_host;             /* concatenated off tables of this rank */
-    std::vector<uint32_t> rows_of_dev;     /* [num_mb][ndev] */
-    DevicePacked dp;
-    uint64_t dp_rows_cap = 0, dp_off_cap = 0, dp_seq_cap = 0;
+    struct Epoch {
+        uint64_t epoch_key_epoch = 0;
+        uint64_t num_mb = 0;
+        std::vector<Mb> mbs;
+        std::vector<int> off_host;         /* concatenated off tables of this rank */
+        std::vector<uint32_t> rows_of_dev; /* [num_mb][ndev] */
+        DevicePacked dp;
+        uint64_t rows_cap = 0, off_cap = 0, seq_cap = 0;
+        hipEvent_t free_event = nullptr;   /* recorded on the compute stream when the GPU is done with dp */
+        bool free_recorded = false;
+    } ep[2];
+    int cur = 0;
+    std::thread worker;
+    bool pending = false;
+    sbr_status pending_status = SBR_OK;
+    hipStream_t copy_stream = nullptr;
     /* work */
     WorkBuffers wb;
     uint8_t* block = nullptr;
@@ -270,15 +281,16 @@ struct sbr_fit_plan {
 namespace {
 
 sbr::MbView mb_view(const sbr_fit_plan* p, uint64_t i) {
-    const sbr_fit_plan::Mb& mb = p->mbs[i];
+    const sbr_fit_plan::Epoch& e = p->ep[p->cur];
+    const sbr_fit_plan::Mb& mb = e.mbs[i];
     sbr::MbView v;
     v.R = mb.R; v.B = mb.B; v.Tm = mb.Tm;
-    v.off = p->dp.off + mb.off_base;
-    v.steps = p->dp.steps + mb.seq_base;
-    v.prev_row = p->dp.prev_row + mb.row_base;
-    v.in_idx = p->dp.in_idx + mb.row_base;
-    v.out_idx = p->dp.out_idx + mb.row_base;
-    v.ctr = p->dp.ctr + mb.row_base;
+    v.off = e.dp.off + mb.off_base;
+    v.steps = e.dp.steps + mb.seq_base;
+    v.prev_row = e.dp.prev_row + mb.row_base;
+    v.in_idx = e.dp.in_idx + mb.row_base;
+    v.out_idx = e.dp.out_idx + mb.row_base;
+    v.ctr = e.dp.ctr + mb.row_base;
     return v;
 }
 
@@ -582,11 +594,14 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         st = dmalloc(&tmp, p->sort_temp_bytes);
         p->sort_temp = tmp;
     }
+    if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
+    for (int i = 0; i < 2 && st == SBR_OK; ++i)
+        if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 1);
-    if (st == SBR_OK) st = dmalloc(&p->ex_acc, 1);
+    if (st == SBR_OK) st = dmalloc(&p->ex_acc, 2); /* [0] examples, [1] negatives scored */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
     hipMemsetAsync(p->loss_acc, 0, sizeof(double), m->stream);
-    hipMemsetAsync(p->ex_acc, 0, sizeof(unsigned long long), m->stream);
+    hipMemsetAsync(p->ex_acc, 0, 2 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
     *out = p;
     return SBR_OK;
@@ -595,45 +610,53 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
 void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     if (!p) return;
     hipSetDevice(p->m->device);
+    if (p->pending) { p->worker.join(); p->pending = false; }
     hipStreamSynchronize(p->m->stream);
-    p->dp.release();
+    for (int i = 0; i < 2; ++i) {
+        p->ep[i].dp.release();
+        if (p->ep[i].free_event) hipEventDestroy(p->ep[i].free_event);
+    }
+    if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     p->wb.release();
     hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
     hipFree(p->loss_acc); hipFree(p->ex_acc);
     delete p;
 }
 
-sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches) {
-    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+/* Host side of one epoch: ≙ thread_rng.shuffle(partition) (sequence_model.rs:109) for every
+ * partition (so that each device also knows the row counts its peers contribute to a step), then
+ * packing of this rank's minibatches and upload of the packed index arrays on the copy stream. */
+static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
     sbr_model* m = p->m;
-    SBRCHK(ensure_device(m));
-    /* ≙ thread_rng.shuffle(partition) (sequence_model.rs:109) — every partition, so that each
-     * device also knows the row counts its peers contribute to a step */
+    HIPCHK(hipSetDevice(m->device));
     for (int q = 0; q < p->ndev; ++q)
         shuffle_pairs(p->seq_start.data() + (size_t)q * p->part_len, p->seq_len.data() + (size_t)q * p->part_len,
                       p->part_len, &p->part_rng[q]);
-    p->epoch_key_epoch = m->global_epoch;
+    e.epoch_key_epoch = m->global_epoch;
     m->global_epoch += 1;
     const uint64_t B = p->bmax;
     const uint64_t nmb = (p->part_len + B - 1) / B;
-    p->num_mb = nmb;
-    p->rows_of_dev.assign(nmb * p->ndev, 0);
+    e.num_mb = nmb;
+    e.rows_of_dev.assign(nmb * p->ndev, 0);
     for (int q = 0; q < p->ndev; ++q) {
         const uint32_t* ln = p->seq_len.data() + (size_t)q * p->part_len;
         for (uint64_t mb = 0; mb < nmb; ++mb) {
             const uint64_t p0 = mb * B, p1 = std::min(p0 + B, p->part_len);
             uint32_t r = 0;
             for (uint64_t i = p0; i < p1; ++i) r += ln[i] - 1;
-            p->rows_of_dev[mb * p->ndev + q] = r;
+            e.rows_of_dev[mb * p->ndev + q] = r;
         }
     }
-    /* pack this rank's minibatches */
     const uint64_t* st = p->seq_start.data() + (size_t)p->rank * p->part_len;
     const uint32_t* ln = p->seq_len.data() + (size_t)p->rank * p->part_len;
-    p->mbs.resize(nmb);
-    p->off_host.clear();
+    e.mbs.resize(nmb);
+    e.off_host.clear();
     std::vector<int> steps_all, prev_all;
     std::vector<uint32_t> in_all, out_all, ctr_all;
+    uint64_t total_rows = 0;
+    for (uint64_t i = 0; i < p->part_len; ++i) total_rows += ln[i] - 1;
+    steps_all.reserve(p->part_len); prev_all.reserve(total_rows);
+    in_all.reserve(total_rows); out_all.reserve(total_rows); ctr_all.reserve(total_rows);
     uint64_t row_base = 0, seq_base = 0;
     Packed pk;
     std::vector<const uint32_t*> first;
@@ -648,10 +671,10 @@ sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches)
             ctr_base.push_back(i * (uint64_t)p->T);
         }
         pack_sequences(first, nsteps, true, &ctr_base, p->T, &pk);
-        sbr_fit_plan::Mb& d = p->mbs[mb];
+        sbr_fit_plan::Mb& d = e.mbs[mb];
         d.R = pk.R; d.B = pk.B; d.Tm = pk.Tm;
-        d.row_base = row_base; d.seq_base = seq_base; d.off_base = p->off_host.size();
-        p->off_host.insert(p->off_host.end(), pk.off.begin(), pk.off.end());
+        d.row_base = row_base; d.seq_base = seq_base; d.off_base = e.off_host.size();
+        e.off_host.insert(e.off_host.end(), pk.off.begin(), pk.off.end());
         steps_all.insert(steps_all.end(), pk.steps.begin(), pk.steps.end());
         prev_all.insert(prev_all.end(), pk.prev_row.begin(), pk.prev_row.end());
         in_all.insert(in_all.end(), pk.in_idx.begin(), pk.in_idx.end());
@@ -660,30 +683,65 @@ sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches)
         row_base += (uint64_t)pk.R;
         seq_base += (uint64_t)pk.B;
     }
-    HIPCHK(hipStreamSynchronize(m->stream));
-    if (row_base > p->dp_rows_cap || p->off_host.size() > p->dp_off_cap || seq_base > p->dp_seq_cap) {
-        p->dp.release();
-        SBRCHK(dmalloc(&p->dp.in_idx, row_base));
-        SBRCHK(dmalloc(&p->dp.out_idx, row_base));
-        SBRCHK(dmalloc(&p->dp.ctr, row_base));
-        SBRCHK(dmalloc(&p->dp.prev_row, row_base));
-        SBRCHK(dmalloc(&p->dp.off, p->off_host.size()));
-        SBRCHK(dmalloc(&p->dp.steps, seq_base));
-        p->dp_rows_cap = row_base; p->dp_off_cap = p->off_host.size(); p->dp_seq_cap = seq_base;
+    /* the GPU may still be reading this buffer's previous contents (two epochs ago) */
+    if (e.free_recorded) {
+        HIPCHK(hipEventSynchronize(e.free_event));
+        e.free_recorded = false;
     }
-    HIPCHK(hipMemcpy(p->dp.in_idx, in_all.data(), row_base * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dp.out_idx, out_all.data(), row_base * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dp.ctr, ctr_all.data(), row_base * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dp.prev_row, prev_all.data(), row_base * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dp.off, p->off_host.data(), p->off_host.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(p->dp.steps, steps_all.data(), seq_base * 4, hipMemcpyHostToDevice));
-    if (out_num_minibatches) *out_num_minibatches = nmb;
+    if (row_base > e.rows_cap || e.off_host.size() > e.off_cap || seq_base > e.seq_cap) {
+        e.dp.release();
+        SBRCHK(dmalloc(&e.dp.in_idx, row_base));
+        SBRCHK(dmalloc(&e.dp.out_idx, row_base));
+        SBRCHK(dmalloc(&e.dp.ctr, row_base));
+        SBRCHK(dmalloc(&e.dp.prev_row, row_base));
+        SBRCHK(dmalloc(&e.dp.off, e.off_host.size()));
+        SBRCHK(dmalloc(&e.dp.steps, seq_base));
+        e.rows_cap = row_base; e.off_cap = e.off_host.size(); e.seq_cap = seq_base;
+    }
+    hipStream_t cs = p->copy_stream;
+    HIPCHK(hipMemcpyAsync(e.dp.in_idx, in_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.out_idx, out_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.ctr, ctr_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.prev_row, prev_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.off, e.off_host.data(), e.off_host.size() * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.steps, steps_all.data(), seq_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipStreamSynchronize(cs));
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    if (p->pending) { /* the next epoch was prefetched: hand the current buffers back and switch */
+        p->worker.join();
+        p->pending = false;
+        SBRCHK(p->pending_status);
+        sbr_fit_plan::Epoch& old = p->ep[p->cur];
+        HIPCHK(hipEventRecord(old.free_event, m->stream));
+        old.free_recorded = true;
+        p->cur ^= 1;
+    } else {
+        sbr_fit_plan::Epoch& e = p->ep[p->cur];
+        HIPCHK(hipEventRecord(e.free_event, m->stream));
+        e.free_recorded = true;
+        SBRCHK(build_epoch(p, e));
+    }
+    if (out_num_minibatches) *out_num_minibatches = p->ep[p->cur].num_mb;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p) {
+    if (!p || p->pending) return SBR_ERR_INVALID_ARGUMENT;
+    p->pending = true;
+    p->pending_status = SBR_OK;
+    p->worker = std::thread([p]() { p->pending_status = build_epoch(p, p->ep[p->cur ^ 1]); });
     return SBR_OK;
 }
 
 sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows) {
-    if (!p || !out_rows || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
-    *out_rows = (uint64_t)p->mbs[minibatch].R;
+    if (!p || !out_rows || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    *out_rows = (uint64_t)p->ep[p->cur].mbs[minibatch].R;
     return SBR_OK;
 }
 
@@ -694,21 +752,22 @@ sbr_status sbr_fit_exchange_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
 }
 
 sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_exchange_out) {
-    if (!p || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     void* block = device_exchange_out ? device_exchange_out : p->block;
-    const sbr_fit_plan::Mb& mb = p->mbs[minibatch];
+    const sbr_fit_plan::Epoch& ep = p->ep[p->cur];
+    const sbr_fit_plan::Mb& mb = ep.mbs[minibatch];
     const sbr::MbView mv = mb_view(p, minibatch);
     const sbr::BlockView bv = block_view(m, block, p->rmax);
-    const int* off_host = p->off_host.data() + mb.off_base;
+    const int* off_host = ep.off_host.data() + mb.off_base;
     {
         ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng ? (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
     }
     {
         ScopedTimer t(m, SBR_K_SCORE, 1);
-        sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], p->epoch_key_epoch), mb.R, m->stream);
+        sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch), mb.R, m->stream);
     }
     sbr::launch_block_header(bv, p->wb.v, mb.R, m->stream);
     {
@@ -722,7 +781,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_
 }
 
 sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* device_exchange_all) {
-    if (!p || minibatch >= p->num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     const uint8_t* all = reinterpret_cast<const uint8_t*>(device_exchange_all ? device_exchange_all : p->block);
@@ -734,7 +793,7 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* d
     }
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, p->ndev, p->rmax, p->rows_of_dev.data() + minibatch * p->ndev,
+        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, p->ndev, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch * p->ndev,
                                  p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -763,6 +822,17 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
     return SBR_OK;
 }
 
+sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    HIPCHK(hipStreamSynchronize(p->m->stream));
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(hipMemcpy(v, p->ex_acc, sizeof(v), hipMemcpyDeviceToHost));
+    if (out_examples) *out_examples = v[0];
+    if (out_negatives_scored) *out_negatives_scored = v[1];
+    return SBR_OK;
+}
+
 sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
                          float* out_loss) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
@@ -773,6 +843,7 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     for (uint32_t e = 0; e < m->hp.num_epochs && st == SBR_OK; ++e) {
         uint64_t nmb = 0;
         st = sbr_fit_epoch_prepare(p, &nmb);
+        if (st == SBR_OK && e + 1 < m->hp.num_epochs) st = sbr_fit_epoch_prefetch(p); /* host packs epoch e+1 while the GPU runs e */
         for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) st = sbr_fit_step(p, mb);
     }
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);

@@ -55,19 +55,32 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // ------------------------------------------------------------------------------------------------
 // header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction,
 // compared with a tolerance) and example count
-__global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, int R, const float* loss) {
+__global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, int R, const float* loss, const uint32_t* tries) {
     __shared__ double part[16];
+    __shared__ unsigned int tpart[16];
     double acc = 0.0;
-    for (int r = threadIdx.x; r < R; r += 1024) acc += (double)loss[r];
+    unsigned int tacc = 0;
+    for (int r = threadIdx.x; r < R; r += 1024) {
+        acc += (double)loss[r];
+        tacc += tries[r];
+    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc += __shfl_xor(acc, off, 64);
+        tacc += __shfl_xor(tacc, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = acc;
+        tpart[threadIdx.x >> 6] = tacc;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         double tot = 0.0;
-        for (int i = 0; i < 16; ++i) tot += part[i];
+        unsigned int ttot = 0;
+        for (int i = 0; i < 16; ++i) { tot += part[i]; ttot += tpart[i]; }
         header[0] = (uint32_t)R;
-        header[1] = header[2] = header[3] = 0;
+        header[1] = ttot; /* negatives scored in this minibatch (reporting only) */
+        header[2] = header[3] = 0;
         *reinterpret_cast<double*>(header + 4) = tot;
         *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
     }
@@ -271,24 +284,25 @@ __global__ void ewma_dense_final_kernel(const float* partials, int nchunks, int 
 // ------------------------------------------------------------------------------------------------
 // K2: LSTM step, forward.  Grid = (32-row tiles of step t) x (16-unit tiles); one wave per gate.
 // Wave g computes z_g = [x_t ; h_{t-1}] Wp_g + b_g for the workgroup's 32 rows x 16 units on
-// v_mfma_f32_16x16x4_f32 (accumulator seeded with the bias, k ascending).  Its whole weight
-// fragment column (2D x 16 floats) is requested from L2 before the A tile is staged, so the two
-// latencies overlap; the A tile ([E[in] ; h_prev], 32 x 2D) goes through LDS; the four gates meet
-// in LDS and the cell is applied by all threads.  Many small workgroups per CU overlap each
-// other's staging, MFMA and epilogue phases.
+// v_mfma_f32_16x16x4_f32 (accumulator seeded with the bias, k ascending).  The A operand goes
+// through LDS in two halves that share one buffer: the gathered x_t rows (k < D) first, the h_{t-1}
+// rows (k >= D) — already in registers — second; the gate pre-activations then meet in the same
+// buffer and the cell is applied by all threads.  Weight fragments (Wp packing, 16 B per lane per
+// 4 k-steps) are requested a half ahead.  16.5 KiB of LDS and ~80 VGPRs per workgroup keep 6+
+// workgroups resident per CU, so staging, MFMA and epilogue phases of different workgroups overlap.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG>
 __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbView mb, int t, float* H, WorkView w) {
-    constexpr int K2 = 2 * D;
-    constexpr int LDA = K2 + 2;
-    constexpr int NS = K2 / 16;
+    constexpr int LDA = D + 2;
+    constexpr int NSH = D / 16;       // weight k-blocks (16 k each) per half
     constexpr int RT = 2;             // 16-row tiles per workgroup
     constexpr int ROWS = 16 * RT;
     constexpr int NT = NG * 64;
     constexpr int LDZ = NG * 16 + 1;
-    constexpr int PF = NS < 16 ? NS : 16;  // weight k-blocks held in registers at once
-    __shared__ float As[ROWS * LDA];
-    __shared__ float Zs[ROWS * LDZ];
+    constexpr int PF = NSH < 8 ? NSH : 8;
+    constexpr int LDS_FLOATS = ROWS * (LDA > LDZ ? LDA : LDZ);  // A halves and the gate exchange share one buffer
+    __shared__ float As[LDS_FLOATS];
+    float* Zs = As;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,68 +314,81 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
     const int b0 = blockIdx.x * ROWS;
     const int nrows = bt - b0 < ROWS ? bt - b0 : ROWS;
     const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
-    // 1. weight fragments of this wave's gate: request the first PF k-blocks now
-    const float* wp = m.Wp + (((size_t)(ut * NG + g) * NS) * 64 + lane) * 4;
+    const float* wp = m.Wp + (((size_t)(ut * NG + g) * (2 * NSH)) * 64 + lane) * 4;
     float4 bf[PF];
 #pragma unroll
     for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)S * 256);
     const float bias = m.bW[g * D + ut * 16 + j16];
-    // 2. stage A: all gathers of the tile in flight together
-    constexpr int NV = ROWS * (K2 / 4);  // float4 slots in the tile
+    // both halves of the A tile are requested up front
+    constexpr int NV = ROWS * (D / 4);
     constexpr int ITER = (NV + NT - 1) / NT;
-    float4 av[ITER];
+    float4 xv[ITER], hv[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int idx = tid + it * NT;
-        const int i = idx / (K2 / 4);
-        const int c4 = (idx % (K2 / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i = idx / (D / 4);
+        const int c4 = (idx % (D / 4)) * 4;
+        xv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < NV && i < nrows) {
-            if (c4 < D) v = ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4);
-            else if (t > 0) v = ld4(H + (size_t)(prev_begin + b0 + i) * D + (c4 - D));
+            xv[it] = ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4);
+            if (t > 0) hv[it] = ld4(H + (size_t)(prev_begin + b0 + i) * D + c4);
         }
-        av[it] = v;
     }
+    auto stage = [&](const float4* v) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * NT;
-        if (idx < NV) {
-            const int i = idx / (K2 / 4);
-            const int c4 = (idx % (K2 / 4)) * 4;
-            float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
-            dst[0] = make_float2(av[it].x, av[it].y);
-            dst[1] = make_float2(av[it].z, av[it].w);
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < NV) {
+                const int i = idx / (D / 4);
+                const int c4 = (idx % (D / 4)) * 4;
+                float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
+                dst[0] = make_float2(v[it].x, v[it].y);
+                dst[1] = make_float2(v[it].z, v[it].w);
+            }
         }
-    }
-    __syncthreads();
-    // 3. MFMA
+    };
     f32x4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){bias, bias, bias, bias};
+    auto mma_half = [&](int half) {
 #pragma unroll
-    for (int S0 = 0; S0 < NS; S0 += PF) {
-        if (S0 > 0) {
+        for (int S0 = 0; S0 < NSH; S0 += PF) {
+            float4 cur[PF];
 #pragma unroll
-            for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(S0 + S) * 256);
-        }
+            for (int S = 0; S < PF; ++S) cur[S] = bf[S];
+            // request the next group of weight k-blocks (possibly of the other half)
+            const int nextS = half * NSH + S0 + PF;
+            if (nextS < 2 * NSH) {
 #pragma unroll
-        for (int S = 0; S < PF; ++S) {
+                for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(nextS + S) * 256);
+            }
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float* arow = &As[(rt * 16 + j16) * LDA + 16 * (S0 + S) + kq];
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], bf[S].x, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], bf[S].y, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], bf[S].z, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], bf[S].w, acc[rt], 0, 0, 0);
+            for (int S = 0; S < PF; ++S) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float* arow = &As[(rt * 16 + j16) * LDA + 16 * (S0 + S) + kq];
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+                }
             }
         }
-    }
+    };
+    stage(xv);
+    __syncthreads();
+    mma_half(0);
+    __syncthreads();
+    stage(hv);
+    __syncthreads();
+    mma_half(1);
+    __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) Zs[(rt * 16 + kq * 4 + reg) * LDZ + g * 16 + j16] = acc[rt][reg];
     __syncthreads();
-    // 4. cell: (row, unit) pairs over all threads
     for (int e = tid; e < ROWS * 16; e += NT) {
         const int i = e >> 4;
         const int uu = e & 15;
@@ -440,20 +467,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_cell_kernel(ModelView m, MbView 
 template <int D, int NG>
 struct BwdCfg {
     static constexpr int NGD = NG * D;
-    static constexpr int RT = NGD <= 512 ? 2 : 1;  // keep the dz tile <= 64 KiB of LDS
+    static constexpr int kparts() {
+        for (int kp = 1; kp <= 8; ++kp)
+            if (NGD % kp == 0 && NGD / kp <= 256 && (NGD / kp) % 16 == 0) return kp;
+        return 1;
+    }
+    static constexpr int KP = kparts();  // the dz tile goes through LDS in KP column parts
+    static constexpr int PW = NGD / KP;
+    static constexpr int RT = 2;
 };
 
 template <int D, int NG>
 __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView mb, int t, BlockView blk, WorkView w) {
     constexpr int K2 = 2 * D;
     constexpr int NGD = NG * D;
-    constexpr int LDZ = NGD + 2;
-    constexpr int NS = NGD / 16;
+    constexpr int KP = BwdCfg<D, NG>::KP;
+    constexpr int PW = BwdCfg<D, NG>::PW;
+    constexpr int LDZ = PW + 2;
+    constexpr int NSP = PW / 16;  // weight k-blocks per part
     constexpr int RT = BwdCfg<D, NG>::RT;
     constexpr int ROWS = 16 * RT;
     constexpr int CTW = K2 / 16 < 4 ? K2 / 16 : 4;  // column tiles (= busy waves) per workgroup
-    constexpr int PF = NS % 8 == 0 ? 8 : (NS % 6 == 0 ? 6 : (NS % 4 == 0 ? 4 : (NS % 3 == 0 ? 3 : (NS % 2 == 0 ? 2 : 1))));
-    extern __shared__ __attribute__((aligned(16))) float Zs[];
+    constexpr int PF = NSP % 8 == 0 ? 8 : (NSP % 6 == 0 ? 6 : (NSP % 4 == 0 ? 4 : (NSP % 3 == 0 ? 3 : (NSP % 2 == 0 ? 2 : 1))));
+    __shared__ float Zs[ROWS * LDZ];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -465,57 +501,67 @@ __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView 
     const int nrows = bt - b0 < ROWS ? bt - b0 : ROWS;
     const int ct = blockIdx.y * CTW + wave;
     const bool busy = wave < CTW;
-    const float* wp = m.WTp + ((size_t)(busy ? ct : 0) * NS * 64 + lane) * 4;
+    const float* wp = m.WTp + ((size_t)(busy ? ct : 0) * (NGD / 16) * 64 + lane) * 4;
     float4 bf[PF];
 #pragma unroll
     for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)S * 256);
-    constexpr int NV = ROWS * (NGD / 4);
+    constexpr int NV = ROWS * (PW / 4);
     constexpr int ITER = (NV + 255) / 256;
-    float4 zv[ITER];
+    float4 zv[KP][ITER];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * 256;
-        const int i = idx / (NGD / 4);
-        const int c4 = (idx % (NGD / 4)) * 4;
-        zv[it] = (idx < NV && i < nrows) ? ld4(w.dZ + (size_t)(row_begin + b0 + i) * NGD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int p = 0; p < KP; ++p)
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < NV) {
-            const int i = idx / (NGD / 4);
-            const int c4 = (idx % (NGD / 4)) * 4;
-            float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + c4]);
-            dst[0] = make_float2(zv[it].x, zv[it].y);
-            dst[1] = make_float2(zv[it].z, zv[it].w);
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            const int i = idx / (PW / 4);
+            const int c4 = (idx % (PW / 4)) * 4;
+            zv[p][it] = (idx < NV && i < nrows) ? ld4(w.dZ + (size_t)(row_begin + b0 + i) * NGD + p * PW + c4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    }
-    __syncthreads();
-    if (!busy) return;
     f32x4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int S0 = 0; S0 < NS; S0 += PF) {
-        float4 cur[PF];
 #pragma unroll
-        for (int S = 0; S < PF; ++S) cur[S] = bf[S];
-        if (S0 + PF < NS) {
+    for (int p = 0; p < KP; ++p) {
+        if (p > 0) __syncthreads();
 #pragma unroll
-            for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(S0 + PF + S) * 256);
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NV) {
+                const int i = idx / (PW / 4);
+                const int c4 = (idx % (PW / 4)) * 4;
+                float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + c4]);
+                dst[0] = make_float2(zv[p][it].x, zv[p][it].y);
+                dst[1] = make_float2(zv[p][it].z, zv[p][it].w);
+            }
         }
+        __syncthreads();
+        if (busy) {
 #pragma unroll
-        for (int S = 0; S < PF; ++S) {
+            for (int S0 = 0; S0 < NSP; S0 += PF) {
+                float4 cur[PF];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * (S0 + S) + kq];
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
-                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+                for (int S = 0; S < PF; ++S) cur[S] = bf[S];
+                const int nextS = p * NSP + S0 + PF;
+                if (nextS < NGD / 16) {
+#pragma unroll
+                    for (int S = 0; S < PF; ++S) bf[S] = ld4(wp + (size_t)(nextS + S) * 256);
+                }
+#pragma unroll
+                for (int S = 0; S < PF; ++S) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * (S0 + S) + kq];
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+                    }
+                }
             }
         }
     }
+    if (!busy) return;
     const int col = ct * 16 + c16;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -812,14 +858,16 @@ __global__ void accumulate_loss_kernel(const uint8_t* all_blocks, uint64_t block
                                        unsigned long long* ex_acc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double l = *loss_acc;
-    unsigned long long e = *ex_acc;
+    unsigned long long e = ex_acc[0], tr = ex_acc[1];
     for (int q = 0; q < ndev; ++q) {
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
         l += *reinterpret_cast<const double*>(hdr + 4);
         e += *reinterpret_cast<const unsigned long long*>(hdr + 6);
+        tr += hdr[1];
     }
     *loss_acc = l;
-    *ex_acc = e;
+    ex_acc[0] = e;
+    ex_acc[1] = tr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -992,7 +1040,7 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
 }
 
 void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
-    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(1024), 0, s, blk.header, rows_host, w.loss);
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(1024), 0, s, blk.header, rows_host, w.loss, w.tries);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
@@ -1019,24 +1067,12 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
             constexpr int CTW = 2 * DD / 16 < 4 ? 2 * DD / 16 : 4;
             if (m.ng == 4) {
                 constexpr int ROWS = 16 * BwdCfg<DD, 4>::RT;
-                constexpr size_t lds = (size_t)ROWS * (4 * DD + 2) * sizeof(float);
-                static bool attr_set_4 = false; /* dynamic LDS above 64 KiB needs the opt-in */
-                if (!attr_set_4) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    attr_set_4 = true;
-                }
                 hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 4>), dim3(cell_blocks), dim3(256), 0, s, m, mb, t, blk, w);
-                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 4>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
+                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 4>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), 0, s, m, mb, t, blk, w);
             } else {
                 constexpr int ROWS = 16 * BwdCfg<DD, 3>::RT;
-                constexpr size_t lds = (size_t)ROWS * (3 * DD + 2) * sizeof(float);
-                static bool attr_set_3 = false; /* dynamic LDS above 64 KiB needs the opt-in */
-                if (!attr_set_3) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_gemm_kernel<DD, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    attr_set_3 = true;
-                }
                 hipLaunchKernelGGL((lstm_bwd_cell_kernel<DD, 3>), dim3(cell_blocks), dim3(256), 0, s, m, mb, t, blk, w);
-                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 3>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), lds, s, m, mb, t, blk, w);
+                hipLaunchKernelGGL((lstm_bwd_gemm_kernel<DD, 3>), dim3((bt + ROWS - 1) / ROWS, (2 * DD / 16) / CTW), dim3(256), 0, s, m, mb, t, blk, w);
             }
         });
     }

@@ -39,8 +39,11 @@ def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None):
     import torch.distributed as dist
 
     gathered = backend.gathered_buffer(world)
-    for _ in range(num_epochs):
-        nmb = backend.epoch_prepare()
+    for e in range(num_epochs):
+        try:
+            nmb = backend.epoch_prepare(prefetch_next=e + 1 < num_epochs)
+        except TypeError:  # backends without host-side prefetch
+            nmb = backend.epoch_prepare()
         for mb in range(nmb):
             local = backend.local_block(mb)
             if world > 1:
@@ -70,8 +73,11 @@ class HipBackend:
         self.block_bytes = self.plan.exchange_bytes()
         self.local = torch.zeros(self.block_bytes, dtype=torch.uint8, device="cuda")
 
-    def epoch_prepare(self) -> int:
-        return self.plan.epoch_prepare()
+    def epoch_prepare(self, prefetch_next: bool = False) -> int:
+        n = self.plan.epoch_prepare()
+        if prefetch_next:
+            self.plan.epoch_prefetch()
+        return n
 
     def local_block(self, minibatch: int):
         self.plan.step_local(minibatch, self.local.data_ptr())

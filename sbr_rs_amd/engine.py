@@ -56,6 +56,9 @@ class FitPlan:
         _check(self._L.sbr_fit_epoch_prepare(self._h, C.byref(n)))
         return n.value
 
+    def epoch_prefetch(self):
+        _check(self._L.sbr_fit_epoch_prefetch(self._h))
+
     def minibatch_rows(self, mb: int) -> int:
         n = C.c_uint64()
         _check(self._L.sbr_fit_minibatch_rows(self._h, mb, C.byref(n)))
@@ -79,6 +82,11 @@ class FitPlan:
         loss, ex = C.c_float(), C.c_uint64()
         _check(self._L.sbr_fit_end(self._h, C.byref(loss), C.byref(ex)))
         return loss.value, ex.value
+
+    def counters(self):
+        ex, neg = C.c_uint64(), C.c_uint64()
+        _check(self._L.sbr_fit_counters(self._h, C.byref(ex), C.byref(neg)))
+        return ex.value, neg.value
 
     def debug_fetch(self, which: int, rows: int) -> np.ndarray:
         d = self.model.dim

@@ -223,11 +223,14 @@ def main():
             bytes_per_row = (2 + k_mean) * 4 * d + (1 + k_mean) * 4
             bytes_per_launch = bytes_per_row * rows_per_launch
             achieved = bytes_per_launch / (score["ms_per_launch"] * 1e-3) / 1e9
+            # HBM bytes per launch from the rocprofv3 PMC passes of this round (FETCH_SIZE and WRITE_SIZE in
+            # separate runs, gfx950 half-count correction applied; profiles/score_kernel_pmc.json), scaled
+            # from bytes per packed row to this run's rows per launch
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and d == 128:
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_row") * rows_per_launch
                 except Exception:
                     traffic = None
             roofline = {"kernel": "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)", "bound": "hbm",

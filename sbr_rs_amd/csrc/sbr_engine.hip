@@ -202,7 +202,7 @@ struct WorkBuffers {
     sbr::WorkView v{};
     void release() {
         hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
-        hipFree(v.partials); hipFree(v.loss); hipFree(v.tries);
+        hipFree(v.partials); hipFree(v.loss); hipFree(v.tries); hipFree(v.part_loss); hipFree(v.part_tries);
         v = sbr::WorkView{};
     }
 };
@@ -218,6 +218,8 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         SBRCHK(dmalloc(&v.dH, rmax * d));
         SBRCHK(dmalloc(&v.loss, rmax));
         SBRCHK(dmalloc(&v.tries, rmax));
+        SBRCHK(dmalloc(&v.part_loss, 2048));
+        SBRCHK(dmalloc(&v.part_tries, 2048));
         if (m->ng) {
             SBRCHK(dmalloc(&v.dZ, rmax * d * (uint64_t)m->ng));
             SBRCHK(dmalloc(&v.dHrec, bmax * d));
@@ -769,7 +771,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_
         ScopedTimer t(m, SBR_K_SCORE, 1);
         sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch), mb.R, m->stream);
     }
-    sbr::launch_block_header(bv, p->wb.v, mb.R, m->stream);
+    sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng ? (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);

@@ -52,6 +52,8 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     float* partials;        /* dense-gradient chunk partials */
     float* loss;            /* [Rmax] */
     uint32_t* tries;        /* [Rmax] */
+    double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
+    unsigned int* part_tries;
 };
 
 /* recurrent forward over all steps of the minibatch (LSTM: one launch per step) */
@@ -62,7 +64,7 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                   int rows_host, hipStream_t s);
 /* debug only: dloss/dh of every packed row (the training path never materialises it) */
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
-void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s);
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s);
 /* BPTT + dense gradient into blk.dense */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s);

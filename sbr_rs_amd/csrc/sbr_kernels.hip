@@ -55,14 +55,15 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // ------------------------------------------------------------------------------------------------
 // header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction,
 // compared with a tolerance) and example count
-__global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, int R, const float* loss, const uint32_t* tries) {
-    __shared__ double part[16];
-    __shared__ unsigned int tpart[16];
+__global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
+                                                          const unsigned int* part_tries, int nparts) {
+    __shared__ double part[4];
+    __shared__ unsigned int tpart[4];
     double acc = 0.0;
     unsigned int tacc = 0;
-    for (int r = threadIdx.x; r < R; r += 1024) {
-        acc += (double)loss[r];
-        tacc += tries[r];
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        acc += part_loss[i];
+        tacc += part_tries[i];
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -75,13 +76,10 @@ __global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, in
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tot = 0.0;
-        unsigned int ttot = 0;
-        for (int i = 0; i < 16; ++i) { tot += part[i]; ttot += tpart[i]; }
         header[0] = (uint32_t)R;
-        header[1] = ttot; /* negatives scored in this minibatch (reporting only) */
+        header[1] = tpart[0] + tpart[1] + tpart[2] + tpart[3]; /* negatives scored in this minibatch (reporting only) */
         header[2] = header[3] = 0;
-        *reinterpret_cast<double*>(header + 4) = tot;
+        *reinterpret_cast<double*>(header + 4) = part[0] + part[1] + part[2] + part[3];
         *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
     }
 }
@@ -97,6 +95,8 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+    double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
+    unsigned int tries_part = 0;
     for (int base = wave * GPW; base < mb.R; base += nwaves * GPW) {
         const int r = base + grp;
         const bool valid = r < mb.R;
@@ -144,8 +144,26 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
                 blk.out_idx[r] = pi;
                 w.loss[r] = l;
                 w.tries[r] = tries;
+                loss_part += (double)l;
+                tries_part += tries;
             }
         }
+    }
+    __shared__ double s_loss[4];
+    __shared__ unsigned int s_tries[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        loss_part += __shfl_xor(loss_part, off, 64);
+        tries_part += __shfl_xor(tries_part, off, 64);
+    }
+    if (lane == 0) {
+        s_loss[threadIdx.x >> 6] = loss_part;
+        s_tries[threadIdx.x >> 6] = tries_part;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
     }
 }
 
@@ -703,7 +721,15 @@ __global__ void dense_reduce_local_kernel(const float* partials, int nchunks, si
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float acc = partials[i];
-    for (int c = 1; c < nchunks; ++c) acc = acc + partials[(size_t)c * n + i];
+    int c = 1;
+    for (; c + 8 <= nchunks; c += 8) { /* loads run ahead of the ordered add chain */
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partials[(size_t)(c + j) * n + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = acc + v[j];
+    }
+    for (; c < nchunks; ++c) acc = acc + partials[(size_t)c * n + i];
     dense[i] = acc;
 }
 
@@ -1022,12 +1048,16 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
     }
 }
 
+static int score_grid(int d, int rows) {
+    const int gpb = 4 * (64 / (d / 4));
+    return grid_for_groups(rows, gpb);
+}
+
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s) {
     if (rows_host > 0) {
         DISPATCH_D(m.d, {
-            const int gpb = 4 * (64 / (DD / 4));
-            hipLaunchKernelGGL((score_kernel<DD>), dim3(grid_for_groups(rows_host, gpb)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+            hipLaunchKernelGGL((score_kernel<DD>), dim3(score_grid(DD, rows_host)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
         });
     }
 }
@@ -1039,8 +1069,9 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
     });
 }
 
-void launch_block_header(const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
-    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(1024), 0, s, blk.header, rows_host, w.loss, w.tries);
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, blk.header, rows_host, w.part_loss, w.part_tries,
+                       rows_host > 0 ? score_grid(m.d, rows_host) : 0);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

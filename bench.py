@@ -15,8 +15,8 @@ embedding_dim 128, LSTM(Normal) + WARP + Adagrad, the largest single-GPU configu
 the north-star HBM-roofline target is quoted on.  (configs[1], MovieLens-100K, is 1.3K
 subsequences — a parity/MRR case, run here untimed for the `test_mrr` field and in
 tests/test_parity_gpu.py.)  With N GPUs the user count scales with N (weak scaling): users are
-sharded, every GPU runs its own partition, and one all-gather per step (RCCL) exchanges the
-devices' blocks.
+sharded, every GPU runs its own partition, and per step one all-to-all + one all-gather (RCCL)
+of dense per-owner gradient chunks realise the synchronised optimiser step.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the gather + WARP-score kernel against the
 HBM roofline; `kernels` lists every kernel family's measured time; `cpu_baseline` is the CPU
@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
 
     import torch
@@ -132,11 +134,11 @@ def main():
     torch.cuda.set_device(local_rank)
     from sbr_rs_amd import engine
     from sbr_rs_amd._abi import Debug
-    from sbr_rs_amd.distributed import HipBackend
+    from sbr_rs_amd.distributed import HipBackend, exchange_step
 
     engine.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -147,9 +149,12 @@ def main():
     ptr, items = synthetic_csr(total_users, args.items, args.max_len)
     hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
     model = engine.Model(hp)
-    backend = HipBackend(model, (ptr, items))
+    exchange = world > 1 or args.force_exchange
+    backend = HipBackend(model, (ptr, items), world if not args.force_exchange else max(world, 2))
     plan = backend.plan
-    gathered = backend.gathered_buffer(world) if world > 1 else None
+    if args.force_exchange and world == 1:  # one rank owns the whole table: a single chunk
+        backend.send = backend.send[:backend.chunk]
+    bufs = backend.buffers(world) if exchange else None
 
     tp0 = time.perf_counter()
     state = {"nmb": backend.epoch_prepare(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0}
@@ -163,19 +168,18 @@ def main():
                 state["reprepared_in_timed_region"] += 1
         mb = state["mb"]
         rows = plan.minibatch_rows(mb)
-        local = backend.local_block(mb)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, local)
-            backend.apply(mb, gathered)
+        backend.compute_local(mb)
+        if exchange:
+            exchange_step(backend, mb, world, bufs)  # scatter, all-to-all, owner reduce, all-gather, apply
         else:
-            backend.apply(mb, local)
+            backend.apply_single(mb)
         state["mb"] += 1
         return rows
 
     def sync():
         model.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -192,7 +196,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -268,7 +272,7 @@ def main():
                 out["test_mrr"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     backend.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

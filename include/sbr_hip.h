@@ -114,7 +114,7 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
  *   begin          = chunking + shuffle + partition      (sequence_model.rs:76-98)
  *   epoch_prepare  = per-epoch reshuffle (:109) + packing + upload; returns #minibatches
  *   step           = one minibatch: forward, negative sampling, loss, BPTT, optimiser (:111-169)
- *   step_local/step_apply = the two halves of step around the multi-device exchange
+ *   step_local/step_apply = the two halves of step (compute, optimiser); multi-device: see below
  *   end            = ≙ the fold at :173-177; returns loss_sum / (1 + examples)            */
 sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t* item_ids,
                          uint64_t num_users, sbr_fit_plan** out);
@@ -131,14 +131,26 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
 sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored);
 void sbr_fit_plan_destroy(sbr_fit_plan* p);
 
-/* Multi-device halves of a step (user-sharded data parallelism, one process per GPU).
- * step_local leaves this device's contribution in the exchange block; the host all-gathers the
- * blocks of all devices (RCCL via torch.distributed) into one buffer laid out
- * [device][exchange_bytes]; step_apply consumes it.  Every device applies the identical update,
- * so replicas stay bit-identical. */
-sbr_status sbr_fit_exchange_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
-sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_exchange_out);
-sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* device_exchange_all);
+/* The two halves of a single-device step (sbr_fit_step = local + apply). */
+sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch);
+sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch);
+
+/* Multi-device step (user-sharded data parallelism, one process per GPU; ≙ the rendezvous of
+ * Parallelism::Synchronous, sequence_model.rs:163-166).  Table rows are owned in contiguous slices
+ * of ceil(num_items / num_devices) rows.  Per step, after sbr_fit_step_local:
+ *   scatter      : own entries reduced per row into num_devices dense chunks (send buffer, one chunk
+ *                  per owner; chunk = [G: S*dim f32][gb: S f32][flags: S u32]) + the small dense block
+ *                  [8-word header | dense grads]                       -> host: all-to-all of the chunks
+ *   owner_reduce : the devices' contributions for the owned slice, added in device order -> one chunk
+ *                                                                     -> host: all-gather of the chunks
+ *                                                                        and of the dense blocks
+ *   apply_table  : every device applies the identical update (replicas stay bit-identical).
+ * All pointers are device pointers supplied by the host (torch tensors in sbr_rs_amd/distributed.py). */
+sbr_status sbr_fit_chunk_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
+sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
+sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send, void* device_dense_out);
+sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk);
+sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all);
 
 /* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
 sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);

@@ -54,6 +54,13 @@ def lib():
         L.orc_fit_exchange_bytes.restype = C.c_uint64
         L.orc_fit_export_local.argtypes = [vp, C.c_int, vp]
         L.orc_fit_step_apply.argtypes = [vp, vp]
+        for name in ("orc_fit_chunk_bytes", "orc_fit_dense_bytes"):
+            getattr(L, name).argtypes = [vp]
+            getattr(L, name).restype = C.c_uint64
+        L.orc_fit_export_dense.argtypes = [vp, C.c_int, vp]
+        L.orc_fit_scatter.argtypes = [vp, C.c_int, vp]
+        L.orc_fit_owner_reduce.argtypes = [vp, vp, vp]
+        L.orc_fit_apply_table.argtypes = [vp, vp, vp]
         L.orc_fit_step.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
         L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
@@ -125,6 +132,7 @@ class OraclePlan:
         return lib().orc_fit_exchange_bytes(self._h)
 
     def step_local(self, mb: int, device: int = 0) -> np.ndarray:
+        """Compute device's local half-step and export its (single-device) exchange block."""
         _check(lib().orc_fit_step_local(self._h, device, mb))
         out = np.zeros(self.exchange_bytes(), dtype=np.uint8)
         _check(lib().orc_fit_export_local(self._h, device, _ptr(out)))
@@ -133,6 +141,37 @@ class OraclePlan:
     def step_apply(self, all_blocks: np.ndarray):
         all_blocks = np.ascontiguousarray(all_blocks, dtype=np.uint8)
         _check(lib().orc_fit_step_apply(self._h, _ptr(all_blocks)))
+
+    # ---- owner-reduce protocol (multi-device) ----
+    def chunk_bytes(self) -> int:
+        return lib().orc_fit_chunk_bytes(self._h)
+
+    def dense_bytes(self) -> int:
+        return lib().orc_fit_dense_bytes(self._h)
+
+    def compute_local(self, mb: int, device: int):
+        _check(lib().orc_fit_step_local(self._h, device, mb))
+
+    def scatter(self, device: int, ndev: int) -> np.ndarray:
+        out = np.zeros(ndev * self.chunk_bytes(), dtype=np.uint8)
+        _check(lib().orc_fit_scatter(self._h, device, _ptr(out)))
+        return out
+
+    def export_dense(self, device: int) -> np.ndarray:
+        out = np.zeros(self.dense_bytes(), dtype=np.uint8)
+        _check(lib().orc_fit_export_dense(self._h, device, _ptr(out)))
+        return out
+
+    def owner_reduce(self, recv: np.ndarray) -> np.ndarray:
+        recv = np.ascontiguousarray(recv, dtype=np.uint8)
+        out = np.zeros(self.chunk_bytes(), dtype=np.uint8)
+        _check(lib().orc_fit_owner_reduce(self._h, _ptr(recv), _ptr(out)))
+        return out
+
+    def apply_table(self, all_chunks: np.ndarray, dense_all: np.ndarray):
+        all_chunks = np.ascontiguousarray(all_chunks, dtype=np.uint8)
+        dense_all = np.ascontiguousarray(dense_all, dtype=np.uint8)
+        _check(lib().orc_fit_apply_table(self._h, _ptr(all_chunks), _ptr(dense_all)))
 
     def end(self):
         loss, ex = C.c_float(), C.c_uint64()

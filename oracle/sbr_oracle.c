@@ -636,6 +636,7 @@ static int orc_entry_cmp(const void* a, const void* b) {
  *  (SURVEY App. A-14); biases likewise for target/negative rows. */
 int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
     orc_model* m = p->m;
+    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: owner-reduce protocol below */
     int d = m->d, ndev = p->ndev;
     uint64_t Rmax = (uint64_t)p->Rmax, bytes = orc_fit_exchange_bytes(p), nd = orc_ndense(m);
     float lr = m->hp.learning_rate, l2 = m->hp.l2_penalty;
@@ -702,16 +703,165 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
     return SBR_OK;
 }
 
+/* ---- multi-device optimiser step: owner-reduce protocol ---------------------------------------
+ * (≙ the rendezvous of Parallelism::Synchronous, sequence_model.rs:163-166)
+ * Rows of the item table are owned in contiguous slices of S = ceil(I / ndev) rows.  Per step:
+ *   scatter      : device q reduces ITS OWN entries per row — sorted by (row, packed row, kind),
+ *                  duplicates added in that order — into a dense send buffer of ndev chunks
+ *                  (chunk p = the rows owned by device p): [G: S*d f32][gb: S f32][flags: S u32],
+ *                  flags bit0 = embedding row touched, bit1 = bias touched.
+ *   all-to-all   : chunk p of every device goes to device p.
+ *   owner_reduce : the owner adds the devices' contributions in device order (first toucher
+ *                  initialises, later ones add) -> one chunk of global sums for its rows.
+ *   all-gather   : of the owners' chunks (= global gradient sums of the whole table) and of the
+ *                  small dense blocks [8-word header | dense grads].
+ *   apply_table  : every device applies the identical Adagrad update to every touched row and
+ *                  to the dense parameters (device-order sum), so replicas stay bit-identical.
+ * With one device this is exactly orc_fit_step_apply's flat order. */
+static uint64_t orc_slice_rows(const orc_plan* p) { return ((uint64_t)p->m->hp.num_items + p->ndev - 1) / p->ndev; }
+uint64_t orc_fit_chunk_bytes(orc_plan* p) { return orc_slice_rows(p) * ((uint64_t)p->m->d + 2) * 4; }
+uint64_t orc_fit_dense_bytes(orc_plan* p) { return (8 + orc_ndense(p->m)) * 4; }
+
+int orc_fit_export_dense(orc_plan* p, int q, void* out) {
+    orc_local* L = &p->loc[q];
+    uint32_t* w = (uint32_t*)out;
+    memset(w, 0, 32);
+    w[0] = (uint32_t)L->R;
+    memcpy(w + 4, &L->loss_sum, 8);
+    memcpy(w + 6, &L->examples, 8);
+    memcpy(w + 8, L->dense, orc_ndense(p->m) * 4);
+    return SBR_OK;
+}
+
+int orc_fit_scatter(orc_plan* p, int q, void* send) {
+    orc_model* m = p->m;
+    orc_local* L = &p->loc[q];
+    int d = m->d;
+    uint64_t S = orc_slice_rows(p), cw = S * ((uint64_t)d + 2);
+    memset(send, 0, (size_t)p->ndev * cw * 4);
+    uint64_t ne = 3ull * L->R;
+    orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (ne ? ne : 1));
+    for (int r = 0; r < L->R; ++r) {
+        ent[3 * r].row = L->in_idx[r]; ent[3 * r].src = 3u * r;
+        ent[3 * r + 1].row = L->out_idx[r]; ent[3 * r + 1].src = 3u * r + 1;
+        ent[3 * r + 2].row = L->neg[r]; ent[3 * r + 2].src = 3u * r + 2;
+    }
+    qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
+    uint64_t i = 0;
+    while (i < ne) {
+        uint32_t row = ent[i].row;
+        uint64_t owner = row / S, lr = row % S;
+        float* chunk = (float*)send + owner * cw;
+        float* g = chunk + lr * d;
+        float* gb = chunk + S * d + lr;
+        uint32_t* fl = (uint32_t*)(chunk + S * d + S) + lr;
+        int first = 1, has_b = 0;
+        uint64_t j = i;
+        for (; j < ne && ent[j].row == row; ++j) {
+            uint32_t r = ent[j].src / 3, kind = ent[j].src % 3;
+            const float* srcv = kind == 0 ? L->dX + (size_t)r * d : L->H + (size_t)r * d;
+            float scale = kind == 0 ? 1.0f : kind == 1 ? -L->coef[r] : L->coef[r];
+            if (first) { for (int k = 0; k < d; ++k) g[k] = scale * srcv[k]; first = 0; }
+            else for (int k = 0; k < d; ++k) g[k] = g[k] + scale * srcv[k];
+            if (kind != 0) { *gb = has_b ? *gb + scale : scale; has_b = 1; }
+        }
+        *fl = 1u | (has_b ? 2u : 0u);
+        i = j;
+    }
+    free(ent);
+    return SBR_OK;
+}
+
+int orc_fit_owner_reduce(orc_plan* p, const void* recv, void* own_chunk) {
+    int d = p->m->d;
+    uint64_t S = orc_slice_rows(p), cw = S * ((uint64_t)d + 2);
+    float* out = (float*)own_chunk;
+    memset(out, 0, cw * 4);
+    uint32_t* ofl = (uint32_t*)(out + S * d + S);
+    for (int q = 0; q < p->ndev; ++q) {
+        const float* c = (const float*)recv + (size_t)q * cw;
+        const uint32_t* fl = (const uint32_t*)(c + S * d + S);
+        for (uint64_t i = 0; i < S; ++i) {
+            if (fl[i] & 1u) {
+                float* g = out + i * d;
+                const float* s = c + i * d;
+                if (ofl[i] & 1u) for (int k = 0; k < d; ++k) g[k] = g[k] + s[k];
+                else for (int k = 0; k < d; ++k) g[k] = s[k];
+            }
+            if (fl[i] & 2u) {
+                float* gb = out + S * d + i;
+                if (ofl[i] & 2u) *gb = *gb + c[S * d + i]; else *gb = c[S * d + i];
+            }
+            ofl[i] |= fl[i];
+        }
+    }
+    return SBR_OK;
+}
+
+int orc_fit_apply_table(orc_plan* p, const void* all_chunks, const void* dense_all) {
+    orc_model* m = p->m;
+    int d = m->d, ndev = p->ndev;
+    uint64_t S = orc_slice_rows(p), cw = S * ((uint64_t)d + 2), nd = orc_ndense(m), I = m->hp.num_items;
+    float lr = m->hp.learning_rate, l2 = m->hp.l2_penalty;
+    float* dg = (float*)malloc(nd * 4);
+    for (int q = 0; q < ndev; ++q) {
+        const uint32_t* w = (const uint32_t*)dense_all + (size_t)q * (8 + nd);
+        const float* dense = (const float*)(w + 8);
+        if (q == 0) memcpy(dg, dense, nd * 4); else for (uint64_t i = 0; i < nd; ++i) dg[i] = dg[i] + dense[i];
+        double ls; uint64_t ex;
+        memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
+        p->loss_sum += ls; p->examples += ex;
+    }
+    if (m->ng) {
+        int nz = m->ng * d;
+        for (size_t i = 0; i < (size_t)2 * d * nz; ++i) sbr_adagrad(&m->W[i], &m->Wacc[i], dg[i], lr, l2);
+        for (int j = 0; j < nz; ++j) sbr_adagrad(&m->bW[j], &m->bWacc[j], dg[(size_t)2 * d * nz + j], lr, l2);
+    } else {
+        for (int k = 0; k < d; ++k) sbr_adagrad(&m->alpha[k], &m->alpha_acc[k], dg[k], lr, l2);
+    }
+    free(dg);
+    for (uint64_t row = 0; row < I; ++row) {
+        const float* c = (const float*)all_chunks + (row / S) * cw;
+        uint64_t lr_ = row % S;
+        uint32_t fl = ((const uint32_t*)(c + S * d + S))[lr_];
+        if (fl & 1u) {
+            const float* g = c + lr_ * d;
+            float* wrow = m->E + (size_t)row * d; float* arow = m->Eacc + (size_t)row * d;
+            for (int k = 0; k < d; ++k) sbr_adagrad(&wrow[k], &arow[k], g[k], lr, l2);
+        }
+        if (fl & 2u) sbr_adagrad(&m->b[row], &m->bacc[row], c[S * d + lr_], lr, l2);
+    }
+    return SBR_OK;
+}
+
 /* One full optimiser step, all devices emulated in this process. */
 int orc_fit_step(orc_plan* p, uint64_t mb) {
-    uint64_t bytes = orc_fit_exchange_bytes(p);
-    char* all = (char*)malloc(bytes * p->ndev);
-    for (int q = 0; q < p->ndev; ++q) {
-        orc_fit_step_local(p, q, mb);
-        orc_fit_export_local(p, q, all + (size_t)q * bytes);
+    if (p->ndev == 1) {
+        uint64_t bytes = orc_fit_exchange_bytes(p);
+        char* blk = (char*)malloc(bytes);
+        orc_fit_step_local(p, 0, mb);
+        orc_fit_export_local(p, 0, blk);
+        int st = orc_fit_step_apply(p, blk);
+        free(blk);
+        return st;
     }
-    int st = orc_fit_step_apply(p, all);
-    free(all);
+    int n = p->ndev;
+    uint64_t cb = orc_fit_chunk_bytes(p), db = orc_fit_dense_bytes(p);
+    char* send = (char*)malloc((size_t)n * n * cb); /* [device][chunk] */
+    char* recv = (char*)malloc((size_t)n * cb);
+    char* all = (char*)malloc((size_t)n * cb);
+    char* dense = (char*)malloc((size_t)n * db);
+    for (int q = 0; q < n; ++q) {
+        orc_fit_step_local(p, q, mb);
+        orc_fit_scatter(p, q, send + (size_t)q * n * cb);
+        orc_fit_export_dense(p, q, dense + (size_t)q * db);
+    }
+    for (int owner = 0; owner < n; ++owner) {
+        for (int q = 0; q < n; ++q) memcpy(recv + (size_t)q * cb, send + ((size_t)q * n + owner) * cb, cb); /* all-to-all */
+        orc_fit_owner_reduce(p, recv, all + (size_t)owner * cb);                                            /* + all-gather */
+    }
+    int st = orc_fit_apply_table(p, all, dense);
+    free(send); free(recv); free(all); free(dense);
     return st;
 }
 

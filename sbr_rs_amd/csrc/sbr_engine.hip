@@ -581,10 +581,10 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     p->items.assign(item_ids, item_ids + nnz);
     p->bmax = m->hp.batch_sequences;
     p->rmax = p->bmax * (T - 1);
-    if ((uint64_t)ndev * 3 * p->rmax >= (1ull << 32) || part * T >= (1ull << 32)) { delete p; return SBR_ERR_INVALID_ARGUMENT; }
+    if (3 * p->rmax >= (1ull << 32) || part * T >= (1ull << 32)) { delete p; return SBR_ERR_INVALID_ARGUMENT; }
     sbr_status st = alloc_work(m, p->rmax, p->bmax, true, &p->wb);
     if (st == SBR_OK) { p->block_bytes = block_bytes_for(m, p->rmax); st = dmalloc(&p->block, p->block_bytes); }
-    const uint64_t max_entries = (uint64_t)ndev * 3 * p->rmax;
+    const uint64_t max_entries = 3 * p->rmax; /* only a device's own entries are ever sorted */
     int item_bits = 1;
     while ((1ull << item_bits) < (uint64_t)m->hp.num_items) ++item_bits;
     p->key_bits = 32 + item_bits;
@@ -747,17 +747,11 @@ sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uin
     return SBR_OK;
 }
 
-sbr_status sbr_fit_exchange_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
-    if (!p || !out_bytes) return SBR_ERR_INVALID_ARGUMENT;
-    *out_bytes = p->block_bytes;
-    return SBR_OK;
-}
-
-sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_exchange_out) {
+sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
-    void* block = device_exchange_out ? device_exchange_out : p->block;
+    void* block = p->block;
     const sbr_fit_plan::Epoch& ep = p->ep[p->cur];
     const sbr_fit_plan::Mb& mb = ep.mbs[minibatch];
     const sbr::MbView mv = mb_view(p, minibatch);
@@ -782,20 +776,20 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch, void* device_
     return SBR_OK;
 }
 
-sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* device_exchange_all) {
-    if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+/* single device: optimiser step straight from the local block */
+sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
+    if (!p || minibatch >= p->ep[p->cur].num_mb || p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
-    const uint8_t* all = reinterpret_cast<const uint8_t*>(device_exchange_all ? device_exchange_all : p->block);
-    if (!device_exchange_all && p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT;
-    sbr::launch_accumulate_loss(all, p->block_bytes, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    const uint8_t* all = p->block;
+    sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
-        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), p->ndev, m->stream);
+        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
     }
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, p->ndev, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch * p->ndev,
+        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, 1, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch,
                                  p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -804,9 +798,74 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch, const void* d
 
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch) {
     if (!p) return SBR_ERR_INVALID_ARGUMENT;
-    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: step_local + all-gather + step_apply */
-    SBRCHK(sbr_fit_step_local(p, minibatch, nullptr));
-    return sbr_fit_step_apply(p, minibatch, nullptr);
+    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: the owner-reduce halves below, driven by the host */
+    SBRCHK(sbr_fit_step_local(p, minibatch));
+    return sbr_fit_step_apply(p, minibatch);
+}
+
+/* ---- multi-device owner-reduce protocol ------------------------------------------ */
+static uint64_t slice_rows(const sbr_fit_plan* p) { return ((uint64_t)p->m->hp.num_items + p->ndev - 1) / p->ndev; }
+
+sbr_status sbr_fit_chunk_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
+    if (!p || !out_bytes) return SBR_ERR_INVALID_ARGUMENT;
+    *out_bytes = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
+    if (!p || !out_bytes) return SBR_ERR_INVALID_ARGUMENT;
+    *out_bytes = (8 + dense_count(p->m)) * 4;
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send, void* device_dense_out) {
+    if (!p || !device_send || !device_dense_out || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const sbr::BlockView bv = block_view(m, p->block, p->rmax);
+    const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys, p->keys_sorted, p->sort_temp,
+                            p->sort_temp_bytes, p->key_bits, m->stream);
+    }
+    /* small dense block = [8-word header | dense grads] */
+    HIPCHK(hipMemcpyAsync(device_dense_out, bv.header, 32, hipMemcpyDeviceToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(device_dense_out) + 32, bv.dense, dense_count(m) * 4,
+                          hipMemcpyDeviceToDevice, m->stream));
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk) {
+    if (!p || !device_recv || !device_own_chunk) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_owner_reduce(m->mv, device_recv, p->ndev, slice_rows(p), device_own_chunk, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all) {
+    if (!p || !device_table || !device_dense_all) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const uint64_t db = (8 + dense_count(m)) * 4;
+    const uint8_t* dall = reinterpret_cast<const uint8_t*>(device_dense_all);
+    sbr::launch_accumulate_loss(dall, db, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    {
+        ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
+        sbr::launch_dense_apply(m->mv, dall, db, 32, p->ndev, m->stream);
+    }
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_table_apply(m->mv, device_table, slice_rows(p), m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
 }
 
 sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples) {

@@ -880,6 +880,143 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ModelView m, const ui
     }
 }
 
+// ---- multi-device: owner-reduce protocol -----------------------------------------
+// chunk = [G: S*d f32][gb: S f32][flags: S u32] for a slice of S = ceil(I / ndev) table rows
+__device__ __forceinline__ float* chunk_ptr(void* base, uint64_t chunk, uint64_t S, int D) {
+    return reinterpret_cast<float*>(base) + chunk * S * ((uint64_t)D + 2);
+}
+__device__ __forceinline__ const float* chunk_ptr(const void* base, uint64_t chunk, uint64_t S, int D) {
+    return reinterpret_cast<const float*>(base) + chunk * S * ((uint64_t)D + 2);
+}
+
+__global__ void clear_chunk_flags_kernel(void* buf, int nchunks, uint64_t S, int D) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)nchunks * S) return;
+    float* c = chunk_ptr(buf, i / S, S, D);
+    reinterpret_cast<uint32_t*>(c + S * D + S)[i % S] = 0u;
+}
+
+// scatter: per-row ordered reduction of THIS device's entries into the send chunks
+template <int D>
+__global__ __launch_bounds__(256) void sparse_scatter_kernel(BlockView blk, const uint64_t* keys, uint64_t n, void* send,
+                                                             uint64_t S) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
+        const uint64_t key = keys[p];
+        const uint32_t row = (uint32_t)(key >> 32);
+        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) continue;
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+        float gb = 0.0f;
+        bool has_b = false, first = true;
+        for (uint64_t e = p; e < n; ++e) {
+            const uint64_t ke = keys[e];
+            if ((uint32_t)(ke >> 32) != row) break;
+            const uint32_t src = (uint32_t)ke;
+            const uint32_t r = src / 3, kind = src % 3;
+            const float* srcp = (kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg;
+            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
+            const float4 v = ld4(srcp);
+            if (first) {
+                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
+                first = false;
+            } else {
+                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
+                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
+            }
+            if (kind != 0) {
+                gb = has_b ? gb + scale : scale;
+                has_b = true;
+            }
+        }
+        float* c = chunk_ptr(send, row / S, S, D);
+        const uint64_t lr = row % S;
+        st4(c + lr * D + 4 * lg, make_float4(gs[0], gs[1], gs[2], gs[3]));
+        if (lg == 0) {
+            if (has_b) c[S * D + lr] = gb;
+            reinterpret_cast<uint32_t*>(c + S * D + S)[lr] = 1u | (has_b ? 2u : 0u);
+        }
+    }
+}
+
+// owner: contributions of the devices added in device order (first toucher initialises)
+template <int D>
+__global__ __launch_bounds__(256) void owner_reduce_kernel(const void* recv, int ndev, uint64_t S, void* own) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    float* out = reinterpret_cast<float*>(own);
+    uint32_t* ofl = reinterpret_cast<uint32_t*>(out + S * D + S);
+    for (uint64_t i = wave * GPW + grp; i < S; i += nwaves * GPW) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gb = 0.0f;
+        uint32_t fl = 0;
+        for (int q = 0; q < ndev; ++q) {
+            const float* c = chunk_ptr(recv, q, S, D);
+            const uint32_t f = reinterpret_cast<const uint32_t*>(c + S * D + S)[i];
+            if (f & 1u) {
+                const float4 v = ld4(c + i * D + 4 * lg);
+                if (fl & 1u) { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
+                else g = v;
+            }
+            if (f & 2u) gb = (fl & 2u) ? gb + c[S * D + i] : c[S * D + i];
+            fl |= f;
+        }
+        if (fl & 1u) st4(out + i * D + 4 * lg, g);
+        if (lg == 0) {
+            if (fl & 2u) out[S * D + i] = gb;
+            ofl[i] = fl;
+        }
+    }
+}
+
+// every device: Adagrad on every touched row from the gathered global sums
+template <int D>
+__global__ __launch_bounds__(256) void table_apply_kernel(ModelView m, const void* table, uint64_t S) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t row = wave * GPW + grp; row < m.num_items; row += nwaves * GPW) {
+        const float* c = chunk_ptr(table, row / S, S, D);
+        const uint64_t lr = row % S;
+        const uint32_t fl = reinterpret_cast<const uint32_t*>(c + S * D + S)[lr];
+        if (fl & 1u) {
+            const float4 g = ld4(c + lr * D + 4 * lg);
+            float* wrow = m.E + row * D + 4 * lg;
+            float* arow = m.Eacc + row * D + 4 * lg;
+            float4 wv = ld4(wrow), av = ld4(arow);
+            sbr_adagrad(&wv.x, &av.x, g.x, m.lr, m.l2);
+            sbr_adagrad(&wv.y, &av.y, g.y, m.lr, m.l2);
+            sbr_adagrad(&wv.z, &av.z, g.z, m.lr, m.l2);
+            sbr_adagrad(&wv.w, &av.w, g.w, m.lr, m.l2);
+            st4(wrow, wv);
+            st4(arow, av);
+        }
+        if ((fl & 2u) && lg == 0) {
+            float bv = m.b[row], ba = m.bacc[row];
+            sbr_adagrad(&bv, &ba, c[S * D + lr], m.lr, m.l2);
+            m.b[row] = bv;
+            m.bacc[row] = ba;
+        }
+    }
+}
+
+__global__ void build_own_keys_kernel(BlockView blk, uint32_t R, uint64_t* keys) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        uint64_t* k = keys + 3ull * r;
+        k[0] = ((uint64_t)blk.in_idx[r] << 32) | (3ull * r);
+        k[1] = ((uint64_t)blk.out_idx[r] << 32) | (3ull * r + 1);
+        k[2] = ((uint64_t)blk.neg[r] << 32) | (3ull * r + 2);
+    }
+}
+
 __global__ void accumulate_loss_kernel(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                                        unsigned long long* ex_acc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1164,6 +1301,35 @@ void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t
 void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                             unsigned long long* ex_acc, hipStream_t s) {
     hipLaunchKernelGGL(accumulate_loss_kernel, dim3(1), dim3(64), 0, s, all_blocks, block_bytes, ndev, loss_acc, ex_acc);
+}
+
+void launch_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                    void* send, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp, size_t sort_temp_bytes, int key_bits,
+                    hipStream_t s) {
+    const uint64_t nflags = (uint64_t)ndev * slice_rows;
+    hipLaunchKernelGGL(clear_chunk_flags_kernel, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, s, send, ndev, slice_rows, m.d);
+    if (rows_host == 0) return;
+    const uint64_t total = 3ull * rows_host;
+    hipLaunchKernelGGL(build_own_keys_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, blk, rows_host, keys);
+    (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((sparse_scatter_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, send, slice_rows);
+    });
+}
+
+void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s) {
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((owner_reduce_kernel<DD>), dim3(grid_for_groups((long long)slice_rows, gpb)), dim3(256), 0, s, recv, ndev, slice_rows, own);
+    });
+}
+
+void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s) {
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((table_apply_kernel<DD>), dim3(grid_for_groups((long long)m.num_items, gpb)), dim3(256), 0, s, m, table, slice_rows);
+    });
 }
 
 void launch_predict(const ModelView& m, const float* user, const uint32_t* items, uint64_t n, float* out, hipStream_t s) {

@@ -5,73 +5,97 @@ What the reference does (sequence_model.rs:90-102, 163-169; mod.rs:35-41): the s
 subsequences are cut into ``num_threads`` partitions, every thread works on its own partition
 against parameters shared through memory, and in ``Parallelism::Synchronous`` the threads
 rendezvous at every optimiser step.  Here a partition lives on a device, the "shared memory" is a
-full parameter replica per GPU, and the rendezvous is one all-gather per step of the devices'
-*exchange blocks* (packed rows' indices, loss coefficients, hidden states, input gradients and
-the dense gradient block — layout in DESIGN.md §5).  Every device then applies the identical,
-deterministically ordered update (dense: device-order sum; sparse: sorted by (row, device, packed
-row)), so replicas stay bit-identical without any parameter broadcast, and the result equals the
-single-process oracle run with ``num_devices = world`` bit for bit.
+full parameter replica per GPU, and the rendezvous is the **owner-reduce** exchange:
+
+    compute_local   forward / negative sampling / backward on the device's own minibatch
+    scatter         the device's own sparse entries reduced per table row into ``world`` dense
+                    chunks, one per owner of a contiguous slice of ceil(I / world) rows
+    all_to_all      chunk p of every device -> device p                      (RCCL, xGMI mesh)
+    owner_reduce    the owner adds the devices' contributions in device order
+    all_gather      of the owners' chunks (global gradient sums of the whole table) and of the
+                    small dense blocks (LSTM / alpha gradients + loss header)  (RCCL)
+    apply_table     every device applies the identical Adagrad update
+
+Per device and step the exchange moves 2 x (world-1)/world x table bytes, independent of the
+batch, and every pairwise link of the xGMI mesh carries table/world bytes per phase — instead of
+(world-1) x (2·4d + 16) bytes per interaction for an all-gather of the raw entries.  Every
+reduction has a fixed order, so replicas stay bit-identical without any parameter broadcast, and
+the result equals the single-process oracle run with ``num_devices = world`` bit for bit.
 
 The driver below is backend-agnostic on purpose: ``tests/test_distributed_cpu.py`` runs it with
-world_size 2 on the gloo backend with CPU tensors (the oracle computing the local halves), which
-covers the sharding and exchange logic without a GPU.
+world_size 2 on the gloo backend with CPU tensors (the oracle computing the device halves), which
+covers the sharding and exchange logic without a GPU; ``tests/test_parity_gpu.py`` drives the HIP
+halves for several simulated ranks on one GPU.
 """
 from __future__ import annotations
 
 from typing import Protocol
 
-import numpy as np
-
 
 class StepBackend(Protocol):
-    """One device's half-steps around the exchange."""
+    """One device's half-steps around the exchange; tensors are 1-D uint8 on the exchange device."""
 
-    def epoch_prepare(self) -> int: ...
-    def local_block(self, minibatch: int): ...          # -> 1-D uint8 tensor on the exchange device
-    def gathered_buffer(self, world: int): ...          # -> 1-D uint8 tensor [world * block_bytes]
-    def apply(self, minibatch: int, gathered) -> None: ...
-    def end(self): ...                                  # -> (loss, examples)
+    def epoch_prepare(self, prefetch_next: bool = False) -> int: ...
+    def compute_local(self, minibatch: int) -> None: ...
+    def apply_single(self, minibatch: int) -> None: ...            # world == 1
+    def scatter(self, minibatch: int): ...                         # -> (send [world*chunk], dense [dense_bytes])
+    def owner_reduce(self, recv): ...                              # -> own chunk [chunk]
+    def apply_table(self, table, dense_all) -> None: ...
+    def buffers(self, world: int): ...                             # -> (recv, table, dense_all)
+    def end(self): ...                                             # -> (loss, examples)
+
+
+def exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=None) -> None:
+    """One optimiser step after compute_local: the owner-reduce exchange."""
+    import torch.distributed as dist
+
+    recv, table, dense_all = bufs
+    send, dense = backend.scatter(minibatch)
+    dist.all_to_all_single(recv, send, group=group)
+    own = backend.owner_reduce(recv)
+    dist.all_gather_into_tensor(table, own, group=group)
+    dist.all_gather_into_tensor(dense_all, dense, group=group)
+    backend.apply_table(table, dense_all)
 
 
 def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None):
     """The epoch/minibatch loop of fit_sequence_model (sequence_model.rs:108-171) with the
-    per-step rendezvous expressed as an all-gather."""
-    import torch.distributed as dist
-
-    gathered = backend.gathered_buffer(world)
+    per-step rendezvous expressed as collectives."""
+    bufs = backend.buffers(world) if world > 1 else None
     for e in range(num_epochs):
-        try:
-            nmb = backend.epoch_prepare(prefetch_next=e + 1 < num_epochs)
-        except TypeError:  # backends without host-side prefetch
-            nmb = backend.epoch_prepare()
+        nmb = backend.epoch_prepare(prefetch_next=e + 1 < num_epochs)
         for mb in range(nmb):
-            local = backend.local_block(mb)
+            backend.compute_local(mb)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, local, group=group)
-                backend.apply(mb, gathered)
+                exchange_step(backend, mb, world, bufs, group)
             else:
-                backend.apply(mb, local)
+                backend.apply_single(mb)
     return backend.end()
 
 
 class HipBackend:
-    """The gfx950 engine as a StepBackend: exchange blocks are torch CUDA tensors whose device
-    pointers go straight into sbr_fit_step_local / sbr_fit_step_apply; the engine is put on
-    torch's current stream so no extra synchronisation is needed around the collective."""
+    """The gfx950 engine as a StepBackend: exchange buffers are torch CUDA tensors whose device
+    pointers go straight into the C-ABI; the engine is put on torch's current stream so no extra
+    synchronisation is needed around the collectives."""
 
-    def __init__(self, model, interactions_or_csr):
+    def __init__(self, model, interactions_or_csr, world: int = 1):
         import torch
 
         self.torch = torch
         self.model = model
+        self.world = world
         if hasattr(interactions_or_csr, "user_pointers"):
             up, it = interactions_or_csr.user_pointers, interactions_or_csr.item_ids
         else:
             up, it = interactions_or_csr
         model.set_stream(torch.cuda.current_stream().cuda_stream)
         self.plan = model.fit_begin(up, it)
-        self.block_bytes = self.plan.exchange_bytes()
-        self.local = torch.zeros(self.block_bytes, dtype=torch.uint8, device="cuda")
+        if world > 1:
+            self.chunk = self.plan.chunk_bytes()
+            self.dense_bytes = self.plan.dense_bytes()
+            self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device="cuda")
+            self.dense = torch.zeros(self.dense_bytes, dtype=torch.uint8, device="cuda")
+            self.own = torch.zeros(self.chunk, dtype=torch.uint8, device="cuda")
 
     def epoch_prepare(self, prefetch_next: bool = False) -> int:
         n = self.plan.epoch_prepare()
@@ -79,15 +103,28 @@ class HipBackend:
             self.plan.epoch_prefetch()
         return n
 
-    def local_block(self, minibatch: int):
-        self.plan.step_local(minibatch, self.local.data_ptr())
-        return self.local
+    def compute_local(self, minibatch: int) -> None:
+        self.plan.step_local(minibatch)
 
-    def gathered_buffer(self, world: int):
-        return self.torch.zeros(world * self.block_bytes, dtype=self.torch.uint8, device="cuda")
+    def apply_single(self, minibatch: int) -> None:
+        self.plan.step_apply(minibatch)
 
-    def apply(self, minibatch: int, gathered) -> None:
-        self.plan.step_apply(minibatch, gathered.data_ptr())
+    def scatter(self, minibatch: int):
+        self.plan.step_scatter(minibatch, self.send.data_ptr(), self.dense.data_ptr())
+        return self.send, self.dense
+
+    def owner_reduce(self, recv):
+        self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr())
+        return self.own
+
+    def apply_table(self, table, dense_all) -> None:
+        self.plan.step_apply_table(table.data_ptr(), dense_all.data_ptr())
+
+    def buffers(self, world: int):
+        t = self.torch
+        return (t.zeros(world * self.chunk, dtype=t.uint8, device="cuda"),
+                t.zeros(world * self.chunk, dtype=t.uint8, device="cuda"),
+                t.zeros(world * self.dense_bytes, dtype=t.uint8, device="cuda"))
 
     def end(self):
         return self.plan.end()
@@ -106,7 +143,7 @@ def fit_distributed(model, interactions, group=None) -> float:
         raise RuntimeError(f"fit with num_threads={world} needs torch.distributed initialised with world size {world}")
     if dist.get_rank(group) != int(model.hp.device_rank):
         raise RuntimeError("process rank does not match hp.device_rank")
-    backend = HipBackend(model, interactions)
+    backend = HipBackend(model, interactions, world)
     try:
         loss, _examples = run_fit(backend, int(model.hp.num_epochs), world, group)
     finally:

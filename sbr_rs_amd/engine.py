@@ -67,16 +67,31 @@ class FitPlan:
     def step(self, mb: int):
         _check(self._L.sbr_fit_step(self._h, mb))
 
-    def exchange_bytes(self) -> int:
+    def step_local(self, mb: int):
+        _check(self._L.sbr_fit_step_local(self._h, mb))
+
+    def step_apply(self, mb: int):
+        _check(self._L.sbr_fit_step_apply(self._h, mb))
+
+    # ---- multi-device owner-reduce protocol (device pointers supplied by the caller) ----
+    def chunk_bytes(self) -> int:
         n = C.c_uint64()
-        _check(self._L.sbr_fit_exchange_bytes(self._h, C.byref(n)))
+        _check(self._L.sbr_fit_chunk_bytes(self._h, C.byref(n)))
         return n.value
 
-    def step_local(self, mb: int, device_ptr: int = 0):
-        _check(self._L.sbr_fit_step_local(self._h, mb, C.c_void_p(device_ptr) if device_ptr else None))
+    def dense_bytes(self) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_fit_dense_bytes(self._h, C.byref(n)))
+        return n.value
 
-    def step_apply(self, mb: int, device_ptr_all: int = 0):
-        _check(self._L.sbr_fit_step_apply(self._h, mb, C.c_void_p(device_ptr_all) if device_ptr_all else None))
+    def step_scatter(self, mb: int, send_ptr: int, dense_ptr: int):
+        _check(self._L.sbr_fit_step_scatter(self._h, mb, C.c_void_p(send_ptr), C.c_void_p(dense_ptr)))
+
+    def step_owner_reduce(self, recv_ptr: int, own_ptr: int):
+        _check(self._L.sbr_fit_step_owner_reduce(self._h, C.c_void_p(recv_ptr), C.c_void_p(own_ptr)))
+
+    def step_apply_table(self, table_ptr: int, dense_all_ptr: int):
+        _check(self._L.sbr_fit_step_apply_table(self._h, C.c_void_p(table_ptr), C.c_void_p(dense_all_ptr)))
 
     def end(self):
         loss, ex = C.c_float(), C.c_uint64()

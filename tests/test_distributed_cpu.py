@@ -1,6 +1,6 @@
 """World-size-2 test of the multi-device path on CPU (gloo): the distributed driver
-(sbr_rs_amd/distributed.run_fit) is run by two processes, the oracle computing each device's
-local half-step; the replicas must end bit-identical to each other and to the single-process
+(sbr_rs_amd/distributed.run_fit: all-to-all + all-gather owner-reduce exchange) is run by two
+processes, the oracle computing each device's halves; the replicas must end bit-identical to each other and to the single-process
 oracle emulating both devices (≙ Parallelism::Synchronous with num_threads = 2,
 /root/reference/src/models/sequence_model.rs:91-98, 163-166; reference test lstm.rs:474-496)."""
 import os
@@ -19,22 +19,35 @@ from sbr_rs_amd.distributed import run_fit
 
 
 class OracleBackend:
-    def __init__(self, model: OracleModel, rank: int, ptr, items):
-        self.rank = rank
-        self.plan = model.fit_begin(ptr, items)
-        self.block_bytes = self.plan.exchange_bytes()
+    """The oracle's device halves behind the same StepBackend interface the HIP engine uses."""
 
-    def epoch_prepare(self):
+    def __init__(self, model: OracleModel, rank: int, world: int, ptr, items):
+        self.rank, self.world = rank, world
+        self.plan = model.fit_begin(ptr, items)
+
+    def epoch_prepare(self, prefetch_next=False):
         return self.plan.epoch_prepare()
 
-    def local_block(self, mb):
-        return torch.from_numpy(self.plan.step_local(mb, device=self.rank))
+    def compute_local(self, mb):
+        self.plan.compute_local(mb, self.rank)
 
-    def gathered_buffer(self, world):
-        return torch.zeros(world * self.block_bytes, dtype=torch.uint8)
+    def apply_single(self, mb):
+        self.plan.step_apply(self.plan.step_local(mb, device=0))
 
-    def apply(self, mb, gathered):
-        self.plan.step_apply(gathered.numpy())
+    def scatter(self, mb):
+        return (torch.from_numpy(self.plan.scatter(self.rank, self.world)),
+                torch.from_numpy(self.plan.export_dense(self.rank)))
+
+    def owner_reduce(self, recv):
+        return torch.from_numpy(self.plan.owner_reduce(recv.numpy()))
+
+    def apply_table(self, table, dense_all):
+        self.plan.apply_table(table.numpy(), dense_all.numpy())
+
+    def buffers(self, world):
+        c, d = self.plan.chunk_bytes(), self.plan.dense_bytes()
+        return (torch.zeros(world * c, dtype=torch.uint8), torch.zeros(world * c, dtype=torch.uint8),
+                torch.zeros(world * d, dtype=torch.uint8))
 
     def end(self):
         return self.plan.end()
@@ -52,7 +65,7 @@ def _worker(rank, world, port, kind, loss, out_dir):
         ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
         hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank)
         m = OracleModel(hp)
-        loss_v, ex = run_fit(OracleBackend(m, rank, ptr, items), 2, world)
+        loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v, ex=ex,
                  **{p.name: m.get_param(p) for p in PARAMS[kind]})
     finally:

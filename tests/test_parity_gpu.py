@@ -165,6 +165,60 @@ def test_whole_fit_bit_exact(kind, loss, d, items, users, T, B):
     assert_same_bits(g.predict(ug, all_items), o.predict(uo, all_items), "predict")
 
 
+@pytest.mark.parametrize("kind,loss,d,world", [
+    (ModelKind.EWMA, LOSS_WARP, 32, 2),
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 64, 3),
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 4),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 2),
+])
+def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
+    """The multi-GPU protocol (scatter / owner_reduce / apply_table through the C-ABI) with `world`
+    simulated ranks on ONE GPU: the collectives are replaced by explicit tensor copies, everything
+    else is the production path.  All replicas must end bit-identical to each other and to the
+    single-process oracle with num_devices = world."""
+    import torch
+
+    items, T, B = 203, 12, 6   # 203 % world != 0 for every world here: ragged last slice
+    ptr, it = synthetic_interactions(90, items, T + 4, seed=17, zipf=True)
+    models, plans = [], []
+    for q in range(world):
+        m = Model(hparams(items, T, d, int(kind), loss, epochs=2, B=B, ndev=world, rank=q))
+        models.append(m)
+        plans.append(m.fit_begin(ptr, it))
+    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
+    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
+    recv = torch.zeros(world * chunk, **u8)
+    own = [torch.zeros(chunk, **u8) for _ in range(world)]
+    for _ in range(2):
+        nmb = {p.epoch_prepare() for p in plans}
+        assert len(nmb) == 1
+        for mb in range(nmb.pop()):
+            for q in range(world):
+                plans[q].step_local(mb)
+                plans[q].step_scatter(mb, send[q].data_ptr(), dense[q].data_ptr())
+                models[q].synchronize()
+            for q in range(world):  # all_to_all_single
+                for src in range(world):
+                    recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
+                torch.cuda.synchronize()
+                plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
+                models[q].synchronize()
+            table = torch.cat(own)          # all_gather_into_tensor
+            dense_all = torch.cat(dense)
+            torch.cuda.synchronize()
+            for q in range(world):
+                plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
+                models[q].synchronize()
+    o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=2, B=B, ndev=world, rank=0))
+    lo = o.fit(ptr, it)
+    for q in range(world):
+        assert_params_equal(models[q], o, kind, f"rank {q} of {world}")
+        lg, ex = plans[q].end()
+        assert lg == pytest.approx(lo, rel=1e-6)
+
+
 def test_batch_of_one_is_per_sequence_sgd():
     ptr, it = synthetic_interactions(20, 80, 12, seed=4)
     hp = hparams(80, 10, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, B=1, epochs=1)

@@ -79,7 +79,13 @@ typedef enum sbr_param {
     SBR_PARAM_LSTM_B = 6,             /* [gates*dim]                              */
     SBR_PARAM_LSTM_B_ACC = 7,
     SBR_PARAM_EWMA_ALPHA = 8,         /* [dim]                                    */
-    SBR_PARAM_EWMA_ALPHA_ACC = 9
+    SBR_PARAM_EWMA_ALPHA_ACC = 9,
+    /* Adam first moments (the "*_ACC" blocks hold the second moments under Adam); empty under Adagrad */
+    SBR_PARAM_ITEM_EMBEDDING_M = 10,
+    SBR_PARAM_ITEM_BIAS_M = 11,
+    SBR_PARAM_LSTM_W_M = 12,
+    SBR_PARAM_LSTM_B_M = 13,
+    SBR_PARAM_EWMA_ALPHA_M = 14
 } sbr_param;
 
 /* Per-minibatch intermediates that tests fetch to compare against the oracle. */
@@ -175,6 +181,10 @@ sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* ou
 sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uint64_t count);
 sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count);
 sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch);
+/* Optimiser steps taken so far (Adam's bias-correction counter) and the epoch counter that keys the
+ * negative draws: together with the parameter blocks this is the complete resumable state. */
+sbr_status sbr_model_get_counters(const sbr_model* m, uint64_t* out_global_epoch, uint64_t* out_optimizer_steps);
+sbr_status sbr_model_set_counters(sbr_model* m, uint64_t global_epoch, uint64_t optimizer_steps);
 
 /* Library / device identification ("gfx950", CU count, HBM bytes); device_name may be NULL. */
 sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out_cus, uint64_t* out_hbm_bytes);

@@ -43,6 +43,8 @@ def lib():
         L.orc_model_set_param.argtypes = [vp, C.c_int, vp, C.c_uint64]
         L.orc_model_get_epoch.argtypes = [vp]
         L.orc_model_get_epoch.restype = C.c_uint64
+        L.orc_model_get_opt_steps.argtypes = [vp]
+        L.orc_model_get_opt_steps.restype = C.c_uint64
         L.orc_chunk_lengths.argtypes = [C.c_uint64, C.c_uint64, u64p, C.c_int]
         L.orc_fit_begin.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
         L.orc_fit_plan_destroy.argtypes = [vp]
@@ -80,6 +82,8 @@ def lib():
         L.orc_epoch_key.restype = C.c_uint64
         L.orc_adagrad.argtypes = [fp, fp, C.c_float, C.c_float, C.c_float]
         L.orc_adagrad.restype = None
+        L.orc_adam.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_uint64]
+        L.orc_adam.restype = None
         L.orc_xorshift_stream.argtypes = [vp, vp, C.c_int]
         L.orc_xorshift_stream.restype = None
         L.orc_fma_chain_gemm.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -231,6 +235,9 @@ class OracleModel:
 
     def global_epoch(self) -> int:
         return lib().orc_model_get_epoch(self._h)
+
+    def optimizer_steps(self) -> int:
+        return lib().orc_model_get_opt_steps(self._h)
 
     def fit(self, user_ptr, item_ids) -> float:
         up = np.ascontiguousarray(user_ptr, dtype=np.uint64)

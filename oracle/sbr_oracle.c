@@ -39,6 +39,9 @@ typedef struct orc_model {
     float *E, *Eacc, *b, *bacc;
     float *W, *Wacc, *bW, *bWacc; /* W [2d][ng*d] */
     float *alpha, *alpha_acc;
+    float *Em, *bm, *Wm, *bWm, *alpha_m; /* Adam first moments */
+    float c1, c2;
+    uint64_t opt_steps;
     sbr_xorshift rng;
     uint64_t global_epoch;
 } orc_model;
@@ -100,7 +103,7 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     if (!orc_dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
         hp->num_devices == 0 || hp->batch_sequences == 0)
         return SBR_ERR_INVALID_ARGUMENT;
-    if (hp->optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_UNSUPPORTED;
+    if (hp->optimizer != SBR_OPT_ADAGRAD && hp->optimizer != SBR_OPT_ADAM) return SBR_ERR_INVALID_ARGUMENT;
     orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
     m->hp = *hp;
     int d = m->d = (int)hp->embedding_dim;
@@ -110,6 +113,9 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     m->Eacc = (float*)calloc(I * d, sizeof(float));
     m->b = (float*)calloc(I, sizeof(float));
     m->bacc = (float*)calloc(I, sizeof(float));
+    int adam = hp->optimizer == SBR_OPT_ADAM;
+    m->c1 = m->c2 = 1.0f;
+    if (adam) { m->Em = (float*)calloc(I * d, sizeof(float)); m->bm = (float*)calloc(I, sizeof(float)); }
     sbr_xs_seed(&m->rng, hp->seed);
     int have = 0;
     double spare = 0.0;
@@ -121,12 +127,14 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
         m->Wacc = (float*)calloc(nw, sizeof(float));
         m->bW = (float*)calloc((size_t)m->ng * d, sizeof(float));
         m->bWacc = (float*)calloc((size_t)m->ng * d, sizeof(float));
+        if (adam) { m->Wm = (float*)calloc(nw, sizeof(float)); m->bWm = (float*)calloc((size_t)m->ng * d, sizeof(float)); }
         double std_w = 1.0 / sqrt(2.0 * d);
         have = 0;
         for (size_t i = 0; i < nw; ++i) m->W[i] = (float)(orc_normal(&m->rng, &have, &spare) * std_w);
     } else {
         m->alpha = (float*)calloc(d, sizeof(float));
         m->alpha_acc = (float*)calloc(d, sizeof(float));
+        if (adam) m->alpha_m = (float*)calloc(d, sizeof(float));
     }
     *out = m;
     return SBR_OK;
@@ -137,6 +145,7 @@ void orc_model_destroy(orc_model* m) {
     free(m->E); free(m->Eacc); free(m->b); free(m->bacc);
     free(m->W); free(m->Wacc); free(m->bW); free(m->bWacc);
     free(m->alpha); free(m->alpha_acc);
+    free(m->Em); free(m->bm); free(m->Wm); free(m->bWm); free(m->alpha_m);
     free(m);
 }
 
@@ -153,6 +162,11 @@ static float* orc_param_ptr(orc_model* m, int which, uint64_t* count) {
         case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return m->bWacc;
         case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return m->alpha;
         case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return m->alpha_acc;
+        case SBR_PARAM_ITEM_EMBEDDING_M: *count = m->Em ? I * d : 0; return m->Em;
+        case SBR_PARAM_ITEM_BIAS_M: *count = m->bm ? I : 0; return m->bm;
+        case SBR_PARAM_LSTM_W_M: *count = m->Wm ? 2 * d * ng * d : 0; return m->Wm;
+        case SBR_PARAM_LSTM_B_M: *count = m->bWm ? ng * d : 0; return m->bWm;
+        case SBR_PARAM_EWMA_ALPHA_M: *count = m->alpha_m ? d : 0; return m->alpha_m;
     }
     *count = 0;
     return NULL;
@@ -176,6 +190,37 @@ int orc_model_set_param(orc_model* m, int which, const float* in, uint64_t count
     return SBR_OK;
 }
 uint64_t orc_model_get_epoch(orc_model* m) { return m->global_epoch; }
+uint64_t orc_model_get_opt_steps(orc_model* m) { return m->opt_steps; }
+
+/* optimiser element update (≙ wyrm optim::{Adagrad, Adam} as recalled) */
+static void orc_opt(orc_model* m, float* w, float* acc, float* mom, float g) {
+    if (m->hp.optimizer == SBR_OPT_ADAM) sbr_adam(w, mom, acc, g, m->hp.learning_rate, m->hp.l2_penalty, m->c1, m->c2);
+    else sbr_adagrad(w, acc, g, m->hp.learning_rate, m->hp.l2_penalty);
+}
+static void orc_begin_optimizer_step(orc_model* m) {
+    m->opt_steps += 1;
+    if (m->hp.optimizer == SBR_OPT_ADAM) sbr_adam_corrections(m->opt_steps, &m->c1, &m->c2);
+}
+static void orc_dense_update(orc_model* m, const float* dg) {
+    int d = m->d;
+    float dummy = 0.0f;
+    if (m->ng) {
+        int nz = m->ng * d;
+        for (size_t i = 0; i < (size_t)2 * d * nz; ++i) orc_opt(m, &m->W[i], &m->Wacc[i], m->Wm ? &m->Wm[i] : &dummy, dg[i]);
+        for (int j = 0; j < nz; ++j) orc_opt(m, &m->bW[j], &m->bWacc[j], m->bWm ? &m->bWm[j] : &dummy, dg[(size_t)2 * d * nz + j]);
+    } else {
+        for (int k = 0; k < d; ++k) orc_opt(m, &m->alpha[k], &m->alpha_acc[k], m->alpha_m ? &m->alpha_m[k] : &dummy, dg[k]);
+    }
+}
+static void orc_row_update(orc_model* m, uint64_t row, const float* g, int has_g, int has_b, float gb) {
+    int d = m->d;
+    float dummy = 0.0f;
+    if (has_g) {
+        float* wrow = m->E + (size_t)row * d; float* arow = m->Eacc + (size_t)row * d;
+        for (int k = 0; k < d; ++k) orc_opt(m, &wrow[k], &arow[k], m->Em ? &m->Em[(size_t)row * d + k] : &dummy, g[k]);
+    }
+    if (has_b) orc_opt(m, &m->b[row], &m->bacc[row], m->bm ? &m->bm[row] : &dummy, gb);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* ≙ CompressedInteractionsUserChunkIterator::next (data.rs:406-431): the FIRST chunk is the
@@ -639,7 +684,7 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
     if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: owner-reduce protocol below */
     int d = m->d, ndev = p->ndev;
     uint64_t Rmax = (uint64_t)p->Rmax, bytes = orc_fit_exchange_bytes(p), nd = orc_ndense(m);
-    float lr = m->hp.learning_rate, l2 = m->hp.l2_penalty;
+    orc_begin_optimizer_step(m);
     /* dense */
     float* dg = (float*)malloc(nd * 4);
     uint64_t total_entries = 0;
@@ -652,13 +697,7 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
         memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
         p->loss_sum += ls; p->examples += ex;
     }
-    if (m->ng) {
-        int nz = m->ng * d;
-        for (size_t i = 0; i < (size_t)2 * d * nz; ++i) sbr_adagrad(&m->W[i], &m->Wacc[i], dg[i], lr, l2);
-        for (int j = 0; j < nz; ++j) sbr_adagrad(&m->bW[j], &m->bWacc[j], dg[(size_t)2 * d * nz + j], lr, l2);
-    } else {
-        for (int k = 0; k < d; ++k) sbr_adagrad(&m->alpha[k], &m->alpha_acc[k], dg[k], lr, l2);
-    }
+    orc_dense_update(m, dg);
     free(dg);
     /* sparse */
     orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (total_entries ? total_entries : 1));
@@ -694,9 +733,7 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
             else for (int k = 0; k < d; ++k) gsum[k] = gsum[k] + scale * srcv[k];
             if (kind != 0) { gb = has_b ? gb + scale : scale; has_b = 1; }
         }
-        float* wrow = m->E + (size_t)row * d; float* arow = m->Eacc + (size_t)row * d;
-        for (int k = 0; k < d; ++k) sbr_adagrad(&wrow[k], &arow[k], gsum[k], lr, l2);
-        if (has_b) sbr_adagrad(&m->b[row], &m->bacc[row], gb, lr, l2);
+        orc_row_update(m, row, gsum, 1, has_b, gb);
         i = j;
     }
     free(gsum); free(ent);
@@ -802,7 +839,7 @@ int orc_fit_apply_table(orc_plan* p, const void* all_chunks, const void* dense_a
     orc_model* m = p->m;
     int d = m->d, ndev = p->ndev;
     uint64_t S = orc_slice_rows(p), cw = S * ((uint64_t)d + 2), nd = orc_ndense(m), I = m->hp.num_items;
-    float lr = m->hp.learning_rate, l2 = m->hp.l2_penalty;
+    orc_begin_optimizer_step(m);
     float* dg = (float*)malloc(nd * 4);
     for (int q = 0; q < ndev; ++q) {
         const uint32_t* w = (const uint32_t*)dense_all + (size_t)q * (8 + nd);
@@ -812,24 +849,13 @@ int orc_fit_apply_table(orc_plan* p, const void* all_chunks, const void* dense_a
         memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
         p->loss_sum += ls; p->examples += ex;
     }
-    if (m->ng) {
-        int nz = m->ng * d;
-        for (size_t i = 0; i < (size_t)2 * d * nz; ++i) sbr_adagrad(&m->W[i], &m->Wacc[i], dg[i], lr, l2);
-        for (int j = 0; j < nz; ++j) sbr_adagrad(&m->bW[j], &m->bWacc[j], dg[(size_t)2 * d * nz + j], lr, l2);
-    } else {
-        for (int k = 0; k < d; ++k) sbr_adagrad(&m->alpha[k], &m->alpha_acc[k], dg[k], lr, l2);
-    }
+    orc_dense_update(m, dg);
     free(dg);
     for (uint64_t row = 0; row < I; ++row) {
         const float* c = (const float*)all_chunks + (row / S) * cw;
         uint64_t lr_ = row % S;
         uint32_t fl = ((const uint32_t*)(c + S * d + S))[lr_];
-        if (fl & 1u) {
-            const float* g = c + lr_ * d;
-            float* wrow = m->E + (size_t)row * d; float* arow = m->Eacc + (size_t)row * d;
-            for (int k = 0; k < d; ++k) sbr_adagrad(&wrow[k], &arow[k], g[k], lr, l2);
-        }
-        if (fl & 2u) sbr_adagrad(&m->b[row], &m->bacc[row], c[S * d + lr_], lr, l2);
+        orc_row_update(m, row, c + lr_ * d, (fl & 1u) != 0, (fl & 2u) != 0, c[S * d + lr_]);
     }
     return SBR_OK;
 }
@@ -1029,4 +1055,9 @@ void orc_fma_chain_gemm(const float* a, const float* b, const float* c0, int M, 
             for (int k = 0; k < K; ++k) acc = sbr_fma(a[i * K + k], b[k * N + j], acc);
             out[i * N + j] = acc;
         }
+}
+void orc_adam(float* w, float* m1, float* v2, float g, float lr, float l2, uint64_t t) {
+    float c1, c2;
+    sbr_adam_corrections(t, &c1, &c2);
+    sbr_adam(w, m1, v2, g, lr, l2, c1, c2);
 }

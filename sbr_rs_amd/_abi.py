@@ -33,6 +33,11 @@ class Param(enum.IntEnum):
     LSTM_B_ACC = 7
     EWMA_ALPHA = 8
     EWMA_ALPHA_ACC = 9
+    ITEM_EMBEDDING_M = 10
+    ITEM_BIAS_M = 11
+    LSTM_W_M = 12
+    LSTM_B_M = 13
+    EWMA_ALPHA_M = 14
 
 
 class Debug(enum.IntEnum):

@@ -53,6 +53,8 @@ def load():
         "sbr_model_get_param": [vp, C.c_int32, vp, C.c_uint64],
         "sbr_model_set_param": [vp, C.c_int32, vp, C.c_uint64],
         "sbr_model_get_epoch": [vp, u64p],
+        "sbr_model_get_counters": [vp, u64p, u64p],
+        "sbr_model_set_counters": [vp, C.c_uint64, C.c_uint64],
         "sbr_device_info": [C.c_char_p, C.c_uint64, u32p, u64p],
         "sbr_model_timing_enable": [vp, C.c_int32],
         "sbr_model_timing_read": [vp, C.POINTER(C.c_double), u64p],
@@ -86,7 +88,7 @@ DECLARED_SYMBOLS = [
     "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_counters", "sbr_fit_plan_destroy", "sbr_fit_chunk_bytes", "sbr_fit_dense_bytes",
     "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_fit_step_scatter", "sbr_fit_step_owner_reduce", "sbr_fit_step_apply_table", "sbr_model_set_stream", "sbr_model_synchronize",
     "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
-    "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_device_info", "sbr_status_string",
+    "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_model_get_counters", "sbr_model_set_counters", "sbr_device_info", "sbr_status_string",
     "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_timing_read", "sbr_set_device", "sbr_selftest_math",
     "sbr_selftest_dot_tree", "sbr_selftest_mfma",
 ]

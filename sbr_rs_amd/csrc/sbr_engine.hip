@@ -80,6 +80,7 @@ struct sbr_model {
     sbr::ModelView mv;
     sbr_xorshift rng;
     uint64_t global_epoch = 0;
+    uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::mutex mu;
@@ -304,6 +305,12 @@ void shuffle_pairs(uint64_t* start, uint32_t* len, uint64_t n, sbr_xorshift* r) 
     }
 }
 
+/* one optimiser step begins: advance the step count and refresh Adam's bias corrections */
+void begin_optimizer_step(sbr_model* m) {
+    m->opt_steps += 1;
+    if (m->hp.optimizer == SBR_OPT_ADAM) sbr_adam_corrections(m->opt_steps, &m->mv.c1, &m->mv.c2);
+}
+
 sbr_status ensure_device(const sbr_model* m) {
     HIPCHK(hipSetDevice(m->device));
     return SBR_OK;
@@ -351,7 +358,7 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
         hp->num_devices > 16 || hp->device_rank >= hp->num_devices || hp->batch_sequences == 0 ||
         hp->model < 0 || hp->model > 2 || hp->loss < 0 || hp->loss > 2)
         return SBR_ERR_INVALID_ARGUMENT;
-    if (hp->optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_UNSUPPORTED; /* Adam: SURVEY §8f-2, not built yet */
+    if (hp->optimizer != SBR_OPT_ADAGRAD && hp->optimizer != SBR_OPT_ADAM) return SBR_ERR_INVALID_ARGUMENT;
     int ndevices = 0;
     if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
     sbr_model* m = new (std::nothrow) sbr_model();
@@ -366,6 +373,8 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     std::memset(&v, 0, sizeof(v));
     v.d = m->d; v.ng = m->ng; v.coupled = m->ng == 3;
     v.num_items = hp->num_items; v.loss = hp->loss; v.lr = hp->learning_rate; v.l2 = hp->l2_penalty;
+    v.optimizer = hp->optimizer; v.c1 = 1.0f; v.c2 = 1.0f;
+    const bool adam = hp->optimizer == SBR_OPT_ADAM;
     const uint64_t I = hp->num_items, d = (uint64_t)m->d;
     sbr_status st = SBR_OK;
     auto fail = [&](sbr_status s) { sbr_model_destroy(m); return s; };
@@ -373,6 +382,12 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     if ((st = dmalloc(&v.Eacc, I * d)) != SBR_OK) return fail(st);
     if ((st = dmalloc(&v.b, I)) != SBR_OK) return fail(st);
     if ((st = dmalloc(&v.bacc, I)) != SBR_OK) return fail(st);
+    if (adam) {
+        if ((st = dmalloc(&v.Em, I * d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.bm, I)) != SBR_OK) return fail(st);
+        hipMemsetAsync(v.Em, 0, I * d * 4, m->stream);
+        hipMemsetAsync(v.bm, 0, I * 4, m->stream);
+    }
     hipMemsetAsync(v.Eacc, 0, I * d * 4, m->stream);
     hipMemsetAsync(v.b, 0, I * 4, m->stream);
     hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
@@ -393,6 +408,12 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
         if ((st = dmalloc(&v.WTp, nw)) != SBR_OK) return fail(st);
         if ((st = dmalloc(&v.bW, nb)) != SBR_OK) return fail(st);
         if ((st = dmalloc(&v.bWacc, nb)) != SBR_OK) return fail(st);
+        if (adam) {
+            if ((st = dmalloc(&v.Wm, nw)) != SBR_OK) return fail(st);
+            if ((st = dmalloc(&v.bWm, nb)) != SBR_OK) return fail(st);
+            hipMemsetAsync(v.Wm, 0, nw * 4, m->stream);
+            hipMemsetAsync(v.bWm, 0, nb * 4, m->stream);
+        }
         hipMemsetAsync(v.Wacc, 0, nw * 4, m->stream);
         hipMemsetAsync(v.bW, 0, nb * 4, m->stream);
         hipMemsetAsync(v.bWacc, 0, nb * 4, m->stream);
@@ -405,6 +426,10 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     } else {
         if ((st = dmalloc(&v.alpha, d)) != SBR_OK) return fail(st);
         if ((st = dmalloc(&v.alpha_acc, d)) != SBR_OK) return fail(st);
+        if (adam) {
+            if ((st = dmalloc(&v.alpha_m, d)) != SBR_OK) return fail(st);
+            hipMemsetAsync(v.alpha_m, 0, d * 4, m->stream);
+        }
         hipMemsetAsync(v.alpha, 0, d * 4, m->stream);
         hipMemsetAsync(v.alpha_acc, 0, d * 4, m->stream);
     }
@@ -421,6 +446,7 @@ void sbr_model_destroy(sbr_model* m) {
     hipFree(v.E); hipFree(v.Eacc); hipFree(v.b); hipFree(v.bacc);
     hipFree(v.W); hipFree(v.Wacc); hipFree(v.bW); hipFree(v.bWacc); hipFree(v.Wp); hipFree(v.WTp);
     hipFree(v.alpha); hipFree(v.alpha_acc);
+    hipFree(v.Em); hipFree(v.bm); hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
     delete m;
@@ -457,6 +483,11 @@ static float* param_ptr(sbr_model* m, int32_t which, uint64_t* count) {
         case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return v.bWacc;
         case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return v.alpha;
         case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return v.alpha_acc;
+        case SBR_PARAM_ITEM_EMBEDDING_M: *count = v.Em ? I * d : 0; return v.Em;
+        case SBR_PARAM_ITEM_BIAS_M: *count = v.bm ? I : 0; return v.bm;
+        case SBR_PARAM_LSTM_W_M: *count = v.Wm ? 2 * d * ng * d : 0; return v.Wm;
+        case SBR_PARAM_LSTM_B_M: *count = v.bWm ? ng * d : 0; return v.bWm;
+        case SBR_PARAM_EWMA_ALPHA_M: *count = v.alpha_m ? d : 0; return v.alpha_m;
     }
     *count = 0;
     return nullptr;
@@ -497,6 +528,20 @@ sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in
 sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch) {
     if (!m || !out_global_epoch) return SBR_ERR_INVALID_ARGUMENT;
     *out_global_epoch = m->global_epoch;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_get_counters(const sbr_model* m, uint64_t* out_global_epoch, uint64_t* out_optimizer_steps) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    if (out_global_epoch) *out_global_epoch = m->global_epoch;
+    if (out_optimizer_steps) *out_optimizer_steps = m->opt_steps;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_set_counters(sbr_model* m, uint64_t global_epoch, uint64_t optimizer_steps) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    m->global_epoch = global_epoch;
+    m->opt_steps = optimizer_steps;
     return SBR_OK;
 }
 
@@ -782,6 +827,7 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     const uint8_t* all = p->block;
+    begin_optimizer_step(m);
     sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
@@ -855,6 +901,7 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
     SBRCHK(ensure_device(m));
     const uint64_t db = (8 + dense_count(m)) * 4;
     const uint8_t* dall = reinterpret_cast<const uint8_t*>(device_dense_all);
+    begin_optimizer_step(m);
     sbr::launch_accumulate_loss(dall, db, p->ndev, p->loss_acc, p->ex_acc, m->stream);
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);

@@ -43,6 +43,10 @@ struct ModelView {
     float *E, *Eacc, *b, *bacc;
     float *W, *Wacc, *bW, *bWacc, *Wp, *WTp;
     float *alpha, *alpha_acc;
+    /* Adam */
+    int optimizer;      /* sbr_optimizer */
+    float c1, c2;       /* 1 - beta^t of the current step */
+    float *Em, *bm, *Wm, *bWm, *alpha_m;
 };
 
 struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */

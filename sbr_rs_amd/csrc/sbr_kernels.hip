@@ -41,6 +41,12 @@ __device__ __forceinline__ float group_allreduce(float p) {
     for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
     return p;
 }
+// optimiser element update: Adagrad (acc = sum of squares) or Adam (acc = second moment, mom = first)
+__device__ __forceinline__ void opt_update(const ModelView& m, float* w, float* acc, float* mom, float g) {
+    if (m.optimizer == SBR_OPT_ADAM) sbr_adam(w, mom, acc, g, m.lr, m.l2, m.c1, m.c2);
+    else sbr_adagrad(w, acc, g, m.lr, m.l2);
+}
+
 __device__ __forceinline__ float dot4(float4 x, float4 y) {
     float p = x.x * y.x;
     p = sbr_fma(x.y, y.y, p);
@@ -763,25 +769,31 @@ __global__ void dense_apply_kernel(ModelView m, const uint8_t* all_blocks, uint6
         const int NGD = m.ng * m.d;
         const size_t nw = (size_t)2 * m.d * NGD;
         if (i < nw) {
-            float wv = m.W[i], G = m.Wacc[i];
-            sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+            const bool adam = m.optimizer == SBR_OPT_ADAM;
+            float wv = m.W[i], G = m.Wacc[i], M = adam ? m.Wm[i] : 0.0f;
+            opt_update(m, &wv, &G, &M, g);
             m.W[i] = wv;
             m.Wacc[i] = G;
+            if (adam) m.Wm[i] = M;
             const int k = (int)(i / NGD), jcol = (int)(i % NGD);
             m.Wp[wp_index(k, jcol, m.d, m.ng)] = wv;
             m.WTp[wtp_index(k, jcol, m.d, m.ng)] = wv;
         } else {
             const size_t j = i - nw;
-            float wv = m.bW[j], G = m.bWacc[j];
-            sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+            const bool adam = m.optimizer == SBR_OPT_ADAM;
+            float wv = m.bW[j], G = m.bWacc[j], M = adam ? m.bWm[j] : 0.0f;
+            opt_update(m, &wv, &G, &M, g);
             m.bW[j] = wv;
             m.bWacc[j] = G;
+            if (adam) m.bWm[j] = M;
         }
     } else {
-        float wv = m.alpha[i], G = m.alpha_acc[i];
-        sbr_adagrad(&wv, &G, g, m.lr, m.l2);
+        const bool adam = m.optimizer == SBR_OPT_ADAM;
+        float wv = m.alpha[i], G = m.alpha_acc[i], M = adam ? m.alpha_m[i] : 0.0f;
+        opt_update(m, &wv, &G, &M, g);
         m.alpha[i] = wv;
         m.alpha_acc[i] = G;
+        if (adam) m.alpha_m[i] = M;
     }
 }
 
@@ -794,6 +806,33 @@ __global__ void repack_lstm_kernel(ModelView m) {
     const float wv = m.W[i];
     m.Wp[wp_index(k, jcol, m.d, m.ng)] = wv;
     m.WTp[wtp_index(k, jcol, m.d, m.ng)] = wv;
+}
+
+// one optimiser update of an item-embedding row (4 elements per lane of the row's group) and its bias
+__device__ __forceinline__ void bias_update(const ModelView& m, uint64_t row, int lg, float gb) {
+    if (lg != 0) return;
+    const bool adam = m.optimizer == SBR_OPT_ADAM;
+    float bv = m.b[row], ba = m.bacc[row], bmm = adam ? m.bm[row] : 0.0f;
+    opt_update(m, &bv, &ba, &bmm, gb);
+    m.b[row] = bv;
+    m.bacc[row] = ba;
+    if (adam) m.bm[row] = bmm;
+}
+template <int D>
+__device__ __forceinline__ void row_update(const ModelView& m, uint64_t row, int lg, float4 g, bool has_b, float gb) {
+    const bool adam = m.optimizer == SBR_OPT_ADAM;
+    float* wrow = m.E + row * D + 4 * lg;
+    float* arow = m.Eacc + row * D + 4 * lg;
+    float4 wv = ld4(wrow), av = ld4(arow);
+    float4 mv = adam ? ld4(m.Em + row * D + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    opt_update(m, &wv.x, &av.x, &mv.x, g.x);
+    opt_update(m, &wv.y, &av.y, &mv.y, g.y);
+    opt_update(m, &wv.z, &av.z, &mv.z, g.z);
+    opt_update(m, &wv.w, &av.w, &mv.w, g.w);
+    st4(wrow, wv);
+    st4(arow, av);
+    if (adam) st4(m.Em + row * D + 4 * lg, mv);
+    if (has_b) bias_update(m, row, lg, gb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,21 +901,7 @@ __global__ __launch_bounds__(256) void sparse_apply_kernel(ModelView m, const ui
                 has_b = true;
             }
         }
-        float* wrow = m.E + (size_t)row * D + 4 * lg;
-        float* arow = m.Eacc + (size_t)row * D + 4 * lg;
-        float4 wv = ld4(wrow), av = ld4(arow);
-        sbr_adagrad(&wv.x, &av.x, gs[0], m.lr, m.l2);
-        sbr_adagrad(&wv.y, &av.y, gs[1], m.lr, m.l2);
-        sbr_adagrad(&wv.z, &av.z, gs[2], m.lr, m.l2);
-        sbr_adagrad(&wv.w, &av.w, gs[3], m.lr, m.l2);
-        st4(wrow, wv);
-        st4(arow, av);
-        if (has_b && lg == 0) {
-            float bv = m.b[row], ba = m.bacc[row];
-            sbr_adagrad(&bv, &ba, gb, m.lr, m.l2);
-            m.b[row] = bv;
-            m.bacc[row] = ba;
-        }
+        row_update<D>(m, row, lg, make_float4(gs[0], gs[1], gs[2], gs[3]), has_b, gb);
     }
 }
 
@@ -988,23 +1013,9 @@ __global__ __launch_bounds__(256) void table_apply_kernel(ModelView m, const voi
         const uint64_t lr = row % S;
         const uint32_t fl = reinterpret_cast<const uint32_t*>(c + S * D + S)[lr];
         if (fl & 1u) {
-            const float4 g = ld4(c + lr * D + 4 * lg);
-            float* wrow = m.E + row * D + 4 * lg;
-            float* arow = m.Eacc + row * D + 4 * lg;
-            float4 wv = ld4(wrow), av = ld4(arow);
-            sbr_adagrad(&wv.x, &av.x, g.x, m.lr, m.l2);
-            sbr_adagrad(&wv.y, &av.y, g.y, m.lr, m.l2);
-            sbr_adagrad(&wv.z, &av.z, g.z, m.lr, m.l2);
-            sbr_adagrad(&wv.w, &av.w, g.w, m.lr, m.l2);
-            st4(wrow, wv);
-            st4(arow, av);
+            row_update<D>(m, row, lg, ld4(c + lr * D + 4 * lg), false, 0.0f);
         }
-        if ((fl & 2u) && lg == 0) {
-            float bv = m.b[row], ba = m.bacc[row];
-            sbr_adagrad(&bv, &ba, c[S * D + lr], m.lr, m.l2);
-            m.b[row] = bv;
-            m.bacc[row] = ba;
-        }
+        if (fl & 2u) bias_update(m, row, lg, c[S * D + lr]);
     }
 }
 

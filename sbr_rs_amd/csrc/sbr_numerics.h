@@ -172,6 +172,32 @@ SBR_HD void sbr_adagrad(float* w, float* G, float g, float lr, float l2) {
     *w = sbr_fma(-step, g2, *w);
 }
 
+/* ---- Adam element update (wyrm::optim::Adam as recalled: beta1 0.9, beta2 0.999, eps 1e-8, L2 folded
+ * into the gradient, bias correction by the optimiser step count).  c1 = 1 - beta1^t and
+ * c2 = 1 - beta2^t are computed on the host (double pow, cast to f32) and passed in.  Sparse
+ * parameters are updated lazily: only the rows a step touches move. */
+#define SBR_ADAM_B1 0.9f
+#define SBR_ADAM_B2 0.999f
+#define SBR_ADAM_EPS 1e-8f
+SBR_HD void sbr_adam(float* w, float* m1, float* v2, float g, float lr, float l2, float c1, float c2) {
+    float g2 = sbr_fma(l2, *w, g);
+    float mm = sbr_fma(SBR_ADAM_B1, *m1, (1.0f - SBR_ADAM_B1) * g2);
+    float vv = sbr_fma(SBR_ADAM_B2, *v2, (1.0f - SBR_ADAM_B2) * (g2 * g2));
+    *m1 = mm;
+    *v2 = vv;
+    float mhat = mm / c1;
+    float vhat = vv / c2;
+    float step = lr / (__builtin_sqrtf(vhat) + SBR_ADAM_EPS);
+    *w = sbr_fma(-step, mhat, *w);
+}
+#include <math.h>
+#if 1 /* host-side helper */
+static inline void sbr_adam_corrections(uint64_t t, float* c1, float* c2) {
+    *c1 = (float)(1.0 - pow((double)SBR_ADAM_B1, (double)t));
+    *c2 = (float)(1.0 - pow((double)SBR_ADAM_B2, (double)t));
+}
+#endif
+
 /* ---- LSTM cell, element level ----------------------------------------------------------------- */
 /* Forward for one hidden unit given the four pre-activations (i, f, g, o blocks of
  * z = [x_t ; h_{t-1}] W + b, each a k-ascending fma chain seeded with the bias). */

@@ -163,6 +163,14 @@ class Model:
         _check(self._L.sbr_model_get_epoch(self._h, C.byref(n)))
         return n.value
 
+    def counters(self):
+        e, t = C.c_uint64(), C.c_uint64()
+        _check(self._L.sbr_model_get_counters(self._h, C.byref(e), C.byref(t)))
+        return e.value, t.value
+
+    def set_counters(self, global_epoch: int, optimizer_steps: int):
+        _check(self._L.sbr_model_set_counters(self._h, global_epoch, optimizer_steps))
+
     def set_stream(self, hip_stream_ptr: int):
         _check(self._L.sbr_model_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 

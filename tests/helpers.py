@@ -50,5 +50,6 @@ def synthetic_interactions(num_users, num_items, max_len, seed=7, min_len=3, zip
     return ptr, items
 
 
-def hparams(num_items, T, dim, model, loss, lr=0.16, l2=0.0004, epochs=1, B=8, seed=bytes([42] * 16), ndev=1, rank=0):
-    return make_hparams(num_items, T, dim, lr, l2, model, loss, OPT_ADAGRAD, PAR_SYNC, seed, epochs, ndev, rank, B)
+def hparams(num_items, T, dim, model, loss, lr=0.16, l2=0.0004, epochs=1, B=8, seed=bytes([42] * 16), ndev=1, rank=0,
+            opt=OPT_ADAGRAD):
+    return make_hparams(num_items, T, dim, lr, l2, model, loss, opt, PAR_SYNC, seed, epochs, ndev, rank, B)

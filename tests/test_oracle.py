@@ -221,3 +221,42 @@ def test_mrr_masks_all_history_and_counts_ties(oracle_lib):
     # user3: test item 0 is in the history => masked => rank = 6
     assert list(ranks) == [2, 4, 6]
     assert mrr == np.float32((np.float32(1) / 2 + np.float32(1) / 4 + np.float32(1) / 6) / np.float32(3))
+
+
+def test_adam_and_adagrad_element_updates_match_float64_formulas(oracle_lib):
+    """wyrm's optimisers as recalled: Adagrad eps 1e-10; Adam beta 0.9/0.999, eps 1e-8,
+    L2 folded into the gradient, bias correction by step count."""
+    rs = np.random.RandomState(3)
+    w64, m64, v64, G64 = 0.3, 0.0, 0.0, 0.0
+    w, m1, v2 = C.c_float(0.3), C.c_float(0.0), C.c_float(0.0)
+    wa, Ga = C.c_float(0.3), C.c_float(0.0)
+    wa64 = 0.3
+    lr, l2 = 0.05, 1e-3
+    for t in range(1, 40):
+        g = float(np.float32(rs.randn()))
+        oracle_lib.orc_adam(C.byref(w), C.byref(m1), C.byref(v2), g, lr, l2, t)
+        g2 = g + l2 * w64
+        m64 = 0.9 * m64 + 0.1 * g2
+        v64 = 0.999 * v64 + 0.001 * g2 * g2
+        w64 -= lr / (np.sqrt(v64 / (1 - 0.999 ** t)) + 1e-8) * (m64 / (1 - 0.9 ** t))
+        assert abs(w.value - w64) < 2e-5 * t
+        oracle_lib.orc_adagrad(C.byref(wa), C.byref(Ga), g, lr, l2)
+        g2 = g + l2 * wa64
+        G64 += g2 * g2
+        wa64 -= lr / (1e-10 + np.sqrt(G64)) * g2
+        assert abs(wa.value - wa64) < 2e-6 * t
+
+
+def test_default_hyperparameters_train_on_the_oracle(oracle_lib):
+    """Hyperparameters::new defaults (lstm.rs:56-71): Coupled LSTM, BPR, Adam, dim 16, lr 0.01."""
+    from helpers import OPT_ADAM
+
+    ptr, items = synthetic_interactions(40, 80, 14, seed=12, zipf=True)
+    hp = hparams(80, 12, 16, int(ModelKind.LSTM_COUPLED), LOSS_BPR, lr=0.01, l2=0.0, epochs=3, B=4, opt=OPT_ADAM)
+    m = OracleModel(hp)
+    first = m.fit(ptr, items)
+    for _ in range(4):
+        last = m.fit(ptr, items)
+    assert last < first  # BPR loss sigma(neg - pos) goes down
+    assert m.optimizer_steps() == 5 * 3 * ((m.fit_begin(ptr, items).epoch_prepare()))
+    assert m.param_count(Param.ITEM_EMBEDDING_M) == 80 * 16 and np.any(m.get_param(Param.LSTM_W_M) != 0)

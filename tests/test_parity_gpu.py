@@ -6,7 +6,7 @@ order-free in f64 and is compared with rtol 1e-6."""
 import numpy as np
 import pytest
 
-from helpers import (LOSS_BPR, LOSS_HINGE, LOSS_WARP, hparams, movielens_protocol, synthetic_interactions)
+from helpers import (LOSS_BPR, LOSS_HINGE, LOSS_WARP, OPT_ADAM, hparams, movielens_protocol, synthetic_interactions)
 from oracle.oracle import OracleError, OracleModel
 from sbr_rs_amd._abi import Debug, ModelKind, Param, Status
 from sbr_rs_amd.engine import Model
@@ -217,6 +217,96 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
         assert_params_equal(models[q], o, kind, f"rank {q} of {world}")
         lg, ex = plans[q].end()
         assert lg == pytest.approx(lo, rel=1e-6)
+
+
+ADAM_BLOCKS = {
+    ModelKind.EWMA: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.EWMA_ALPHA_M],
+    ModelKind.LSTM_NORMAL: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.LSTM_W_M, Param.LSTM_B_M],
+    ModelKind.LSTM_COUPLED: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.LSTM_W_M, Param.LSTM_B_M],
+}
+
+
+@pytest.mark.parametrize("kind,loss,d,B", [
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 4),     # Hyperparameters::new defaults (lstm.rs:56-71)
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 64, 9),
+    (ModelKind.EWMA, LOSS_HINGE, 128, 16),
+])
+def test_adam_whole_fit_bit_exact(kind, loss, d, B):
+    items, T = 150, 12
+    ptr, it = synthetic_interactions(50, items, T + 4, seed=41, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, lr=0.01, l2=1e-5, epochs=3, B=B, opt=OPT_ADAM)
+    g, o = make_pair(hp)
+    lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+    g.fit(ptr, it), o.fit(ptr, it)  # bias-correction counter persists across fits
+    assert_params_equal(g, o, kind, "adam")
+    for p in ADAM_BLOCKS[kind]:
+        assert_same_bits(g.get_param(p), o.get_param(p), f"adam moment {p.name}")
+    assert g.counters() == (o.global_epoch(), o.optimizer_steps())
+    assert lg == pytest.approx(lo, rel=1e-6)
+    mg, rg = g.mrr_score(ptr, it)
+    mo, ro = o.mrr_score(ptr, it)
+    assert np.array_equal(rg, ro) and mg == mo
+
+
+def test_adam_multi_device_halves(kind=ModelKind.LSTM_COUPLED):
+    import torch
+
+    world, items, T, B, d = 2, 101, 10, 5, 32
+    ptr, it = synthetic_interactions(60, items, T + 3, seed=19, zipf=True)
+    mk = lambda q: hparams(items, T, d, int(kind), LOSS_BPR, lr=0.02, epochs=1, B=B, ndev=world, rank=q, opt=OPT_ADAM)
+    models = [Model(mk(q)) for q in range(world)]
+    plans = [m.fit_begin(ptr, it) for m in models]
+    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
+    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
+    own = [torch.zeros(chunk, **u8) for _ in range(world)]
+    recv = torch.zeros(world * chunk, **u8)
+    nmb = plans[0].epoch_prepare()
+    assert plans[1].epoch_prepare() == nmb
+    for mb in range(nmb):
+        for q in range(world):
+            plans[q].step_local(mb)
+            plans[q].step_scatter(mb, send[q].data_ptr(), dense[q].data_ptr())
+            models[q].synchronize()
+        for q in range(world):
+            for src in range(world):
+                recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
+            torch.cuda.synchronize()
+            plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
+            models[q].synchronize()
+        table, dense_all = torch.cat(own), torch.cat(dense)
+        torch.cuda.synchronize()
+        for q in range(world):
+            plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
+            models[q].synchronize()
+    o = OracleModel(mk(0))
+    o.fit(ptr, it)
+    for q in range(world):
+        assert_params_equal(models[q], o, kind, f"adam rank {q}")
+        for p in ADAM_BLOCKS[kind]:
+            assert_same_bits(models[q].get_param(p), o.get_param(p), f"adam rank {q} {p.name}")
+
+
+def test_default_hyperparameters_through_the_python_api():
+    """The reference's README flow with Hyperparameters::new defaults (Coupled LSTM, BPR, Adam)."""
+    import sbr_rs_amd as sbr
+
+    ptr, it = synthetic_interactions(80, 120, 20, seed=3, zipf=True)
+    users = np.repeat(np.arange(80), np.diff(ptr.astype(np.int64)))
+    data = sbr.data.Interactions.from_arrays(users, it, np.arange(len(it)), 80, 120)
+    rng = sbr.XorShiftRng.from_seed(bytes([42] * 16))
+    train, test = sbr.data.user_based_split(data, rng, 0.2)
+    model = sbr.lstm.Hyperparameters.new(data.num_items(), 16).rng(rng).num_epochs(3).batch_sequences(8).build()
+    l0 = model.fit(train.to_compressed())
+    l1 = model.fit(train.to_compressed())
+    assert np.isfinite(l0) and l1 < l0
+    mrr = sbr.evaluation.mrr_score(model, test.to_compressed())
+    assert 0.0 < mrr <= 1.0
+    user = model.user_representation([1, 2, 3])
+    assert model.predict(user, np.arange(120)).shape == (120,)
+    with pytest.raises(sbr.FittingError.NoInteractions):
+        sbr.ewma.Hyperparameters.new(120, 16).build().fit(sbr.data.Interactions(10, 120).to_compressed())
 
 
 def test_batch_of_one_is_per_sequence_sgd():

@@ -1124,11 +1124,12 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
         int* d_rep = nullptr;
         uint32_t *d_test = nullptr, *d_tih = nullptr, *d_hist = nullptr, *d_ranks = nullptr, *d_flag = nullptr;
+        float* d_ts = nullptr;
         uint64_t* d_hptr = nullptr;
         sbr_status st = SBR_OK;
         if ((st = dmalloc(&d_rep, nu)) == SBR_OK && (st = dmalloc(&d_test, nu)) == SBR_OK && (st = dmalloc(&d_tih, nu)) == SBR_OK &&
             (st = dmalloc(&d_hist, hist_items.size())) == SBR_OK && (st = dmalloc(&d_ranks, nu)) == SBR_OK &&
-            (st = dmalloc(&d_flag, 1)) == SBR_OK && (st = dmalloc(&d_hptr, nu + 1)) == SBR_OK) {
+            (st = dmalloc(&d_flag, 1)) == SBR_OK && (st = dmalloc(&d_hptr, nu + 1)) == SBR_OK && (st = dmalloc(&d_ts, nu)) == SBR_OK) {
             hipMemcpy(d_rep, rep_row.data(), nu * 4, hipMemcpyHostToDevice);
             hipMemcpy(d_test, test_item.data(), nu * 4, hipMemcpyHostToDevice);
             hipMemcpy(d_tih, test_in_hist.data(), nu * 4, hipMemcpyHostToDevice);
@@ -1137,7 +1138,7 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
             hipMemset(d_flag, 0, 4);
             {
                 ScopedTimer t(m, SBR_K_RANK, 1);
-                sbr::launch_rank(m->mv, H, d_rep, (uint32_t)nu, d_test, d_tih, d_hptr, d_hist, d_ranks, d_flag, m->stream);
+                sbr::launch_rank(m->mv, H, d_rep, (uint32_t)nu, d_test, d_tih, d_hptr, d_hist, d_ts, d_ranks, d_flag, m->stream);
             }
             uint32_t flag = 0;
             if (hipStreamSynchronize(m->stream) != hipSuccess ||
@@ -1147,7 +1148,7 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
             else if (flag)
                 st = SBR_ERR_INVALID_PREDICTION; /* predict fails the call on a non-finite score */
         }
-        hipFree(H); hipFree(d_rep); hipFree(d_test); hipFree(d_tih); hipFree(d_hist); hipFree(d_ranks); hipFree(d_flag); hipFree(d_hptr);
+        hipFree(H); hipFree(d_rep); hipFree(d_test); hipFree(d_tih); hipFree(d_hist); hipFree(d_ranks); hipFree(d_flag); hipFree(d_hptr); hipFree(d_ts);
         if (st != SBR_OK) return st;
     }
     float sum = 0.0f; /* evaluation.rs:47 — sequential f32 sum in user order */

@@ -93,8 +93,8 @@ void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int
 /* prediction side */
 void launch_predict(const ModelView& m, const float* user, const uint32_t* items, uint64_t n, float* out, hipStream_t s);
 void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint32_t num_users, const uint32_t* test_item,
-                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, uint32_t* ranks,
-                 uint32_t* nonfinite_flag, hipStream_t s);
+                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, float* ts_scratch,
+                 uint32_t* ranks, uint32_t* nonfinite_flag, hipStream_t s);
 /* device self-tests of the numerics contract (tests/test_numerics_gpu.py) */
 void launch_selftest_math(const float* x, float* out_exp, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s);
 void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s);

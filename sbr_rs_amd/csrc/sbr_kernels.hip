@@ -1072,40 +1072,148 @@ __global__ void predict_kernel(ModelView m, const float* user, const uint32_t* i
     out[i] = m.b[it] + chain_dot<D>(hs, m.E + (size_t)it * D);
 }
 
-// One workgroup per test user.  rank = #{i : pred_i >= pred_test} with all history items masked
-// to f32::MIN (evaluation.rs:30-41): counted over all items, then corrected for the (unique)
-// history items.
+// ------------------------------------------------------------------------------------------------
+// K7: full-catalogue scoring + rank (mrr_score, evaluation.rs:27-43) as an f32 MFMA GEMM with a
+// rank-count epilogue; the U x I score matrix is never materialised.
+//   rank_test_score_kernel : ts[u] = MIN if the test item is in the history, else bias + chain dot
+//   rank_gemm_kernel       : S[u][i] = b[i] + sum_k h[u][k] E[i][k] on v_mfma_f32_32x32x2_f32
+//                            (k ascending from 0 = the oracle's chain order); counts S >= ts[u]
+//   rank_history_kernel    : corrects the count for the (unique) history items, which the reference
+//                            masks to f32::MIN (evaluation.rs:30-32)
+// A workgroup owns 128 users (4 waves x 32) and a contiguous range of items: the users' states
+// stay in registers as MFMA A fragments, 32-item tiles of E stream through LDS.
+// ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void rank_kernel(ModelView m, const float* reps, const int* rep_row, const uint32_t* test_item,
-                                                   const uint32_t* test_in_hist, const uint64_t* hist_ptr,
-                                                   const uint32_t* hist_items, uint32_t* ranks, uint32_t* nonfinite_flag) {
-    __shared__ float hs[D];
-    __shared__ int wave_cnt[4];
+__global__ void rank_test_score_kernel(ModelView m, const float* reps, const int* rep_row, uint32_t num_users,
+                                       const uint32_t* test_item, const uint32_t* test_in_hist, float* ts, uint32_t* ranks) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= num_users) return;
+    const uint32_t ti = test_item[u];
+    ts[u] = test_in_hist[u] ? SBR_F32_MIN : m.b[ti] + chain_dot<D>(reps + (size_t)rep_row[u] * D, m.E + (size_t)ti * D);
+    ranks[u] = 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void rank_gemm_kernel(ModelView m, const float* reps, const int* rep_row, uint32_t num_users,
+                                                        const float* ts, uint32_t items_per_group, uint32_t* ranks,
+                                                        uint32_t* nonfinite_flag) {
+    constexpr int LDE = D + 1;
+    constexpr int KS = D / 2;  // MFMA k-steps
+    __shared__ float Es[2][32 * LDE];
+    __shared__ float Bs[2][32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+    const uint32_t u0 = blockIdx.x * 128 + wave * 32;
+    // A fragments of this wave's 32 users: a[s] = h[u0 + l31][2 s + hh], held for the whole item range
+    float a[KS];
+    {
+        const uint32_t u = u0 + l31;
+        const float* h = reps + (size_t)rep_row[u < num_users ? u : num_users - 1] * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = u < num_users ? h[2 * s + hh] : 0.0f;
+    }
+    // thresholds of the 16 users this lane's accumulator registers belong to
+    float tsr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t u = u0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        tsr[q] = u < num_users ? ts[u] : 0.0f;
+    }
+    int cnt[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cnt[q] = 0;
+    bool bad = false;
+    const uint32_t i_begin = blockIdx.y * items_per_group;
+    uint32_t i_end = i_begin + items_per_group;
+    if (i_end > m.num_items) i_end = m.num_items;
+    const int ntiles = i_begin < i_end ? (int)((i_end - i_begin + 31) / 32) : 0;
+    // staging map: thread -> (item row tid/8, float4 columns (tid%8) + 8 j)
+    constexpr int NV = 32 * (D / 4);
+    constexpr int ITER = (NV + 255) / 256;
+    float4 ev[ITER];
+    float bv = 0.0f;
+    auto fetch = [&](int tile) {
+        const uint32_t ib = i_begin + (uint32_t)tile * 32;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            const int r = idx / (D / 4);
+            const int c4 = (idx % (D / 4)) * 4;
+            ev[it] = (idx < NV && ib + r < i_end) ? ld4(m.E + (size_t)(ib + r) * D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 32) bv = ib + tid < i_end ? m.b[ib + tid] : 0.0f;
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            if (idx < NV) {
+                const int r = idx / (D / 4);
+                const int c4 = (idx % (D / 4)) * 4;
+                float* dst = &Es[buf][r * LDE + c4];
+                dst[0] = ev[it].x; dst[1] = ev[it].y; dst[2] = ev[it].z; dst[3] = ev[it].w;
+            }
+        }
+        if (tid < 32) Bs[buf][tid] = bv;
+    };
+    if (ntiles > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        const float* eb = &Es[buf][l31 * LDE + hh];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], eb[2 * s], acc, 0, 0, 0);
+        const float bias = Bs[buf][l31];
+        const bool item_ok = i_begin + (uint32_t)tile * 32 + l31 < i_end;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float sc = bias + acc[q];
+            if (item_ok) {
+                if (!(sc - sc == 0.0f)) bad = true;
+                if (sc >= tsr[q]) ++cnt[q];
+            }
+        }
+        if (tile + 1 < ntiles) stage(buf ^ 1);
+        __syncthreads();
+    }
+    // per-user totals: sum over the 32 item lanes of each half-wave
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int c = cnt[q];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        const uint32_t u = u0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        if (l31 == 0 && u < num_users && c) atomicAdd(&ranks[u], (uint32_t)c);
+    }
+    if (__any(bad) && lane == 0) atomicOr(nonfinite_flag, 1u);
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void rank_history_kernel(ModelView m, const float* reps, const int* rep_row, const float* ts,
+                                                          const uint64_t* hist_ptr, const uint32_t* hist_items, uint32_t* ranks) {
     const int u = blockIdx.x;
     const float* h = reps + (size_t)rep_row[u] * D;
-    for (int k = threadIdx.x; k < D; k += blockDim.x) hs[k] = h[k];
-    __syncthreads();
-    const uint32_t ti = test_item[u];
-    const float ts = test_in_hist[u] ? SBR_F32_MIN : m.b[ti] + chain_dot<D>(hs, m.E + (size_t)ti * D);
+    const float t = ts[u];
     int cnt = 0;
-    bool bad = false;
-    for (uint32_t i = threadIdx.x; i < m.num_items; i += blockDim.x) {
-        const float s = m.b[i] + chain_dot<D>(hs, m.E + (size_t)i * D);
-        if (!(s - s == 0.0f)) bad = true; /* non-finite */
-        if (s >= ts) ++cnt;
-    }
-    for (uint64_t e = hist_ptr[u] + threadIdx.x; e < hist_ptr[u + 1]; e += blockDim.x) {
+    for (uint64_t e = hist_ptr[u] + threadIdx.x; e < hist_ptr[u + 1]; e += 64) {
         const uint32_t i = hist_items[e];
-        const float s = m.b[i] + chain_dot<D>(hs, m.E + (size_t)i * D);
-        if (s >= ts) --cnt;
-        if (SBR_F32_MIN >= ts) ++cnt;
+        const float s = m.b[i] + chain_dot<D>(h, m.E + (size_t)i * D);
+        if (s >= t) --cnt;               /* it was counted by the GEMM pass ...          */
+        if (SBR_F32_MIN >= t) ++cnt;     /* ... but the masked value only counts against MIN */
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = cnt;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(nonfinite_flag, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) ranks[u] = (uint32_t)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+    if (threadIdx.x == 0 && cnt) atomicAdd(&ranks[u], (uint32_t)cnt); /* two's complement: adds a negative delta */
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1349,11 +1457,22 @@ void launch_predict(const ModelView& m, const float* user, const uint32_t* items
 }
 
 void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint32_t num_users, const uint32_t* test_item,
-                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, uint32_t* ranks,
-                 uint32_t* nonfinite_flag, hipStream_t s) {
+                 const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, float* ts_scratch,
+                 uint32_t* ranks, uint32_t* nonfinite_flag, hipStream_t s) {
     if (num_users == 0) return;
+    const uint32_t utiles = (num_users + 127) / 128;
+    // item groups: enough workgroups to fill the chip, at least one 32-item tile each
+    uint32_t groups = (1024 + utiles - 1) / utiles;
+    const uint32_t max_groups = (m.num_items + 31) / 32;
+    if (groups > max_groups) groups = max_groups;
+    if (groups < 1) groups = 1;
+    uint32_t per = (m.num_items + groups - 1) / groups;
+    per = ((per + 31) / 32) * 32;
+    groups = (m.num_items + per - 1) / per;
     DISPATCH_D(m.d, {
-        hipLaunchKernelGGL((rank_kernel<DD>), dim3(num_users), dim3(256), 0, s, m, reps, rep_row, test_item, test_in_hist, hist_ptr, hist_items, ranks, nonfinite_flag);
+        hipLaunchKernelGGL((rank_test_score_kernel<DD>), dim3((num_users + 255) / 256), dim3(256), 0, s, m, reps, rep_row, num_users, test_item, test_in_hist, ts_scratch, ranks);
+        hipLaunchKernelGGL((rank_gemm_kernel<DD>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
+        hipLaunchKernelGGL((rank_history_kernel<DD>), dim3(num_users), dim3(64), 0, s, m, reps, rep_row, ts_scratch, hist_ptr, hist_items, ranks);
     });
 }
 

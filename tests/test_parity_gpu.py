@@ -378,6 +378,32 @@ def test_invalid_arguments():
         g.predict(np.zeros(16, np.float32), np.array([10], dtype=np.uint32))  # item id out of range
 
 
+@pytest.mark.parametrize("kind,d,items,users", [
+    (ModelKind.EWMA, 128, 5003, 700),     # several 128-user tiles, ragged item range
+    (ModelKind.LSTM_NORMAL, 32, 1683, 180),
+    (ModelKind.LSTM_COUPLED, 256, 999, 37),
+    (ModelKind.EWMA, 16, 70, 300),        # fewer items than one workgroup's range
+])
+def test_mrr_gemm_ranks_bit_exact(kind, d, items, users):
+    """mrr_score through the MFMA scoring kernel: ranks (integers) and MRR equal the oracle's."""
+    T = 24
+    hp = hparams(items, T, d, int(kind), LOSS_HINGE, B=16)
+    g, o = make_pair(hp)
+    rs = np.random.RandomState(d)
+    E = (rs.randn(items, d) * 0.3).astype(np.float32)
+    E[rs.randint(0, items, 20)] = E[0]  # exact score ties
+    bias = np.round(rs.randn(items) * 0.5, 1).astype(np.float32)
+    for m in (g, o):
+        m.set_param(Param.ITEM_EMBEDDING, E)
+        m.set_param(Param.ITEM_BIAS, bias)
+    ptr, it = synthetic_interactions(users, items, 3 * T, seed=77, min_len=1, zipf=True)
+    mg, rg = g.mrr_score(ptr, it)
+    mo, ro = o.mrr_score(ptr, it)
+    assert rg.shape == ro.shape and rg.size > users // 2
+    assert np.array_equal(rg, ro)
+    assert mg == mo
+
+
 def test_test_item_in_history_ranks_last():
     """evaluation.rs:30-41: a test item that also occurs in the history is masked => rank = #items."""
     hp = hparams(20, 8, 16, int(ModelKind.EWMA), LOSS_HINGE, B=4)

@@ -389,14 +389,21 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
             }
 #pragma unroll
             for (int S = 0; S < PF; ++S) {
+                float av[RT][4];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const float* arow = &As[(rt * 16 + j16) * LDA + 16 * (S0 + S) + kq];
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+                    av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
                 }
+                // independent accumulators alternate so that no MFMA waits on its predecessor
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][0], cur[S].x, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][1], cur[S].y, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][2], cur[S].z, acc[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], cur[S].w, acc[rt], 0, 0, 0);
             }
         }
     };
@@ -573,14 +580,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView 
                 }
 #pragma unroll
                 for (int S = 0; S < PF; ++S) {
+                    float av[RT][4];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
                         const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * (S0 + S) + kq];
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[0], cur[S].x, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4], cur[S].y, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[8], cur[S].z, acc[rt], 0, 0, 0);
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[12], cur[S].w, acc[rt], 0, 0, 0);
+                        av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
                     }
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][0], cur[S].x, acc[rt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][1], cur[S].y, acc[rt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][2], cur[S].z, acc[rt], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], cur[S].w, acc[rt], 0, 0, 0);
                 }
             }
         }

@@ -260,3 +260,16 @@ def test_default_hyperparameters_train_on_the_oracle(oracle_lib):
     assert last < first  # BPR loss sigma(neg - pos) goes down
     assert m.optimizer_steps() == 5 * 3 * ((m.fit_begin(ptr, items).epoch_prepare()))
     assert m.param_count(Param.ITEM_EMBEDDING_M) == 80 * 16 and np.any(m.get_param(Param.LSTM_W_M) != 0)
+
+
+def test_dataset_loader_reads_fixture_and_csv(tmp_path):
+    """≙ datasets.rs:57-60: CSV with header user_id,item_id,rating,timestamp -> Interactions."""
+    from sbr_rs_amd import datasets
+
+    data = datasets.download_movielens_100k()
+    assert data.len() == 100000 and data.num_items() == 1683
+    p = tmp_path / "d.csv"
+    p.write_text("user_id,item_id,rating,timestamp\n196,242,3.0,881250949\n186,302,3.0,891717742\n")
+    small = datasets.load_csv(str(p))
+    assert small.len() == 2 and small.num_users() == 197 and small.num_items() == 303
+    assert [x.timestamp() for x in small.data()] == [881250949, 891717742]

@@ -31,6 +31,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define EWMA_CHUNK_SEQS 256
+#ifndef SBR_FWD_RT
+#define SBR_FWD_RT 2   /* 16-row tiles per sequence-resident workgroup */
+#endif
+#ifndef SBR_FWD_UPW
+#define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
+#endif
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -438,6 +444,162 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
             w.C[r * D + u] = cc;
             H[r * D + u] = hh;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2, sequence-resident form: one workgroup owns a tile of 32 sequences (rows b0..b0+31 of the
+// length-sorted minibatch) for ALL its time steps — sequences are independent, so no grid-wide
+// synchronisation is needed, h_{t-1} never leaves LDS and c_{t-1} never leaves registers.  Wave w
+// owns unit tile w with all gates (cell is lane-local); per step it computes
+// z = [x_t ; h_{t-1}] Wp + b on v_mfma_f32_16x16x4_f32 (bias-seeded accumulators, k ascending),
+// applies the cell, writes G/C/H rows for BPTT and h_t into LDS.  The gather of x_{t+1} is in
+// flight during the MFMAs of step t; weights stream from L2 in the Wp fragment packing.  Different
+// workgroups drift out of phase over the steps, so one workgroup's gathers/epilogue overlap
+// another's MFMAs (per-step launches start every workgroup in lockstep and serialise the phases).
+// ------------------------------------------------------------------------------------------------
+template <int D, int NG, int RT, int UPW>
+__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : 3) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles) {
+    constexpr int K2 = 2 * D;
+    constexpr int LDA = K2 + 2;
+    constexpr int NS = K2 / 16;
+    constexpr int UT = D / 16;
+    constexpr int NW = UT / UPW;      // waves; wave v owns unit tiles v*UPW .. v*UPW+UPW-1
+    constexpr int NT = NW * 64;
+    constexpr int ROWS = 16 * RT;
+    constexpr int NV = ROWS * (D / 4);
+    constexpr int ITER = (NV + NT - 1) / NT;
+    __shared__ float As[ROWS * LDA];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j16 = lane & 15;
+    const int kq = lane >> 4;
+    // tiles are sorted by length; fold the list so that consecutive resident slots of a CU get
+    // long/short/long/short ... and every CU ends up with about the same number of steps
+    const int nslot = 256;
+    const int q = (int)blockIdx.x / nslot, c = (int)blockIdx.x % nslot;
+    const int fold_w = ntiles - q * nslot < nslot ? ntiles - q * nslot : nslot;
+    const int tile = (q & 1) ? q * nslot + (fold_w - 1 - c) : (int)blockIdx.x;
+    const int b0 = tile * ROWS;
+    const int nsteps = mb.steps[b0];
+    float bias[UPW][NG];
+#pragma unroll
+    for (int p = 0; p < UPW; ++p)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bias[p][g] = m.bW[g * D + (wv * UPW + p) * 16 + j16];
+    float cst[RT][UPW][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int p = 0; p < UPW; ++p)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) cst[rt][p][reg] = 0.0f;
+    for (int idx = tid; idx < ROWS * D; idx += NT) As[(idx / D) * LDA + D + (idx % D)] = 0.0f;  // h_{-1} = 0
+    float4 xn[ITER];
+    auto prefetch_x = [&](int row_begin, int nrows) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NT;
+            const int i = idx / (D / 4);
+            const int c4 = (idx % (D / 4)) * 4;
+            xn[it] = (idx < NV && i < nrows) ? ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int row_begin = mb.off[0];
+    int nrows = mb.off[1] - row_begin - b0;
+    nrows = nrows < ROWS ? nrows : ROWS;
+    prefetch_x(row_begin, nrows);
+    for (int t = 0; t < nsteps; ++t) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * NT;
+            if (idx < NV) {
+                const int i = idx / (D / 4);
+                const int c4 = (idx % (D / 4)) * 4;
+                float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
+                dst[0] = make_float2(xn[it].x, xn[it].y);
+                dst[1] = make_float2(xn[it].z, xn[it].w);
+            }
+        }
+        __syncthreads();  // x_t staged, h_{t-1} written by the previous epilogue
+        int row_begin_next = 0, nrows_next = 0;
+        if (t + 1 < nsteps) {
+            row_begin_next = mb.off[t + 1];
+            nrows_next = mb.off[t + 2] - row_begin_next - b0;
+            nrows_next = nrows_next < ROWS ? nrows_next : ROWS;
+            prefetch_x(row_begin_next, nrows_next);  // in flight during the MFMAs below
+        }
+        f32x4 acc[RT][UPW][NG];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < UPW; ++p)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[rt][p][g] = (f32x4){bias[p][g], bias[p][g], bias[p][g], bias[p][g]};
+        float4 bA[UPW][NG], bB[UPW][NG];
+        auto load_b = [&](float4 (*dst)[NG], int S) {
+#pragma unroll
+            for (int p = 0; p < UPW; ++p)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    dst[p][g] = ld4(m.Wp + ((((size_t)((wv * UPW + p) * NG + g)) * NS + S) * 64 + lane) * 4);
+        };
+        auto mma_block = [&](int S, float4 (*bf)[NG]) {
+            float av[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* arow = &As[(rt * 16 + j16) * LDA + 16 * S + kq];
+                av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
+            }
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int p = 0; p < UPW; ++p)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const float bval = sub == 0 ? bf[p][g].x : sub == 1 ? bf[p][g].y : sub == 2 ? bf[p][g].z : bf[p][g].w;
+                            acc[rt][p][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], bval, acc[rt][p][g], 0, 0, 0);
+                        }
+        };
+        load_b(bA, 0);
+#pragma unroll 1
+        for (int S = 0; S < NS; S += 2) {
+            load_b(bB, S + 1);
+            mma_block(S, bA);
+            if (S + 2 < NS) load_b(bA, S + 2);
+            mma_block(S + 1, bB);
+        }
+        __syncthreads();  // every wave is done reading As
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int p = 0; p < UPW; ++p) {
+                const int u = (wv * UPW + p) * 16 + j16;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = rt * 16 + kq * 4 + reg;
+                    if (i < nrows) {
+                        const size_t r = (size_t)(row_begin + b0 + i);
+                        float zi, zf, zg, zo;
+                        if (NG == 4) { zi = acc[rt][p][0][reg]; zf = acc[rt][p][1][reg]; zg = acc[rt][p][2][reg]; zo = acc[rt][p][NG - 1][reg]; }
+                        else { zi = 0.0f; zf = acc[rt][p][0][reg]; zg = acc[rt][p][1][reg]; zo = acc[rt][p][2][reg]; }
+                        float gi, gf, gg, go, cc, hh;
+                        sbr_lstm_cell_fwd(zi, zf, zg, zo, cst[rt][p][reg], NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
+                        cst[rt][p][reg] = cc;
+                        float* G = w.G + r * 4 * D;
+                        G[u] = gi; G[D + u] = gf; G[2 * D + u] = gg; G[3 * D + u] = go;
+                        w.C[r * D + u] = cc;
+                        H[r * D + u] = hh;
+                        As[i * LDA + D + u] = hh;
+                    }
+                }
+            }
+        row_begin = row_begin_next;
+        nrows = nrows_next;
     }
 }
 
@@ -1303,6 +1465,20 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         DISPATCH_D(m.d, {
             const int gpb = 4 * (64 / (DD / 4));
             hipLaunchKernelGGL((ewma_forward_kernel<DD>), dim3(grid_for_groups(mb.B, gpb)), dim3(256), 0, s, m, mb, H);
+        });
+        return;
+    }
+    if (m.d <= 128) { /* sequence-resident kernel: one launch for all time steps */
+        DISPATCH_D(m.d, {
+            if constexpr (DD <= 128) {
+                constexpr int RT = SBR_FWD_RT;
+                constexpr int UPW = (DD / 16) % SBR_FWD_UPW == 0 ? SBR_FWD_UPW : 1;
+                const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
+                if (m.ng == 4)
+                    hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
+                else
+                    hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
+            }
         });
         return;
     }

@@ -776,6 +776,173 @@ __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5, sequence-resident form: one workgroup owns a tile of 32 sequences for ALL its time steps,
+// walking t downwards.  Per step: (a) cell backward for the tile — every thread owns two
+// (row, 4-unit) items, keeps their dc carry in registers, re-forms dloss/dh from (neg, coef) with
+// two row gathers, reads the recurrent dh from LDS — writes dz into LDS (GEMM operand) and HBM
+// (dense-gradient GEMM); (b) dxh = dz * W^T on v_mfma_f32_16x16x4_f32 (accumulators from 0,
+// j ascending), wave w producing column tiles w (dX of the row, stored) and UT+w (recurrent dh for
+// step t-1, kept in LDS).  The inputs of step t-1 (gates, cell states, embedding rows) are
+// requested before the GEMM of step t and arrive under its MFMAs.  One workgroup per CU; tiles are
+// dispatched longest first, so the tail is made of the shortest tiles.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NG>
+__global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+    constexpr int NGD = NG * D;
+    constexpr int LDZ = NGD + 2;
+    constexpr int NSZ = NGD / 16;
+    constexpr int UT = D / 16;
+    constexpr int NW = UT;
+    constexpr int NT = NW * 64;
+    constexpr int ROWS = 32;
+    constexpr int RT = 2;
+    constexpr int Q = D / 4;
+    constexpr int CITER = (ROWS * Q) / NT;  // = 2 for every supported D
+    __shared__ float Zs[ROWS * LDZ];
+    __shared__ float Rs[ROWS * D];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15;
+    const int kq = lane >> 4;
+    const int b0 = blockIdx.x * ROWS;
+    const int nsteps = mb.steps[b0];
+    for (int idx = tid; idx < ROWS * D; idx += NT) Rs[idx] = 0.0f;
+    float dc[CITER][4];
+#pragma unroll
+    for (int k = 0; k < CITER; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dc[k][j] = 0.0f;
+    // prefetched cell inputs of the step about to be processed
+    float4 pg[CITER][4], pc[CITER], pcp[CITER], pen[CITER], pep[CITER];
+    float pcoef[CITER];
+    int p_row_begin = 0, p_nrows = 0;
+    auto prefetch = [&](int t) {
+        p_row_begin = mb.off[t];
+        p_nrows = mb.off[t + 1] - p_row_begin - b0;
+        p_nrows = p_nrows < ROWS ? p_nrows : ROWS;
+        const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
+#pragma unroll
+        for (int k = 0; k < CITER; ++k) {
+            const int idx = tid + k * NT;
+            const int i = idx / Q;
+            const int u = (idx % Q) * 4;
+            if (i < p_nrows) {
+                const size_t r = (size_t)(p_row_begin + b0 + i);
+                const float* G = w.G + r * 4 * D;
+                pg[k][0] = ld4(G + u); pg[k][1] = ld4(G + D + u); pg[k][2] = ld4(G + 2 * D + u); pg[k][3] = ld4(G + 3 * D + u);
+                pc[k] = ld4(w.C + r * D + u);
+                pcp[k] = t > 0 ? ld4(w.C + (size_t)(prev_begin + b0 + i) * D + u) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pcoef[k] = blk.coef[r];
+                pen[k] = ld4(m.E + (size_t)blk.neg[r] * D + u);
+                pep[k] = ld4(m.E + (size_t)blk.out_idx[r] * D + u);
+            }
+        }
+    };
+    prefetch(nsteps - 1);
+    for (int t = nsteps - 1; t >= 0; --t) {
+        const int row_begin = p_row_begin;
+        const int nrows = p_nrows;
+        __syncthreads();  // Rs of the previous step is complete, Zs is free
+        // (a) cell backward
+#pragma unroll
+        for (int k = 0; k < CITER; ++k) {
+            const int idx = tid + k * NT;
+            const int i = idx / Q;
+            const int u = (idx % Q) * 4;
+            float dz[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dz[g][j] = 0.0f;
+            if (i < nrows) {
+                const float g_ = pcoef[k];
+                const float4 rec = *reinterpret_cast<const float4*>(&Rs[i * D + u]);
+                const float dhl[4] = {g_ * pen[k].x - g_ * pep[k].x, g_ * pen[k].y - g_ * pep[k].y,
+                                      g_ * pen[k].z - g_ * pep[k].z, g_ * pen[k].w - g_ * pep[k].w};
+                const float recv[4] = {rec.x, rec.y, rec.z, rec.w};
+                const float gi[4] = {pg[k][0].x, pg[k][0].y, pg[k][0].z, pg[k][0].w};
+                const float gf[4] = {pg[k][1].x, pg[k][1].y, pg[k][1].z, pg[k][1].w};
+                const float gg[4] = {pg[k][2].x, pg[k][2].y, pg[k][2].z, pg[k][2].w};
+                const float go[4] = {pg[k][3].x, pg[k][3].y, pg[k][3].z, pg[k][3].w};
+                const float cc[4] = {pc[k].x, pc[k].y, pc[k].z, pc[k].w};
+                const float cp[4] = {pcp[k].x, pcp[k].y, pcp[k].z, pcp[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dh = dhl[j] + recv[j];
+                    float dco;
+                    sbr_lstm_cell_bwd(dh, dc[k][j], gi[j], gf[j], gg[j], go[j], cc[j], cp[j], NG == 3, &dz[0][j], &dz[1][j],
+                                      &dz[2][j], &dz[3][j], &dco);
+                    dc[k][j] = dco;
+                }
+                float* dZ = w.dZ + (size_t)(row_begin + b0 + i) * NGD;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int src = NG == 4 ? g : g + 1;
+                    st4(dZ + g * D + u, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3]));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int src = NG == 4 ? g : g + 1;
+                float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + g * D + u]);
+                dst[0] = make_float2(dz[src][0], dz[src][1]);
+                dst[1] = make_float2(dz[src][2], dz[src][3]);
+            }
+        }
+        __syncthreads();
+        if (t > 0) prefetch(t - 1);  // arrives under the MFMAs below
+        // (b) GEMM
+        f32x4 acc[2][RT];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[cc][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* wp0 = m.WTp + ((size_t)wv * NSZ * 64 + lane) * 4;
+        const float* wp1 = m.WTp + ((size_t)(UT + wv) * NSZ * 64 + lane) * 4;
+        float4 bA0 = ld4(wp0), bA1 = ld4(wp1), bB0, bB1;
+        auto mma_block = [&](int S, float4 b0v, float4 b1v) {
+            float av[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * S + kq];
+                av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
+            }
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const float v0 = sub == 0 ? b0v.x : sub == 1 ? b0v.y : sub == 2 ? b0v.z : b0v.w;
+                const float v1 = sub == 0 ? b1v.x : sub == 1 ? b1v.y : sub == 2 ? b1v.z : b1v.w;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], v0, acc[0][rt], 0, 0, 0);
+                    acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], v1, acc[1][rt], 0, 0, 0);
+                }
+            }
+        };
+#pragma unroll 1
+        for (int S = 0; S < NSZ; S += 2) {
+            bB0 = ld4(wp0 + (size_t)(S + 1) * 256);
+            bB1 = ld4(wp1 + (size_t)(S + 1) * 256);
+            mma_block(S, bA0, bA1);
+            if (S + 2 < NSZ) {
+                bA0 = ld4(wp0 + (size_t)(S + 2) * 256);
+                bA1 = ld4(wp1 + (size_t)(S + 2) * 256);
+            }
+            mma_block(S + 1, bB0, bB1);
+        }
+        // epilogue: dX to HBM, recurrent dh to LDS (Rs was consumed before the second barrier above)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = rt * 16 + kq * 4 + reg;
+                if (i < nrows) blk.dX[(size_t)(row_begin + b0 + i) * D + wv * 16 + c16] = acc[0][rt][reg];
+                Rs[i * D + wv * 16 + c16] = acc[1][rt][reg];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Dense gradient dW[k][j] = sum_r xh[r][k] dz[r][j] : v_mfma_f32_32x32x2_f32.  One workgroup (4
 // waves, 2x2) per 128x128 output tile and 1024-row chunk; every wave keeps a 64x64 sub-tile (2x2
 // accumulators, from 0, rows ascending).  32-row slabs of xh (gathered: E rows / previous hidden
@@ -1536,7 +1703,20 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w.partials, nch, m.d, m.alpha, blk.dense);
         return;
     }
-    for (int t = tm_host - 1; t >= 0; --t) {
+    bool stepwise = true;
+    if (m.d <= 128 && (m.ng * m.d) % 32 == 0) { /* sequence-resident BPTT: one launch for all time steps */
+        DISPATCH_D(m.d, {
+            if constexpr (DD <= 128) {
+                const int ntiles = (b_host + 31) / 32;
+                if (m.ng == 4)
+                    hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                else
+                    hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                stepwise = false;
+            }
+        });
+    }
+    for (int t = stepwise ? tm_host - 1 : -1; t >= 0; --t) {
         const int bt = off_host[t + 1] - off_host[t];
         DISPATCH_D(m.d, {
             const int cell_blocks = (bt * (DD / 4) + 255) / 256;

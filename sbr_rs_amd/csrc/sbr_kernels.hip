@@ -1007,6 +1007,10 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
         }
     };
     const int nslabs = (nr + SLAB - 1) / SLAB;
+    // bias-gradient row (k = 2D): column sums of dz, a plain add chain over the rows of the chunk;
+    // done by the tk == 0 workgroups from the dz slab they stage anyway (threads 0..127, one column each)
+    float bias_acc = 0.0f;
+    const bool do_bias = tk == 0 && tid < 128 && tj * 128 + tid < NGD;
     fetch(0);
     for (int slab = 0; slab < nslabs; ++slab) {
 #pragma unroll
@@ -1027,8 +1031,13 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (do_bias) {
+            const int rows_here = nr - slab * SLAB < SLAB ? nr - slab * SLAB : SLAB;
+            for (int r = 0; r < rows_here; ++r) bias_acc = bias_acc + Zs[r * 128 + tid];
+        }
         __syncthreads();
     }
+    if (do_bias) w.partials[((size_t)c * (K2 + 1) + K2) * NGD + tj * 128 + tid] = bias_acc;
     float* part = w.partials + (size_t)c * (K2 + 1) * NGD;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1041,28 +1050,6 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
                 if (k < K2 && j < NGD) part[(size_t)k * NGD + j] = acc[a][b][q];
             }
         }
-}
-
-// bias-gradient row of the partials: chain of plain adds over the rows of the chunk (loads are
-// issued eight rows ahead of the dependent add chain)
-__global__ __launch_bounds__(256) void lstm_dbias_kernel(MbView mb, const float* dZ, int K2, int NGD, float* partials) {
-    const int c = blockIdx.x;
-    const int j = blockIdx.y * 256 + threadIdx.x;
-    if (j >= NGD) return;
-    const int r0 = c * SBR_DW_CHUNK_ROWS;
-    int r1 = r0 + SBR_DW_CHUNK_ROWS;
-    if (r1 > mb.R) r1 = mb.R;
-    float acc = 0.0f;
-    int r = r0;
-    for (; r + 8 <= r1; r += 8) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = dZ[(size_t)(r + i) * NGD + j];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc = acc + v[i];
-    }
-    for (; r < r1; ++r) acc = acc + dZ[(size_t)r * NGD + j];
-    partials[((size_t)c * (K2 + 1) + K2) * NGD + j] = acc;
 }
 
 __global__ void dense_reduce_local_kernel(const float* partials, int nchunks, size_t n, float* dense) {
@@ -1741,7 +1728,6 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         else
             hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(tiles, nch), dim3(256), 0, s, m, mb, blk, w);
     });
-    hipLaunchKernelGGL(lstm_dbias_kernel, dim3(nch, (NGD + 255) / 256), dim3(256), 0, s, mb, w.dZ, K2, NGD, w.partials);
     const size_t n = (size_t)(K2 + 1) * NGD;
     hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
 }

@@ -891,8 +891,11 @@ __global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m
             }
         }
         __syncthreads();
-        if (t > 0) prefetch(t - 1);  // arrives under the MFMAs below
-        // (b) GEMM
+        // (b) GEMM.  Vector loads retire in order, so the weight-fragment loads of the first PFD
+        // k-blocks are issued BEFORE the (slow, HBM) prefetch of step t-1's cell inputs: the MFMAs
+        // of those blocks then run without waiting behind the gathers, which get PFD blocks of
+        // MFMA time to land.
+        constexpr int PFD = NSZ % 8 == 0 ? 8 : (NSZ % 6 == 0 ? 6 : (NSZ % 4 == 0 ? 4 : (NSZ % 3 == 0 ? 3 : (NSZ % 2 == 0 ? 2 : 1))));
         f32x4 acc[2][RT];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
@@ -900,7 +903,13 @@ __global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m
             for (int rt = 0; rt < RT; ++rt) acc[cc][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* wp0 = m.WTp + ((size_t)wv * NSZ * 64 + lane) * 4;
         const float* wp1 = m.WTp + ((size_t)(UT + wv) * NSZ * 64 + lane) * 4;
-        float4 bA0 = ld4(wp0), bA1 = ld4(wp1), bB0, bB1;
+        float4 ring0[PFD], ring1[PFD];
+#pragma unroll
+        for (int S = 0; S < PFD; ++S) {
+            ring0[S] = ld4(wp0 + (size_t)S * 256);
+            ring1[S] = ld4(wp1 + (size_t)S * 256);
+        }
+        if (t > 0) prefetch(t - 1);
         auto mma_block = [&](int S, float4 b0v, float4 b1v) {
             float av[RT][4];
 #pragma unroll
@@ -920,15 +929,15 @@ __global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m
             }
         };
 #pragma unroll 1
-        for (int S = 0; S < NSZ; S += 2) {
-            bB0 = ld4(wp0 + (size_t)(S + 1) * 256);
-            bB1 = ld4(wp1 + (size_t)(S + 1) * 256);
-            mma_block(S, bA0, bA1);
-            if (S + 2 < NSZ) {
-                bA0 = ld4(wp0 + (size_t)(S + 2) * 256);
-                bA1 = ld4(wp1 + (size_t)(S + 2) * 256);
+        for (int S0 = 0; S0 < NSZ; S0 += PFD) {
+#pragma unroll
+            for (int j = 0; j < PFD; ++j) {
+                mma_block(S0 + j, ring0[j], ring1[j]);
+                if (S0 + j + PFD < NSZ) {
+                    ring0[j] = ld4(wp0 + (size_t)(S0 + j + PFD) * 256);
+                    ring1[j] = ld4(wp1 + (size_t)(S0 + j + PFD) * 256);
+                }
             }
-            mma_block(S + 1, bB0, bB1);
         }
         // epilogue: dX to HBM, recurrent dh to LDS (Rs was consumed before the second barrier above)
 #pragma unroll
@@ -1691,7 +1700,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         return;
     }
     bool stepwise = true;
-    if (m.d <= 128 && (m.ng * m.d) % 32 == 0) { /* sequence-resident BPTT: one launch for all time steps */
+    if (m.d <= 128) { /* sequence-resident BPTT: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
                 const int ntiles = (b_host + 31) / 32;

@@ -83,6 +83,8 @@ struct sbr_model {
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::mutex mu;
     bool timing = false;
     std::vector<TimingPair> pending;
@@ -96,17 +98,19 @@ struct ScopedTimer {
     sbr_model* m;
     TimingPair tp;
     bool on;
-    ScopedTimer(sbr_model* model, int family, uint64_t launches) : m(model), on(model->timing) {
+    hipStream_t st;
+    ScopedTimer(sbr_model* model, int family, uint64_t launches, hipStream_t stream = nullptr)
+        : m(model), on(model->timing), st(stream ? stream : model->stream) {
         if (!on) return;
         tp.family = family;
         tp.launches = launches;
         hipEventCreate(&tp.a);
         hipEventCreate(&tp.b);
-        hipEventRecord(tp.a, m->stream);
+        hipEventRecord(tp.a, st);
     }
     ~ScopedTimer() {
         if (!on) return;
-        hipEventRecord(tp.b, m->stream);
+        hipEventRecord(tp.b, st);
         m->pending.push_back(tp);
     }
 };
@@ -202,7 +206,7 @@ struct DevicePacked { /* device image of one or more Packed, concatenated */
 struct WorkBuffers {
     sbr::WorkView v{};
     void release() {
-        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
+        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.X); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
         hipFree(v.partials); hipFree(v.loss); hipFree(v.tries); hipFree(v.part_loss); hipFree(v.part_tries);
         v = sbr::WorkView{};
     }
@@ -214,6 +218,7 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
     if (m->ng) {
         SBRCHK(dmalloc(&v.C, rmax * d));
         SBRCHK(dmalloc(&v.G, rmax * d * 4));
+        SBRCHK(dmalloc(&v.X, rmax * d));
     }
     if (training) {
         SBRCHK(dmalloc(&v.dH, rmax * d));
@@ -276,6 +281,7 @@ struct sbr_fit_plan {
     int key_bits = 64;
     double* loss_acc = nullptr;
     unsigned long long* ex_acc = nullptr;
+    bool dense_pending = false; /* the side stream still owes blk.dense */
     /* last step (debug) */
     int last_R = 0;
     const void* last_block = nullptr;
@@ -369,6 +375,9 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return SBR_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     m->own_stream = true;
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     sbr::ModelView& v = m->mv;
     std::memset(&v, 0, sizeof(v));
     v.d = m->d; v.ng = m->ng; v.coupled = m->ng == 3;
@@ -449,6 +458,9 @@ void sbr_model_destroy(sbr_model* m) {
     hipFree(v.Em); hipFree(v.bm); hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
+    if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
     delete m;
 }
 
@@ -658,6 +670,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     if (!p) return;
     hipSetDevice(p->m->device);
     if (p->pending) { p->worker.join(); p->pending = false; }
+    hipStreamSynchronize(p->m->side);
     hipStreamSynchronize(p->m->stream);
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
@@ -792,6 +805,14 @@ sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uin
     return SBR_OK;
 }
 
+static sbr_status join_dense(sbr_fit_plan* p) {
+    if (p->dense_pending) {
+        HIPCHK(hipStreamWaitEvent(p->m->stream, p->m->ev_join, 0));
+        p->dense_pending = false;
+    }
+    return SBR_OK;
+}
+
 sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
@@ -815,6 +836,17 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng ? (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }
+    /* the dense-gradient GEMM (MFMA-bound, reads dZ / X / H only) goes to the side stream so that the
+     * HBM-bound sparse update that follows on the main stream overlaps it; joined in step_apply /
+     * step_scatter before anything reads blk.dense */
+    HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    {
+        ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, m->side);
+        sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, m->side);
+    }
+    HIPCHK(hipEventRecord(m->ev_join, m->side));
+    p->dense_pending = true;
     p->last_R = mb.R;
     p->last_block = block;
     HIPCHK(hipGetLastError());
@@ -830,13 +862,14 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     begin_optimizer_step(m);
     sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
     {
-        ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
-        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
-    }
-    {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         sbr::launch_sparse_apply(m->mv, all, p->block_bytes, 1, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch,
                                  p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->stream);
+    }
+    SBRCHK(join_dense(p));
+    {
+        ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
+        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -875,6 +908,7 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
         sbr::launch_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys, p->keys_sorted, p->sort_temp,
                             p->sort_temp_bytes, p->key_bits, m->stream);
     }
+    SBRCHK(join_dense(p));
     /* small dense block = [8-word header | dense grads] */
     HIPCHK(hipMemcpyAsync(device_dense_out, bv.header, 32, hipMemcpyDeviceToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(device_dense_out) + 32, bv.dense, dense_count(m) * 4,
@@ -963,6 +997,7 @@ sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, u
     if (!p || !host_out || !p->last_block) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
+    SBRCHK(join_dense(p));
     HIPCHK(hipStreamSynchronize(m->stream));
     const sbr::BlockView bv = block_view(m, const_cast<void*>(p->last_block), p->rmax);
     const uint64_t R = (uint64_t)p->last_R, d = (uint64_t)m->d;

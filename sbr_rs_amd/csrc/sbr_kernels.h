@@ -51,6 +51,7 @@ struct ModelView {
 
 struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     float *C, *G, *dH, *dZ;
+    float* X;               /* [Rmax][d] copy of the gathered input rows (forward) for the dense-gradient GEMM */
     float *dHrec, *dCrec;   /* [Bmax][d] */
     float* dab;             /* EWMA per-sequence dalpha partials [Bmax][d] */
     float* partials;        /* dense-gradient chunk partials */
@@ -69,9 +70,18 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
 /* debug only: dloss/dh of every packed row (the training path never materialises it) */
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
 void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s);
-/* BPTT + dense gradient into blk.dense */
+/* BPTT (dX, dZ) and, separately, the dense gradient into blk.dense (may run on a second stream:
+ * it reads only dZ, X, H) */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s);
+void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+                           int b_host, hipStream_t s);
+/* sparse update split in two so that the key sort can start early */
+void launch_sparse_sort(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                        const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                        size_t sort_temp_bytes, int key_bits, hipStream_t s);
+void launch_sparse_apply_sorted(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                                const uint32_t* rows_of_device_host, const uint64_t* keys_sorted, hipStream_t s);
 /* dense: sum over device blocks in device order + Adagrad (+ repack of the LSTM weights) */
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
                         int ndev, hipStream_t s);

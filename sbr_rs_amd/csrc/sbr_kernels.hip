@@ -362,6 +362,7 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
         hv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < NV && i < nrows) {
             xv[it] = ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4);
+            if (blockIdx.y == 0) st4(w.X + (size_t)(row_begin + b0 + i) * D + c4, xv[it]);  // copy for the dense-gradient GEMM
             if (t > 0) hv[it] = ld4(H + (size_t)(prev_begin + b0 + i) * D + c4);
         }
     }
@@ -521,6 +522,9 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : 3) void lstm_fw
                 float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
                 dst[0] = make_float2(xn[it].x, xn[it].y);
                 dst[1] = make_float2(xn[it].z, xn[it].w);
+                // copy of the gathered input rows: the dense-gradient GEMM streams it instead of
+                // re-gathering E, which lets it run concurrently with the sparse update of E
+                if (i < nrows) st4(w.X + (size_t)(row_begin + b0 + i) * D + c4, xn[it]);
             }
         }
         __syncthreads();  // x_t staged, h_{t-1} written by the previous epilogue
@@ -966,7 +970,6 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
     constexpr int SLAB = 32;
     __shared__ float Xs[SLAB * 128];
     __shared__ float Zs[SLAB * 128];
-    __shared__ int s_in[SBR_DW_CHUNK_ROWS];
     __shared__ int s_prev[SBR_DW_CHUNK_ROWS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -979,7 +982,6 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
     if (r1 > mb.R) r1 = mb.R;
     const int nr = r1 - r0;
     for (int i = tid; i < nr; i += 256) {
-        s_in[i] = (int)mb.in_idx[r0 + i];
         s_prev[i] = mb.prev_row[r0 + i];
     }
     __syncthreads();
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
             const int lr = slab * SLAB + srow + 8 * i;
             float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), zv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (lr < nr) {
-                if (kcol < D) xv = ld4(m.E + (size_t)s_in[lr] * D + kcol);
+                if (kcol < D) xv = ld4(w.X + (size_t)(r0 + lr) * D + kcol);
                 else if (kcol < K2) {
                     const int pr = s_prev[lr];
                     if (pr >= 0) xv = ld4(blk.H + (size_t)pr * D + (kcol - D));
@@ -1728,6 +1730,11 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
             }
         });
     }
+}
+
+void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+                           int b_host, hipStream_t s) {
+    if (rows_host == 0 || m.ng == 0) return; /* EWMA's dalpha and the empty case are handled by launch_recurrent_backward */
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
@@ -1759,26 +1766,47 @@ size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits) {
     return bytes;
 }
 
-void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                         size_t sort_temp_bytes, int key_bits, hipStream_t s) {
-    DevRows dr;
+static uint64_t sparse_layout(int ndev, const uint32_t* rows_of_device_host, DevRows* dr, uint32_t* maxr) {
     uint64_t total = 0;
-    uint32_t maxr = 0;
-    for (int q = 0; q < 16; ++q) { dr.rows[q] = 0; dr.key_base[q] = 0; }
+    *maxr = 0;
+    for (int q = 0; q < 16; ++q) { dr->rows[q] = 0; dr->key_base[q] = 0; }
     for (int q = 0; q < ndev; ++q) {
-        dr.rows[q] = rows_of_device_host[q];
-        dr.key_base[q] = (uint32_t)total;
+        dr->rows[q] = rows_of_device_host[q];
+        dr->key_base[q] = (uint32_t)total;
         total += 3ull * rows_of_device_host[q];
-        if (rows_of_device_host[q] > maxr) maxr = rows_of_device_host[q];
+        if (rows_of_device_host[q] > *maxr) *maxr = rows_of_device_host[q];
     }
+    return total;
+}
+
+void launch_sparse_sort(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                        const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                        size_t sort_temp_bytes, int key_bits, hipStream_t s) {
+    DevRows dr;
+    uint32_t maxr = 0;
+    const uint64_t total = sparse_layout(ndev, rows_of_device_host, &dr, &maxr);
     if (total == 0) return;
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid_for_groups(maxr, 256), ndev), dim3(256), 0, s, all_blocks, block_bytes, rmax, dr, keys);
     (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
+}
+
+void launch_sparse_apply_sorted(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                                const uint32_t* rows_of_device_host, const uint64_t* keys_sorted, hipStream_t s) {
+    DevRows dr;
+    uint32_t maxr = 0;
+    const uint64_t total = sparse_layout(ndev, rows_of_device_host, &dr, &maxr);
+    if (total == 0) return;
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((sparse_apply_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, m, all_blocks, block_bytes, rmax, keys_sorted, total);
     });
+}
+
+void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
+                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                         size_t sort_temp_bytes, int key_bits, hipStream_t s) {
+    launch_sparse_sort(m, all_blocks, block_bytes, ndev, rmax, rows_of_device_host, keys, keys_sorted, sort_temp, sort_temp_bytes, key_bits, s);
+    launch_sparse_apply_sorted(m, all_blocks, block_bytes, ndev, rmax, rows_of_device_host, keys_sorted, s);
 }
 
 void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,

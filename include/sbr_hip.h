@@ -158,6 +158,15 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
 sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk);
 sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all);
 
+/* The same multi-device fit driven from ONE process (≙ fit with num_threads(n) on one host,
+ * sequence_model.rs:90-102): models[r] was created with num_devices = n, device_rank = r, the same
+ * seed, on the device that was current at its creation (sbr_set_device).  The exchange runs as
+ * peer copies between the devices' streams, ordered with events; results are bit-identical to the
+ * one-process-per-GPU driver.  n = 1 is sbr_model_fit. */
+sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, float* out_loss);
+sbr_status sbr_device_count(int32_t* out_count);
+
 /* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
 sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);
 sbr_status sbr_model_synchronize(sbr_model* m);

@@ -58,5 +58,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+REPO = os.path.dirname(HERE)
+FACADE_SRC = os.path.join(REPO, "tests", "cpp", "facade_tests.cpp")
+FACADE_BIN = os.path.join(REPO, "tests", "cpp", "_build", "facade_tests")
+
+
+def build_facade_tests(force: bool = False, verbose: bool = True) -> str:
+    """g++ build of the C++ host layer's test program (include/sbr.hpp over libsbr_hip.so)."""
+    cxx = shutil.which("g++") or "g++"
+    deps = [FACADE_SRC, os.path.join(REPO, "include", "sbr.hpp"), os.path.join(REPO, "include", "sbr_hip.h"), LIB]
+    if force or _stale(FACADE_BIN, deps):
+        os.makedirs(os.path.dirname(FACADE_BIN), exist_ok=True)
+        cmd = [cxx, "-std=c++17", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(REPO, "include"), FACADE_SRC, "-o", FACADE_BIN,
+               "-L" + HERE, "-lsbr_hip", "-Wl,-rpath,$ORIGIN/../../../sbr_rs_amd"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return FACADE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_facade_tests(force="--force" in sys.argv))

@@ -993,6 +993,124 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     return st;
 }
 
+/* Single-process multi-device fit: the in-process analogue of fit with num_threads(n)
+ * (sequence_model.rs:90-102, 163-169).  One host thread drives n replicas, each on its own HIP
+ * device and stream; the owner-reduce exchange of sbr_fit_step_scatter / _owner_reduce /
+ * _apply_table is carried by peer copies (xGMI when the devices are peers) ordered with events:
+ *   scattered[r]  send_r / dense_r of this step are complete
+ *   reduced[p]    own_p of this step is complete
+ *   applied[q]    q has finished reading its peers' buffers and has applied the step          */
+sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, float* out_loss) {
+    if (!models || n == 0) return SBR_ERR_INVALID_ARGUMENT;
+    for (uint32_t r = 0; r < n; ++r) {
+        const sbr_model* m = models[r];
+        if (!m || m->hp.num_devices != n || m->hp.device_rank != r || m->hp.num_epochs != models[0]->hp.num_epochs)
+            return SBR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 1) return sbr_model_fit(models[0], user_ptr, item_ids, num_users, out_loss);
+
+    struct Dev {
+        sbr_fit_plan* plan = nullptr;
+        uint8_t *send = nullptr, *dense = nullptr, *recv = nullptr, *own = nullptr, *table = nullptr, *dense_all = nullptr;
+        hipEvent_t scattered = nullptr, reduced = nullptr, applied = nullptr;
+    };
+    std::vector<Dev> dev(n);
+    uint64_t chunk = 0, db = 0;
+    auto cleanup = [&]() {
+        for (uint32_t r = 0; r < n; ++r) {
+            hipSetDevice(models[r]->device);
+            hipStreamSynchronize(models[r]->stream);
+        }
+        for (uint32_t r = 0; r < n; ++r) {
+            Dev& v = dev[r];
+            hipSetDevice(models[r]->device);
+            hipFree(v.send); hipFree(v.dense); hipFree(v.recv); hipFree(v.own); hipFree(v.table); hipFree(v.dense_all);
+            if (v.scattered) hipEventDestroy(v.scattered);
+            if (v.reduced) hipEventDestroy(v.reduced);
+            if (v.applied) hipEventDestroy(v.applied);
+            if (v.plan) sbr_fit_plan_destroy(v.plan);
+        }
+    };
+    auto run = [&]() -> sbr_status {
+        for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_begin(models[r], user_ptr, item_ids, num_users, &dev[r].plan));
+        SBRCHK(sbr_fit_chunk_bytes(dev[0].plan, &chunk));
+        SBRCHK(sbr_fit_dense_bytes(dev[0].plan, &db));
+        for (uint32_t r = 0; r < n; ++r) {
+            Dev& v = dev[r];
+            SBRCHK(ensure_device(models[r]));
+            for (uint32_t q = 0; q < n; ++q)
+                if (models[q]->device != models[r]->device) {
+                    int can = 0;
+                    if (hipDeviceCanAccessPeer(&can, models[r]->device, models[q]->device) == hipSuccess && can)
+                        (void)hipDeviceEnablePeerAccess(models[q]->device, 0); /* already-enabled is fine */
+                }
+            (void)hipGetLastError();
+            SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.recv, n * chunk));
+            SBRCHK(dmalloc(&v.own, chunk)); SBRCHK(dmalloc(&v.table, n * chunk)); SBRCHK(dmalloc(&v.dense_all, n * db));
+            HIPCHK(hipEventCreateWithFlags(&v.scattered, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&v.reduced, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&v.applied, hipEventDisableTiming));
+        }
+        const uint32_t epochs = models[0]->hp.num_epochs;
+        bool first = true;
+        for (uint32_t e = 0; e < epochs; ++e) {
+            uint64_t nmb = 0;
+            for (uint32_t r = 0; r < n; ++r) {
+                uint64_t k = 0;
+                SBRCHK(sbr_fit_epoch_prepare(dev[r].plan, &k));
+                if (r && k != nmb) return SBR_ERR_INVALID_ARGUMENT;
+                nmb = k;
+                if (e + 1 < epochs) SBRCHK(sbr_fit_epoch_prefetch(dev[r].plan));
+            }
+            for (uint64_t mb = 0; mb < nmb; ++mb) {
+                for (uint32_t r = 0; r < n; ++r) {
+                    SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
+                    if (!first) /* peers must be done reading send_r / dense_r / own_r of the previous step */
+                        for (uint32_t q = 0; q < n; ++q)
+                            if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
+                    SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send, dev[r].dense));
+                    HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
+                }
+                for (uint32_t p = 0; p < n; ++p) { /* all-to-all: chunk p of every device -> device p */
+                    SBRCHK(ensure_device(models[p]));
+                    for (uint32_t r = 0; r < n; ++r) {
+                        if (r != p) HIPCHK(hipStreamWaitEvent(models[p]->stream, dev[r].scattered, 0));
+                        HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault,
+                                              models[p]->stream));
+                    }
+                    SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
+                    HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
+                }
+                for (uint32_t q = 0; q < n; ++q) { /* all-gather of the owners' chunks and of the dense blocks */
+                    SBRCHK(ensure_device(models[q]));
+                    for (uint32_t p = 0; p < n; ++p) {
+                        if (p != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[p].reduced, 0));
+                        HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, models[q]->stream));
+                        HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, models[q]->stream));
+                    }
+                    SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+                    HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+                }
+                first = false;
+            }
+        }
+        for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(dev[r].plan, nullptr, nullptr));
+        return sbr_fit_end(dev[0].plan, out_loss, nullptr);
+    };
+    const sbr_status st = run();
+    cleanup();
+    return st;
+}
+
+sbr_status sbr_device_count(int32_t* out_count) {
+    if (!out_count) return SBR_ERR_INVALID_ARGUMENT;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
+    *out_count = nd;
+    return SBR_OK;
+}
+
 sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, uint64_t bytes) {
     if (!p || !host_out || !p->last_block) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;

@@ -38,6 +38,24 @@ def set_device(ordinal: int):
     _check(_lib.load().sbr_set_device(int(ordinal)))
 
 
+def device_count() -> int:
+    n = C.c_int32()
+    _check(_lib.load().sbr_device_count(C.byref(n)))
+    return n.value
+
+
+def group_fit(models, user_ptr, item_ids) -> float:
+    """Single-process multi-device fit (sbr_group_fit): models[r] built with num_devices = len(models),
+    device_rank = r and the same seed.  ≙ fit with num_threads(n) in one process."""
+    L = _lib.load()
+    up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+    it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+    handles = (C.c_void_p * len(models))(*[m._h for m in models])
+    loss = C.c_float()
+    _check(L.sbr_group_fit(handles, len(models), _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
+    return loss.value
+
+
 _DBG_U32 = {1, 7, 8, 9}
 
 

@@ -139,11 +139,41 @@ class _ImplicitSequenceModel:
     def fit(self, interactions: CompressedInteractions) -> float:
         """Fit the model; returns the loss value.  Raises FittingError.NoInteractions
         (lstm.rs:395-397 → sequence_model.rs:86-88)."""
-        if int(self.params.hp.num_devices) != 1:
+        world = int(self.params.hp.num_devices)
+        if world == 1:
+            return self.params.fit(interactions.user_pointers, interactions.item_ids)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            # one process per GPU (torchrun): this process drives replica hp.device_rank
             from .distributed import fit_distributed
 
             return fit_distributed(self.params, interactions)
-        return self.params.fit(interactions.user_pointers, interactions.item_ids)
+        # one process, num_threads replicas (≙ the reference's rayon workers): sbr_group_fit
+        from .engine import group_fit
+
+        return group_fit(self._replicas(), interactions.user_pointers, interactions.item_ids)
+
+    def _replicas(self):
+        """Replica r of a single-process multi-device model lives on HIP device r mod device_count;
+        the peers are created at the first fit, from the same seed as the primary."""
+        if getattr(self, "_peers", None) is None:
+            import copy
+
+            from .engine import device_count, set_device
+
+            if int(self.params.hp.device_rank) != 0 or self.params.counters() != (0, 0):
+                raise RuntimeError("single-process multi-device fit needs the untrained rank-0 model")
+            ndev = device_count()
+            peers = []
+            for r in range(1, int(self.params.hp.num_devices)):
+                hp = copy.copy(self.params.hp)
+                hp.device_rank = r
+                set_device(r % ndev)
+                peers.append(Model(hp))
+            set_device(0)
+            self._peers = peers
+        return [self.params] + self._peers
 
     def user_representation(self, item_ids) -> ImplicitUser:
         return ImplicitUser(self.params.user_representation(np.asarray(item_ids, dtype=np.uint32)))

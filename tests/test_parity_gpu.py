@@ -219,6 +219,32 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
         assert lg == pytest.approx(lo, rel=1e-6)
 
 
+@pytest.mark.parametrize("kind,loss,d,world,opt", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 2, 0),
+    (ModelKind.EWMA, LOSS_HINGE, 64, 3, 0),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 4, OPT_ADAM),
+])
+def test_group_fit_single_process(kind, loss, d, world, opt):
+    """sbr_group_fit: `world` replicas driven from ONE process, the exchange as event-ordered peer
+    copies between the replicas' streams (here all on one GPU).  ≙ fit with num_threads(world);
+    must equal the oracle with num_devices = world bit for bit, on every replica, and a second
+    fit call must keep training from the same state on both sides."""
+    from sbr_rs_amd.engine import group_fit
+
+    items, T, B = 211, 12, 5
+    ptr, it = synthetic_interactions(100, items, T + 5, seed=23, zipf=True)
+    mk = lambda q: hparams(items, T, d, int(kind), loss, epochs=3, B=B, ndev=world, rank=q, opt=opt,
+                           lr=0.02 if opt == OPT_ADAM else 0.16)
+    models = [Model(mk(q)) for q in range(world)]
+    o = OracleModel(mk(0))
+    for call in range(2):
+        lg = group_fit(models, ptr, it)
+        lo = o.fit(ptr, it)
+        assert lg == pytest.approx(lo, rel=1e-6)
+        for q in range(world):
+            assert_params_equal(models[q], o, kind, f"group_fit call {call} rank {q} of {world}")
+
+
 ADAM_BLOCKS = {
     ModelKind.EWMA: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.EWMA_ALPHA_M],
     ModelKind.LSTM_NORMAL: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.LSTM_W_M, Param.LSTM_B_M],
@@ -307,6 +333,24 @@ def test_default_hyperparameters_through_the_python_api():
     assert model.predict(user, np.arange(120)).shape == (120,)
     with pytest.raises(sbr.FittingError.NoInteractions):
         sbr.ewma.Hyperparameters.new(120, 16).build().fit(sbr.data.Interactions(10, 120).to_compressed())
+
+
+def test_num_threads_two_through_the_python_api():
+    """`.num_threads(2)` in ONE process (≙ lstm.rs:475-497's configuration): two replicas, group fit;
+    equals the oracle with num_devices = 2."""
+    import sbr_rs_amd as sbr
+
+    ptr, it = synthetic_interactions(70, 150, 18, seed=4, zipf=True)
+    seed = bytes([7] * 16)
+    comp = sbr.data.CompressedInteractions(70, 150, ptr, it, np.zeros(len(it), dtype=np.uint64))
+    model = (sbr.lstm.Hyperparameters.new(150, 16).from_seed(seed).embedding_dim(32).loss(sbr.Loss.Hinge)
+             .optimizer(sbr.Optimizer.Adagrad).lstm_variant(sbr.LSTMVariant.Normal).learning_rate(0.16).l2_penalty(0.0004)
+             .num_epochs(2).num_threads(2).batch_sequences(6).build())
+    lg = model.fit(comp)
+    o = OracleModel(hparams(150, 16, 32, int(ModelKind.LSTM_NORMAL), LOSS_HINGE, epochs=2, B=6, seed=seed, ndev=2))
+    lo = o.fit(ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    assert_params_equal(model.params, o, ModelKind.LSTM_NORMAL, "num_threads(2)")
 
 
 def test_save_load_resumes_training_bit_exactly(tmp_path):

@@ -42,14 +42,21 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measu
 FP32_MFMA_PEAK_TF = 157.3  # dense f32-input MFMA peak
 
 
-def synthetic_csr(num_users: int, num_items: int, max_len: int, seed: int = 42):
-    """BASELINE.md §3 generator: len_u ~ U{3..max_len}, items ~ U[0, num_items) (pure-roofline
-    variant: no cache reuse), timestamps = position."""
+def synthetic_csr(num_users: int, num_items: int, max_len: int, seed: int = 42, zipf: bool = False):
+    """BASELINE.md §3 generator: len_u ~ U{3..max_len}, timestamps = position; items ~ U[0, num_items)
+    (the pure-roofline variant: no cache reuse) or Zipf(1.0) over a random permutation of the
+    catalogue (the realistic variant)."""
     rs = np.random.RandomState(seed)
     lens = rs.randint(3, max_len + 1, size=num_users).astype(np.uint64)
     ptr = np.zeros(num_users + 1, dtype=np.uint64)
     ptr[1:] = np.cumsum(lens)
-    items = rs.randint(0, num_items, size=int(ptr[-1])).astype(np.uint32)
+    nnz = int(ptr[-1])
+    if zipf:
+        cdf = np.cumsum(1.0 / np.arange(1, num_items + 1, dtype=np.float64))
+        ranks = np.searchsorted(cdf, rs.random_sample(nnz) * cdf[-1])
+        items = rs.permutation(num_items)[np.minimum(ranks, num_items - 1)].astype(np.uint32)
+    else:
+        items = rs.randint(0, num_items, size=nnz).astype(np.uint32)
     return ptr, items
 
 
@@ -61,25 +68,66 @@ def make_hp(args, world, rank, model_kind, loss, num_items, epochs=1, batch=None
 
 
 def cpu_baseline(args):
-    """The oracle (kind "port") on a bounded sample: one minibatch worth of users of the same
-    generator, same model/hyper-parameters, one epoch; fit time only."""
+    """The oracle (kind "port") on a bounded sample of the same workload: every worker thread owns a
+    model and one minibatch worth of users of the same generator and runs one epoch of it; fit time
+    only.  Workers are independent (≙ the reference's rayon workers on their own partitions,
+    sequence_model.rs:99-102, without its shared-parameter traffic or rendezvous), so the aggregate
+    is an upper bound for a `cores`-thread CPU run; the single-thread figure is reported beside it."""
+    import threading
+
     from oracle.oracle import OracleModel
 
     users = min(args.cpu_users, args.users)
-    ptr, items = synthetic_csr(users, args.items, args.max_len, seed=43)
-    hp = make_hp(args, 1, 0, 0, 2, args.items, epochs=1, batch=min(args.batch_sequences, users))
-    m = OracleModel(hp)
-    plan = m.fit_begin(ptr, items)
-    nmb = plan.epoch_prepare()
-    rows = sum(plan.minibatch_rows(mb) for mb in range(nmb))
+    workers = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+
+    def prepare(seed):
+        ptr, items = synthetic_csr(users, args.items, args.max_len, seed=seed)
+        hp = make_hp(args, 1, 0, 0, 2, args.items, epochs=1, batch=min(args.batch_sequences, users))
+        m = OracleModel(hp)
+        plan = m.fit_begin(ptr, items)
+        nmb = plan.epoch_prepare()
+        return m, plan, nmb, sum(plan.minibatch_rows(mb) for mb in range(nmb))
+
+    def run(job):
+        _m, plan, nmb, _rows = job
+        for mb in range(nmb):
+            plan.step(mb)  # ctypes releases the GIL for the duration of the C call
+
+    one = prepare(43)
     t0 = time.perf_counter()
-    for mb in range(nmb):
-        plan.step(mb)
-    dt = time.perf_counter() - t0
-    return {"value": rows / dt, "unit": "interactions/s", "cores": 1, "kind": "port",
-            "sample": f"{users} users of the same generator ({rows} interactions, {nmb} minibatch(es)), "
-                      f"LSTM+WARP dim {args.dim}, 1 epoch, single-thread C oracle, {dt:.1f} s",
-            "host_cores_available": os.cpu_count()}
+    run(one)
+    dt1 = time.perf_counter() - t0
+    single = one[3] / dt1
+    out = {"value": single, "unit": "interactions/s", "cores": 1, "kind": "port",
+           "sample": f"{users} users of the same generator ({one[3]} interactions, {one[2]} minibatch(es)), "
+                     f"LSTM+WARP dim {args.dim}, 1 epoch, single-thread C oracle, {dt1:.1f} s",
+           "single_thread_value": single, "host_cores_available": os.cpu_count()}
+    del one
+    if workers > 1:
+        jobs = [None] * workers
+        ready, go = threading.Barrier(workers + 1), threading.Barrier(workers + 1)
+
+        def worker(w):
+            jobs[w] = prepare(100 + w)  # model initialisation also runs outside the GIL
+            ready.wait()
+            go.wait()
+            run(jobs[w])
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(workers)]
+        for t in threads:
+            t.start()
+        ready.wait()
+        t0 = time.perf_counter()
+        go.wait()
+        for t in threads:
+            t.join()
+        dtn = time.perf_counter() - t0
+        rows = sum(j[3] for j in jobs)
+        out.update({"value": rows / dtn, "cores": workers,
+                    "sample": f"{workers} independent worker threads x {users} users of the same generator "
+                              f"({rows} interactions), LSTM+WARP dim {args.dim}, 1 epoch each, C oracle, {dtn:.1f} s wall "
+                              f"(single thread: {single:.0f} interactions/s)"})
+    return out
 
 
 def movielens_mrr():
@@ -110,9 +158,12 @@ def main():
     ap.add_argument("--items", type=int, default=1_000_000)
     ap.add_argument("--max-len", type=int, default=64)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--batch-sequences", type=int, default=16384)
+    ap.add_argument("--batch-sequences", type=int, default=32768, help="subsequences per optimiser step and GPU")
+    ap.add_argument("--item-distribution", choices=["uniform", "zipf"], default="uniform",
+                    help="uniform = the pure-roofline run (no cache reuse); zipf = Zipf(1.0) over a permuted catalogue")
     ap.add_argument("--model", choices=["lstm", "lstm-coupled", "ewma"], default="lstm")
     ap.add_argument("--loss", choices=["bpr", "hinge", "warp"], default="warp")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="worker threads of the CPU baseline (capped at the host's cores)")
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
@@ -141,12 +192,15 @@ def main():
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
+        if world == 1:  # --force-exchange without a launcher
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     model_kind = {"lstm": 0, "lstm-coupled": 1, "ewma": 2}[args.model]
     loss_kind = {"bpr": 0, "hinge": 1, "warp": 2}[args.loss]
     total_users = args.users * world
-    ptr, items = synthetic_csr(total_users, args.items, args.max_len)
+    ptr, items = synthetic_csr(total_users, args.items, args.max_len, zipf=args.item_distribution == "zipf")
     hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
     model = engine.Model(hp)
     exchange = world > 1 or args.force_exchange
@@ -227,14 +281,15 @@ def main():
             bytes_per_row = (2 + k_mean) * 4 * d + (1 + k_mean) * 4
             bytes_per_launch = bytes_per_row * rows_per_launch
             achieved = bytes_per_launch / (score["ms_per_launch"] * 1e-3) / 1e9
-            # HBM bytes per launch from the rocprofv3 PMC passes of this round (FETCH_SIZE and WRITE_SIZE in
-            # separate runs, gfx950 half-count correction applied; profiles/score_kernel_pmc.json), scaled
-            # from bytes per packed row to this run's rows per launch
+            # HBM bytes per launch from the rocprofv3 PMC passes of the default bench command (FETCH_SIZE and
+            # WRITE_SIZE in separate runs, gfx950 half-count correction applied; profiles/score_kernel_pmc.json);
+            # for a different batch or k it is scaled by this run's algorithmic bytes over the profiled run's
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
             if os.path.exists(pmc) and d == 128:
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_row") * rows_per_launch
+                    prof = json.load(open(pmc))
+                    traffic = prof["hbm_bytes_per_launch"] * bytes_per_launch / prof["profiled_run"]["algorithmic_bytes_per_launch"]
                 except Exception:
                     traffic = None
             roofline = {"kernel": "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)", "bound": "hbm",
@@ -259,7 +314,7 @@ def main():
             "config": {"workload": f"BASELINE.json configs[2]: synthetic {args.users} users/GPU x {args.items} items, "
                                    f"seq_len<={args.max_len}, dim {args.dim}, {args.model}+{args.loss}, Adagrad lr 0.16 l2 4e-4",
                        "users_per_gpu": args.users, "items": args.items, "max_len": args.max_len, "dim": args.dim,
-                       "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": "uniform",
+                       "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": args.item_distribution,
                        "parallelism": f"user-sharded dp{world}" if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],

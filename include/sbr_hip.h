@@ -145,8 +145,10 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch);
  * Parallelism::Synchronous, sequence_model.rs:163-166).  Table rows are owned in contiguous slices
  * of ceil(num_items / num_devices) rows.  Per step, after sbr_fit_step_local:
  *   scatter      : own entries reduced per row into num_devices dense chunks (send buffer, one chunk
- *                  per owner; chunk = [G: S*dim f32][gb: S f32][flags: S u32]) + the small dense block
- *                  [8-word header | dense grads]                       -> host: all-to-all of the chunks
+ *                  per owner; chunk = [G: S*dim f32][gb: S f32][flags: S u32])
+ *                                                                     -> host: all-to-all of the chunks
+ *   dense        : the small dense block [8-word header | dense grads]; call it after the all-to-all
+ *                  has been queued: it waits for the dense-gradient GEMM, which then overlaps the transfer
  *   owner_reduce : the devices' contributions for the owned slice, added in device order -> one chunk
  *                                                                     -> host: all-gather of the chunks
  *                                                                        and of the dense blocks
@@ -154,7 +156,8 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch);
  * All pointers are device pointers supplied by the host (torch tensors in sbr_rs_amd/distributed.py). */
 sbr_status sbr_fit_chunk_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
 sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
-sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send, void* device_dense_out);
+sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send);
+sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out);
 sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk);
 sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all);
 

@@ -64,7 +64,7 @@ class KernelFamily(enum.IntEnum):
 
 
 NUM_KERNEL_FAMILIES = 7
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SbrHparams(C.Structure):

@@ -326,7 +326,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 1; }
+uint32_t sbr_abi_version(void) { return 2; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -375,7 +375,11 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return SBR_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     m->own_stream = true;
-    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+    /* the side stream carries the MFMA-bound dense-gradient GEMM beside the HBM-bound sparse update:
+     * lowest priority, so the update's workgroups are placed first whenever a slot frees up */
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     sbr::ModelView& v = m->mv;
@@ -824,7 +828,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const sbr::BlockView bv = block_view(m, block, p->rmax);
     const int* off_host = ep.off_host.data() + mb.off_base;
     {
-        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng ? (uint64_t)mb.Tm : 1);
+        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
         sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
     }
     {
@@ -833,7 +837,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     }
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
     {
-        ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng ? (uint64_t)mb.Tm : 1);
+        ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }
     /* the dense-gradient GEMM (MFMA-bound, reads dZ / X / H only) goes to the side stream so that the
@@ -897,8 +901,8 @@ sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
     return SBR_OK;
 }
 
-sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send, void* device_dense_out) {
-    if (!p || !device_send || !device_dense_out || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send) {
+    if (!p || !device_send || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
@@ -908,8 +912,18 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
         sbr::launch_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys, p->keys_sorted, p->sort_temp,
                             p->sort_temp_bytes, p->key_bits, m->stream);
     }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* small dense block = [8-word header | dense grads]; joins the side stream's dense-gradient GEMM, so
+ * calling it late (after the chunk all-to-all has been queued) lets that GEMM overlap the transfer */
+sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out) {
+    if (!p || !device_dense_out) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     SBRCHK(join_dense(p));
-    /* small dense block = [8-word header | dense grads] */
     HIPCHK(hipMemcpyAsync(device_dense_out, bv.header, 32, hipMemcpyDeviceToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(device_dense_out) + 32, bv.dense, dense_count(m) * 4,
                           hipMemcpyDeviceToDevice, m->stream));
@@ -997,8 +1011,8 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
  * (sequence_model.rs:90-102, 163-169).  One host thread drives n replicas, each on its own HIP
  * device and stream; the owner-reduce exchange of sbr_fit_step_scatter / _owner_reduce /
  * _apply_table is carried by peer copies (xGMI when the devices are peers) ordered with events:
- *   scattered[r]  send_r / dense_r of this step are complete
- *   reduced[p]    own_p of this step is complete
+ *   scattered[r]  send_r of this step is complete
+ *   reduced[p]    own_p and dense_p of this step are complete
  *   applied[q]    q has finished reading its peers' buffers and has applied the step          */
 sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
                          uint64_t num_users, float* out_loss) {
@@ -1069,7 +1083,7 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                     if (!first) /* peers must be done reading send_r / dense_r / own_r of the previous step */
                         for (uint32_t q = 0; q < n; ++q)
                             if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
-                    SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send, dev[r].dense));
+                    SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
                     HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
                 }
                 for (uint32_t p = 0; p < n; ++p) { /* all-to-all: chunk p of every device -> device p */
@@ -1080,6 +1094,7 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                                               models[p]->stream));
                     }
                     SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
+                    SBRCHK(sbr_fit_step_dense(dev[p].plan, dev[p].dense));
                     HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
                 }
                 for (uint32_t q = 0; q < n; ++q) { /* all-gather of the owners' chunks and of the dense blocks */
@@ -1176,7 +1191,7 @@ sbr_status forward_histories(sbr_model* m, const std::vector<const uint32_t*>& f
     mv.off = dp.off; mv.steps = dp.steps; mv.prev_row = dp.prev_row;
     mv.in_idx = dp.in_idx; mv.out_idx = dp.out_idx; mv.ctr = dp.ctr;
     {
-        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng ? (uint64_t)pk.Tm : 1);
+        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)pk.Tm : 1);
         sbr::launch_recurrent_forward(m->mv, mv, H, wb.v, pk.Tm, pk.off.data(), m->stream);
     }
     hipError_t e = hipStreamSynchronize(m->stream);

@@ -38,7 +38,8 @@ class StepBackend(Protocol):
     def epoch_prepare(self, prefetch_next: bool = False) -> int: ...
     def compute_local(self, minibatch: int) -> None: ...
     def apply_single(self, minibatch: int) -> None: ...            # world == 1
-    def scatter(self, minibatch: int): ...                         # -> (send [world*chunk], dense [dense_bytes])
+    def scatter(self, minibatch: int): ...                         # -> send [world*chunk]
+    def dense(self): ...                                           # -> dense block [dense_bytes]
     def owner_reduce(self, recv): ...                              # -> own chunk [chunk]
     def apply_table(self, table, dense_all) -> None: ...
     def buffers(self, world: int): ...                             # -> (recv, table, dense_all)
@@ -50,11 +51,33 @@ def exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=
     import torch.distributed as dist
 
     recv, table, dense_all = bufs
-    send, dense = backend.scatter(minibatch)
+    send = backend.scatter(minibatch)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device collectives: stage through host memory.  This is the transport for hosts
+        # without RCCL peers (two ranks sharing one GPU in tests/test_distributed_gpu.py); "nccl" is
+        # the production transport and keeps everything on the device.
+        _staged_exchange(backend, dist, group, send, recv, table, dense_all)
+        return
     dist.all_to_all_single(recv, send, group=group)
     own = backend.owner_reduce(recv)
+    dense = backend.dense()  # joins the dense-gradient GEMM, which ran beside the all-to-all
     dist.all_gather_into_tensor(table, own, group=group)
     dist.all_gather_into_tensor(dense_all, dense, group=group)
+    backend.apply_table(table, dense_all)
+
+
+def _staged_exchange(backend, dist, group, send, recv, table, dense_all) -> None:
+    import torch
+
+    world = dist.get_world_size(group)
+    h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+    dist.all_to_all_single(h_recv, send.cpu(), group=group)
+    recv.copy_(h_recv)
+    own = backend.owner_reduce(recv)
+    for dst, src in ((table, own), (dense_all, backend.dense())):
+        parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+        dist.all_gather(parts, src.cpu(), group=group)
+        dst.copy_(torch.cat(parts))
     backend.apply_table(table, dense_all)
 
 
@@ -94,7 +117,7 @@ class HipBackend:
             self.chunk = self.plan.chunk_bytes()
             self.dense_bytes = self.plan.dense_bytes()
             self.send = torch.zeros(world * self.chunk, dtype=torch.uint8, device="cuda")
-            self.dense = torch.zeros(self.dense_bytes, dtype=torch.uint8, device="cuda")
+            self._dense = torch.zeros(self.dense_bytes, dtype=torch.uint8, device="cuda")
             self.own = torch.zeros(self.chunk, dtype=torch.uint8, device="cuda")
 
     def epoch_prepare(self, prefetch_next: bool = False) -> int:
@@ -110,8 +133,12 @@ class HipBackend:
         self.plan.step_apply(minibatch)
 
     def scatter(self, minibatch: int):
-        self.plan.step_scatter(minibatch, self.send.data_ptr(), self.dense.data_ptr())
-        return self.send, self.dense
+        self.plan.step_scatter(minibatch, self.send.data_ptr())
+        return self.send
+
+    def dense(self):
+        self.plan.step_dense(self._dense.data_ptr())
+        return self._dense
 
     def owner_reduce(self, recv):
         self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr())

@@ -102,8 +102,11 @@ class FitPlan:
         _check(self._L.sbr_fit_dense_bytes(self._h, C.byref(n)))
         return n.value
 
-    def step_scatter(self, mb: int, send_ptr: int, dense_ptr: int):
-        _check(self._L.sbr_fit_step_scatter(self._h, mb, C.c_void_p(send_ptr), C.c_void_p(dense_ptr)))
+    def step_scatter(self, mb: int, send_ptr: int):
+        _check(self._L.sbr_fit_step_scatter(self._h, mb, C.c_void_p(send_ptr)))
+
+    def step_dense(self, dense_ptr: int):
+        _check(self._L.sbr_fit_step_dense(self._h, C.c_void_p(dense_ptr)))
 
     def step_owner_reduce(self, recv_ptr: int, own_ptr: int):
         _check(self._L.sbr_fit_step_owner_reduce(self._h, C.c_void_p(recv_ptr), C.c_void_p(own_ptr)))

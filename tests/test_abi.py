@@ -31,7 +31,9 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.DECLARED_SYMBOLS) == declared, "loader table and header disagree"
     for name in declared:
         assert hasattr(L, name), name
-    assert L.sbr_abi_version() == 1
+    from sbr_rs_amd._abi import ABI_VERSION
+
+    assert L.sbr_abi_version() == ABI_VERSION
     assert b"No interactions" in L.sbr_status_string(int(Status.NO_INTERACTIONS))
 
 

@@ -35,8 +35,10 @@ class OracleBackend:
         self.plan.step_apply(self.plan.step_local(mb, device=0))
 
     def scatter(self, mb):
-        return (torch.from_numpy(self.plan.scatter(self.rank, self.world)),
-                torch.from_numpy(self.plan.export_dense(self.rank)))
+        return torch.from_numpy(self.plan.scatter(self.rank, self.world))
+
+    def dense(self):
+        return torch.from_numpy(self.plan.export_dense(self.rank))
 
     def owner_reduce(self, recv):
         return torch.from_numpy(self.plan.owner_reduce(recv.numpy()))

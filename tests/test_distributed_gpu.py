@@ -1,0 +1,73 @@
+"""Two PROCESSES driving the HIP engine through sbr_rs_amd.distributed (the code path `torchrun`
+takes for --gpus N): rendezvous, rank -> replica mapping, per-rank HipBackend, the owner-reduce
+exchange and fit_distributed.  A gpurun box has one GPU and RCCL refuses two ranks on one device, so
+both ranks share cuda:0 and the collectives travel over gloo with host staging
+(distributed._staged_exchange); every kernel and every C-ABI call is the production one.  Each
+replica must end bit-identical to the oracle emulating both devices."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import LOSS_HINGE, LOSS_WARP, hparams, synthetic_interactions
+from sbr_rs_amd._abi import ModelKind, Param
+
+PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.EWMA_ALPHA],
+          0: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B]}
+CASE = dict(users=70, items=157, T=12, B=5, d=32, epochs=2, seed=9)
+
+
+def _worker(rank, world, port, kind, loss, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sbr_rs_amd as sbr
+        from sbr_rs_amd._abi import ModelKind as MK
+
+        c = CASE
+        ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
+        comp = sbr.data.CompressedInteractions(c["users"], c["items"], ptr, items, np.zeros(len(items), dtype=np.uint64))
+        if kind == int(MK.EWMA):
+            h = sbr.ewma.Hyperparameters.new(c["items"], c["T"])
+        else:
+            h = sbr.lstm.Hyperparameters.new(c["items"], c["T"]).lstm_variant(sbr.LSTMVariant.Normal)
+        model = (h.from_seed(bytes([42] * 16)).embedding_dim(c["d"]).learning_rate(0.16).l2_penalty(0.0004)
+                 .loss(sbr.Loss(loss)).optimizer(sbr.Optimizer.Adagrad).num_epochs(c["epochs"]).num_threads(world)
+                 .batch_sequences(c["B"]).build(device_rank=rank))
+        loss_v = model.fit(comp)  # -> fit_distributed: a process group is initialised
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v,
+                 **{p.name: model.params.get_param(p) for p in PARAMS[kind]})
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,loss", [(int(ModelKind.LSTM_NORMAL), LOSS_WARP), (int(ModelKind.EWMA), LOSS_HINGE)])
+def test_two_processes_share_one_gpu(tmp_path, oracle_lib, kind, loss):
+    import torch.multiprocessing as mp
+
+    from oracle.oracle import OracleModel
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, str(tmp_path)), nprocs=world, join=True)
+    c = CASE
+    ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
+    ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world))
+    ref_loss = ref.fit(ptr, items)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for p in PARAMS[kind]:
+            assert np.array_equal(z[p.name].view(np.uint32), ref.get_param(p).view(np.uint32)), f"rank {r}: {p.name}"
+        assert float(z["loss"]) == pytest.approx(ref_loss, rel=1e-6)

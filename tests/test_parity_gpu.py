@@ -197,7 +197,8 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
         for mb in range(nmb.pop()):
             for q in range(world):
                 plans[q].step_local(mb)
-                plans[q].step_scatter(mb, send[q].data_ptr(), dense[q].data_ptr())
+                plans[q].step_scatter(mb, send[q].data_ptr())
+                plans[q].step_dense(dense[q].data_ptr())
                 models[q].synchronize()
             for q in range(world):  # all_to_all_single
                 for src in range(world):
@@ -293,7 +294,8 @@ def test_adam_multi_device_halves(kind=ModelKind.LSTM_COUPLED):
     for mb in range(nmb):
         for q in range(world):
             plans[q].step_local(mb)
-            plans[q].step_scatter(mb, send[q].data_ptr(), dense[q].data_ptr())
+            plans[q].step_scatter(mb, send[q].data_ptr())
+            plans[q].step_dense(dense[q].data_ptr())
             models[q].synchronize()
         for q in range(world):
             for src in range(world):

@@ -63,7 +63,8 @@ def synthetic_csr(num_users: int, num_items: int, max_len: int, seed: int = 42, 
 def make_hp(args, world, rank, model_kind, loss, num_items, epochs=1, batch=None, dim=None, max_len=None):
     from sbr_rs_amd._abi import make_hparams
 
-    return make_hparams(num_items, max_len or args.max_len, dim or args.dim, 0.16, 0.0004, model_kind, loss, 0, 1,
+    par = 0 if getattr(args, "parallelism", "sync") == "async" else 1
+    return make_hparams(num_items, max_len or args.max_len, dim or args.dim, 0.16, 0.0004, model_kind, loss, 0, par,
                         bytes([42] * 16), epochs, world, rank, batch or args.batch_sequences)
 
 
@@ -163,6 +164,9 @@ def main():
                     help="uniform = the pure-roofline run (no cache reuse); zipf = Zipf(1.0) over a permuted catalogue")
     ap.add_argument("--model", choices=["lstm", "lstm-coupled", "ewma"], default="lstm")
     ap.add_argument("--loss", choices=["bpr", "hinge", "warp"], default="warp")
+    ap.add_argument("--parallelism", choices=["sync", "async"], default="sync",
+                    help="multi-GPU step: sync = Parallelism::Synchronous (the reference default); async = the "
+                         "staleness-one pipeline (Parallelism::Asynchronous): compute k+1 under the exchange of step k")
     ap.add_argument("--cpu-threads", type=int, default=16, help="worker threads of the CPU baseline (capped at the host's cores)")
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,7 +189,7 @@ def main():
     torch.cuda.set_device(local_rank)
     from sbr_rs_amd import engine
     from sbr_rs_amd._abi import Debug
-    from sbr_rs_amd.distributed import HipBackend, exchange_step
+    from sbr_rs_amd.distributed import HipBackend, StepLoop
 
     engine.set_device(local_rank)
     dist = None
@@ -203,30 +207,30 @@ def main():
     ptr, items = synthetic_csr(total_users, args.items, args.max_len, zipf=args.item_distribution == "zipf")
     hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
     model = engine.Model(hp)
-    exchange = world > 1 or args.force_exchange
     backend = HipBackend(model, (ptr, items), world if not args.force_exchange else max(world, 2))
     plan = backend.plan
     if args.force_exchange and world == 1:  # one rank owns the whole table: a single chunk
         backend.send = backend.send[:backend.chunk]
-    bufs = backend.buffers(world) if exchange else None
+    # the production step sequencing (sbr_rs_amd/distributed.py); --force-exchange runs the collectives at world 1
+    loop = StepLoop(backend, world if not args.force_exchange else max(world, 2), asynchronous=args.parallelism == "async")
+    if args.force_exchange and world == 1:
+        loop.world = 2  # take the exchange branch; the process group itself has a single rank
+        c, db = backend.chunk, backend.dense_bytes
+        loop.bufs = tuple(torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (c, c, db))
 
     tp0 = time.perf_counter()
-    state = {"nmb": backend.epoch_prepare(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0}
+    state = {"nmb": loop.begin_epoch(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0}
     epoch_prepare_ms = 1e3 * (time.perf_counter() - tp0)
 
     def one_step(timed: bool) -> int:
         if state["mb"] >= state["nmb"]:
-            state["nmb"] = backend.epoch_prepare(prefetch_next=True)  # epoch switch; the host packed it in the background
+            state["nmb"] = loop.begin_epoch(prefetch_next=True)  # epoch switch; the host packed it in the background
             state["mb"] = 0
             if timed:
                 state["reprepared_in_timed_region"] += 1
         mb = state["mb"]
         rows = plan.minibatch_rows(mb)
-        backend.compute_local(mb)
-        if exchange:
-            exchange_step(backend, mb, world, bufs)  # scatter, all-to-all, owner reduce, all-gather, apply
-        else:
-            backend.apply_single(mb)
+        loop.step(mb)  # compute_local + (exchange: scatter, all-to-all, owner reduce, all-gather) + apply
         state["mb"] += 1
         return rows
 
@@ -315,7 +319,8 @@ def main():
                                    f"seq_len<={args.max_len}, dim {args.dim}, {args.model}+{args.loss}, Adagrad lr 0.16 l2 4e-4",
                        "users_per_gpu": args.users, "items": args.items, "max_len": args.max_len, "dim": args.dim,
                        "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": args.item_distribution,
-                       "parallelism": f"user-sharded dp{world}" if world > 1 else "single device"},
+                       "parallelism": (f"user-sharded dp{world}, {'staleness-one pipelined (Asynchronous)' if args.parallelism == 'async' else 'synchronous'} "
+                                       "owner-reduce exchange over RCCL") if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
@@ -327,10 +332,17 @@ def main():
                 out["test_mrr"] = movielens_mrr()
             except Exception as e:  # the throughput line must survive a fixture problem
                 out["test_mrr"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     backend.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio, which is flushed at exit when stdout is a pipe:
+        # flush it now so that the JSON line is the last line of stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -64,6 +64,7 @@ def lib():
         L.orc_fit_owner_reduce.argtypes = [vp, vp, vp]
         L.orc_fit_apply_table.argtypes = [vp, vp, vp]
         L.orc_fit_step.argtypes = [vp, C.c_uint64]
+        L.orc_fit_epoch_async.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
         L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
         L.orc_model_fit.argtypes = [vp, vp, vp, C.c_uint64, fp]

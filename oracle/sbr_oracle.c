@@ -891,6 +891,39 @@ int orc_fit_step(orc_plan* p, uint64_t mb) {
     return st;
 }
 
+/* Parallelism::Asynchronous (mod.rs:36-38) with more than one device.  The reference's Hogwild
+ * workers read parameters their peers are still updating, so their gradients are stale by an
+ * unpredictable amount.  The engine's deterministic analogue fixes the staleness at exactly one
+ * step: every device computes minibatch k+1 on parameters that lack update k, which lets the
+ * exchange of step k run underneath that computation.  One epoch, all devices emulated here;
+ * with a single device there is nobody to be asynchronous with and the step is the synchronous one. */
+int orc_fit_epoch_async(orc_plan* p, uint64_t nmb) {
+    int n = p->ndev;
+    if (n < 2 || nmb == 0) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t cb = orc_fit_chunk_bytes(p), db = orc_fit_dense_bytes(p);
+    char* send = (char*)malloc((size_t)n * n * cb);
+    char* recv = (char*)malloc((size_t)n * cb);
+    char* all = (char*)malloc((size_t)n * cb);
+    char* dense = (char*)malloc((size_t)n * db);
+    int st = SBR_OK;
+    for (int q = 0; q < n; ++q) orc_fit_step_local(p, q, 0);
+    for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) {
+        for (int q = 0; q < n; ++q) {
+            orc_fit_scatter(p, q, send + (size_t)q * n * cb);
+            orc_fit_export_dense(p, q, dense + (size_t)q * db);
+        }
+        if (mb + 1 < nmb)
+            for (int q = 0; q < n; ++q) orc_fit_step_local(p, q, mb + 1); /* before update mb lands */
+        for (int owner = 0; owner < n; ++owner) {
+            for (int q = 0; q < n; ++q) memcpy(recv + (size_t)q * cb, send + ((size_t)q * n + owner) * cb, cb);
+            orc_fit_owner_reduce(p, recv, all + (size_t)owner * cb);
+        }
+        st = orc_fit_apply_table(p, all, dense);
+    }
+    free(send); free(recv); free(all); free(dense);
+    return st;
+}
+
 int orc_fit_end(orc_plan* p, float* out_loss, uint64_t* out_examples) {
     /* ≙ loss_value / (1.0 + examples) (sequence_model.rs:173).  The reference reads a stale node
      * value (:157 before :160); the engine reports the true summed loss. */
@@ -930,7 +963,8 @@ int orc_model_fit(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
     for (uint32_t e = 0; e < m->hp.num_epochs; ++e) {
         uint64_t nmb = 0;
         orc_fit_epoch_prepare(p, &nmb);
-        for (uint64_t mb = 0; mb < nmb; ++mb) orc_fit_step(p, mb);
+        if (p->ndev > 1 && m->hp.parallelism == SBR_PAR_ASYNCHRONOUS) orc_fit_epoch_async(p, nmb);
+        else for (uint64_t mb = 0; mb < nmb; ++mb) orc_fit_step(p, mb);
     }
     orc_fit_end(p, out_loss, NULL);
     orc_fit_plan_destroy(p);

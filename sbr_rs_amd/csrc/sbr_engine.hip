@@ -84,7 +84,7 @@ struct sbr_model {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scored = nullptr, ev_sorted = nullptr;
     std::mutex mu;
     bool timing = false;
     std::vector<TimingPair> pending;
@@ -381,7 +381,9 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) { delete m; return SBR_ERR_HIP; }
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_scored, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_sorted, hipEventDisableTiming) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     sbr::ModelView& v = m->mv;
     std::memset(&v, 0, sizeof(v));
     v.d = m->d; v.ng = m->ng; v.coupled = m->ng == 3;
@@ -465,6 +467,8 @@ void sbr_model_destroy(sbr_model* m) {
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
+    if (m->ev_scored) hipEventDestroy(m->ev_scored);
+    if (m->ev_sorted) hipEventDestroy(m->ev_sorted);
     delete m;
 }
 
@@ -836,6 +840,19 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch), mb.R, m->stream);
     }
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
+    /* the sort of the sparse-update keys needs only the index arrays and the sampled negatives: it runs
+     * on the side stream underneath the backward pass (joined by step_apply / step_scatter) */
+    HIPCHK(hipEventRecord(m->ev_scored, m->stream));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_scored, 0));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1, m->side);
+        if (p->ndev == 1)
+            sbr::launch_sparse_sort(m->mv, p->block, p->block_bytes, 1, p->rmax, ep.rows_of_dev.data() + minibatch, p->keys,
+                                    p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
+        else
+            sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
+    }
+    HIPCHK(hipEventRecord(m->ev_sorted, m->side));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
@@ -867,8 +884,9 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_sparse_apply(m->mv, all, p->block_bytes, 1, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch,
-                                 p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->stream);
+        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        sbr::launch_sparse_apply_sorted(m->mv, all, p->block_bytes, 1, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch,
+                                        p->keys_sorted, m->stream);
     }
     SBRCHK(join_dense(p));
     {
@@ -909,8 +927,8 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys, p->keys_sorted, p->sort_temp,
-                            p->sort_temp_bytes, p->key_bits, m->stream);
+        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        sbr::launch_scatter_sorted(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys_sorted, m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1027,8 +1045,10 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
     struct Dev {
         sbr_fit_plan* plan = nullptr;
         uint8_t *send = nullptr, *dense = nullptr, *recv = nullptr, *own = nullptr, *table = nullptr, *dense_all = nullptr;
-        hipEvent_t scattered = nullptr, reduced = nullptr, applied = nullptr;
+        hipEvent_t scattered = nullptr, reduced = nullptr, applied = nullptr, gathered = nullptr;
+        hipStream_t xs = nullptr; /* exchange stream (Asynchronous) */
     };
+    const bool async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS;
     std::vector<Dev> dev(n);
     uint64_t chunk = 0, db = 0;
     auto cleanup = [&]() {
@@ -1043,8 +1063,91 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             if (v.scattered) hipEventDestroy(v.scattered);
             if (v.reduced) hipEventDestroy(v.reduced);
             if (v.applied) hipEventDestroy(v.applied);
+            if (v.gathered) hipEventDestroy(v.gathered);
+            if (v.xs) { hipStreamSynchronize(v.xs); hipStreamDestroy(v.xs); }
             if (v.plan) sbr_fit_plan_destroy(v.plan);
         }
+    };
+    bool first = true;
+    /* Parallelism::Synchronous: compute, exchange, apply — every device sees every update before its next minibatch */
+    auto sync_step = [&](uint64_t mb) -> sbr_status {
+        for (uint32_t r = 0; r < n; ++r) {
+            SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
+            if (!first) /* peers must be done reading send_r / dense_r / own_r of the previous step */
+                for (uint32_t q = 0; q < n; ++q)
+                    if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
+            SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
+            HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
+        }
+        for (uint32_t p = 0; p < n; ++p) { /* all-to-all: chunk p of every device -> device p */
+            SBRCHK(ensure_device(models[p]));
+            for (uint32_t r = 0; r < n; ++r) {
+                if (r != p) HIPCHK(hipStreamWaitEvent(models[p]->stream, dev[r].scattered, 0));
+                HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault,
+                                      models[p]->stream));
+            }
+            SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
+            SBRCHK(sbr_fit_step_dense(dev[p].plan, dev[p].dense));
+            HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
+        }
+        for (uint32_t q = 0; q < n; ++q) { /* all-gather of the owners' chunks and of the dense blocks */
+            SBRCHK(ensure_device(models[q]));
+            for (uint32_t p = 0; p < n; ++p) {
+                if (p != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[p].reduced, 0));
+                HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, models[q]->stream));
+                HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, models[q]->stream));
+            }
+            SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+            HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+        }
+        first = false;
+        return SBR_OK;
+    };
+    /* Parallelism::Asynchronous (mod.rs:36-38), the deterministic analogue of Hogwild: staleness is
+     * fixed at one step.  Device r computes minibatch mb+1 on its compute stream while the exchange of
+     * step mb (peer copies + owner reduce) runs on its exchange stream; update mb is applied after
+     * that computation has read the parameters. */
+    auto async_epoch = [&](uint64_t nmb) -> sbr_status {
+        for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_step_local(dev[r].plan, 0));
+        for (uint64_t mb = 0; mb < nmb; ++mb) {
+            for (uint32_t r = 0; r < n; ++r) {
+                if (!first)
+                    for (uint32_t q = 0; q < n; ++q)
+                        if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
+                SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
+                SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
+                HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
+            }
+            if (mb + 1 < nmb)
+                for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_step_local(dev[r].plan, mb + 1));
+            for (uint32_t p = 0; p < n; ++p) {
+                SBRCHK(ensure_device(models[p]));
+                for (uint32_t r = 0; r < n; ++r) {
+                    HIPCHK(hipStreamWaitEvent(dev[p].xs, dev[r].scattered, 0));
+                    HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault, dev[p].xs));
+                }
+                hipStream_t compute = models[p]->stream;
+                models[p]->stream = dev[p].xs; /* the owner reduce belongs to the exchange stream */
+                const sbr_status st = sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own);
+                models[p]->stream = compute;
+                SBRCHK(st);
+                HIPCHK(hipEventRecord(dev[p].reduced, dev[p].xs));
+            }
+            for (uint32_t q = 0; q < n; ++q) {
+                SBRCHK(ensure_device(models[q]));
+                for (uint32_t p = 0; p < n; ++p) {
+                    if (p != q) HIPCHK(hipStreamWaitEvent(dev[q].xs, dev[p].reduced, 0));
+                    HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, dev[q].xs));
+                    HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, dev[q].xs));
+                }
+                HIPCHK(hipEventRecord(dev[q].gathered, dev[q].xs));
+                HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[q].gathered, 0));
+                SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+                HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+            }
+            first = false;
+        }
+        return SBR_OK;
     };
     auto run = [&]() -> sbr_status {
         for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_begin(models[r], user_ptr, item_ids, num_users, &dev[r].plan));
@@ -1065,9 +1168,10 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             HIPCHK(hipEventCreateWithFlags(&v.scattered, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&v.reduced, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&v.applied, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&v.gathered, hipEventDisableTiming));
+            if (async) HIPCHK(hipStreamCreateWithFlags(&v.xs, hipStreamNonBlocking));
         }
         const uint32_t epochs = models[0]->hp.num_epochs;
-        bool first = true;
         for (uint32_t e = 0; e < epochs; ++e) {
             uint64_t nmb = 0;
             for (uint32_t r = 0; r < n; ++r) {
@@ -1077,38 +1181,9 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                 nmb = k;
                 if (e + 1 < epochs) SBRCHK(sbr_fit_epoch_prefetch(dev[r].plan));
             }
-            for (uint64_t mb = 0; mb < nmb; ++mb) {
-                for (uint32_t r = 0; r < n; ++r) {
-                    SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
-                    if (!first) /* peers must be done reading send_r / dense_r / own_r of the previous step */
-                        for (uint32_t q = 0; q < n; ++q)
-                            if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
-                    SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
-                    HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
-                }
-                for (uint32_t p = 0; p < n; ++p) { /* all-to-all: chunk p of every device -> device p */
-                    SBRCHK(ensure_device(models[p]));
-                    for (uint32_t r = 0; r < n; ++r) {
-                        if (r != p) HIPCHK(hipStreamWaitEvent(models[p]->stream, dev[r].scattered, 0));
-                        HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault,
-                                              models[p]->stream));
-                    }
-                    SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
-                    SBRCHK(sbr_fit_step_dense(dev[p].plan, dev[p].dense));
-                    HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
-                }
-                for (uint32_t q = 0; q < n; ++q) { /* all-gather of the owners' chunks and of the dense blocks */
-                    SBRCHK(ensure_device(models[q]));
-                    for (uint32_t p = 0; p < n; ++p) {
-                        if (p != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[p].reduced, 0));
-                        HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, models[q]->stream));
-                        HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, models[q]->stream));
-                    }
-                    SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
-                    HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
-                }
-                first = false;
-            }
+            if (async) SBRCHK(async_epoch(nmb));
+            else
+                for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(sync_step(mb));
         }
         for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(dev[r].plan, nullptr, nullptr));
         return sbr_fit_end(dev[0].plan, out_loss, nullptr);

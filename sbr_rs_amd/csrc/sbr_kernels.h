@@ -92,9 +92,10 @@ void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t
                          const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
                          size_t sort_temp_bytes, int key_bits, hipStream_t s);
 /* multi-device owner-reduce protocol: own entries -> dense send chunks; owner's ordered sum; global apply */
-void launch_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                    void* send, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp, size_t sort_temp_bytes, int key_bits,
-                    hipStream_t s);
+void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                     size_t sort_temp_bytes, int key_bits, hipStream_t s);
+void launch_scatter_sorted(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                           void* send, const uint64_t* keys_sorted, hipStream_t s);
 void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
 void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s);
 /* accumulate loss/examples headers of all blocks into the plan accumulators */

@@ -1814,15 +1814,22 @@ void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int
     hipLaunchKernelGGL(accumulate_loss_kernel, dim3(1), dim3(64), 0, s, all_blocks, block_bytes, ndev, loss_acc, ex_acc);
 }
 
-void launch_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                    void* send, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp, size_t sort_temp_bytes, int key_bits,
-                    hipStream_t s) {
-    const uint64_t nflags = (uint64_t)ndev * slice_rows;
-    hipLaunchKernelGGL(clear_chunk_flags_kernel, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, s, send, ndev, slice_rows, m.d);
+/* keys of the device's own entries, sorted: needs only the index arrays and the sampled negatives, so
+ * the engine runs it on the side stream underneath the backward pass */
+void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                     size_t sort_temp_bytes, int key_bits, hipStream_t s) {
     if (rows_host == 0) return;
     const uint64_t total = 3ull * rows_host;
     hipLaunchKernelGGL(build_own_keys_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, blk, rows_host, keys);
     (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
+}
+
+void launch_scatter_sorted(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                           void* send, const uint64_t* keys_sorted, hipStream_t s) {
+    const uint64_t nflags = (uint64_t)ndev * slice_rows;
+    hipLaunchKernelGGL(clear_chunk_flags_kernel, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, s, send, ndev, slice_rows, m.d);
+    if (rows_host == 0) return;
+    const uint64_t total = 3ull * rows_host;
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((sparse_scatter_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, send, slice_rows);

@@ -66,7 +66,7 @@ def exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=
     backend.apply_table(table, dense_all)
 
 
-def _staged_exchange(backend, dist, group, send, recv, table, dense_all) -> None:
+def _staged_exchange(backend, dist, group, send, recv, table, dense_all, dense=None) -> None:
     import torch
 
     world = dist.get_world_size(group)
@@ -74,25 +74,93 @@ def _staged_exchange(backend, dist, group, send, recv, table, dense_all) -> None
     dist.all_to_all_single(h_recv, send.cpu(), group=group)
     recv.copy_(h_recv)
     own = backend.owner_reduce(recv)
-    for dst, src in ((table, own), (dense_all, backend.dense())):
+    for dst, src in ((table, own), (dense_all, backend.dense() if dense is None else dense)):
         parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
         dist.all_gather(parts, src.cpu(), group=group)
         dst.copy_(torch.cat(parts))
     backend.apply_table(table, dense_all)
 
 
-def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None):
+class StepLoop:
+    """The optimiser-step sequencing of one device, shared by ``run_fit`` and ``bench.py``.
+
+    Synchronous (``Parallelism::Synchronous``, mod.rs:39-40): compute, exchange, apply.
+
+    Asynchronous (``Parallelism::Asynchronous``, mod.rs:36-38) with more than one device: the
+    deterministic analogue of Hogwild, staleness fixed at one step — minibatch k+1 is computed on
+    parameters that lack update k, so the exchange of step k (on its own stream, when the backend
+    has streams) runs underneath that computation; update k is applied afterwards.  With one
+    device both modes are the same step."""
+
+    def __init__(self, backend: StepBackend, world: int, asynchronous: bool = False, group=None):
+        self.backend, self.world, self.group = backend, world, group
+        self.asynchronous = bool(asynchronous) and world > 1
+        self.bufs = backend.buffers(world) if world > 1 else None
+        self.num_minibatches = 0
+        self._computed = -1  # minibatch whose local results are in the backend's block
+
+    def begin_epoch(self, prefetch_next: bool = False) -> int:
+        self.num_minibatches = self.backend.epoch_prepare(prefetch_next=prefetch_next)
+        self._computed = -1
+        return self.num_minibatches
+
+    def step(self, minibatch: int) -> None:
+        be = self.backend
+        if self._computed != minibatch:
+            be.compute_local(minibatch)
+        if self.world == 1:
+            be.apply_single(minibatch)
+        elif not self.asynchronous:
+            exchange_step(be, minibatch, self.world, self.bufs, self.group)
+        else:
+            nxt = minibatch + 1 if minibatch + 1 < self.num_minibatches else None
+            pipelined_exchange_step(be, minibatch, nxt, self.bufs, self.group)
+            if nxt is not None:
+                self._computed = nxt
+
+
+def pipelined_exchange_step(backend: StepBackend, minibatch: int, next_minibatch, bufs, group=None) -> None:
+    """Asynchronous step: [scatter, dense] -> {exchange on the side || compute_local(next)} -> apply."""
+    import torch.distributed as dist
+
+    recv, table, dense_all = bufs
+    send = backend.scatter(minibatch)
+    dense = backend.dense()
+    streams = getattr(backend, "exchange_streams", None)
+    if streams is None or dist.get_backend(group) == "gloo":
+        # no device streams to overlap on (CPU backend, or host-staged gloo): same order of effects
+        if next_minibatch is not None:
+            backend.compute_local(next_minibatch)
+        if send.is_cuda:
+            _staged_exchange(backend, dist, group, send, recv, table, dense_all, dense=dense)
+        else:
+            dist.all_to_all_single(recv, send, group=group)
+            own = backend.owner_reduce(recv)
+            dist.all_gather_into_tensor(table, own, group=group)
+            dist.all_gather_into_tensor(dense_all, dense, group=group)
+            backend.apply_table(table, dense_all)
+        return
+    with streams() as (torch, compute, side):
+        side.wait_stream(compute)                      # send / dense are complete
+        with torch.cuda.stream(side):
+            dist.all_to_all_single(recv, send, group=group)
+            own = backend.owner_reduce(recv, stream=side)
+            dist.all_gather_into_tensor(table, own, group=group)
+            dist.all_gather_into_tensor(dense_all, dense, group=group)
+        if next_minibatch is not None:
+            backend.compute_local(next_minibatch)      # on the compute stream, under the exchange
+        compute.wait_stream(side)
+    backend.apply_table(table, dense_all)
+
+
+def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None, asynchronous: bool = False):
     """The epoch/minibatch loop of fit_sequence_model (sequence_model.rs:108-171) with the
     per-step rendezvous expressed as collectives."""
-    bufs = backend.buffers(world) if world > 1 else None
+    loop = StepLoop(backend, world, asynchronous, group)
     for e in range(num_epochs):
-        nmb = backend.epoch_prepare(prefetch_next=e + 1 < num_epochs)
+        nmb = loop.begin_epoch(prefetch_next=e + 1 < num_epochs)
         for mb in range(nmb):
-            backend.compute_local(mb)
-            if world > 1:
-                exchange_step(backend, mb, world, bufs, group)
-            else:
-                backend.apply_single(mb)
+            loop.step(mb)
     return backend.end()
 
 
@@ -111,7 +179,9 @@ class HipBackend:
             up, it = interactions_or_csr.user_pointers, interactions_or_csr.item_ids
         else:
             up, it = interactions_or_csr
-        model.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._compute = torch.cuda.current_stream()
+        self._side = torch.cuda.Stream() if world > 1 else None
+        model.set_stream(self._compute.cuda_stream)
         self.plan = model.fit_begin(up, it)
         if world > 1:
             self.chunk = self.plan.chunk_bytes()
@@ -140,9 +210,24 @@ class HipBackend:
         self.plan.step_dense(self._dense.data_ptr())
         return self._dense
 
-    def owner_reduce(self, recv):
-        self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr())
+    def owner_reduce(self, recv, stream=None):
+        if stream is not None:  # launch on the exchange stream (Asynchronous)
+            self.model.set_stream(stream.cuda_stream)
+        try:
+            self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr())
+        finally:
+            if stream is not None:
+                self.model.set_stream(self._compute.cuda_stream)
         return self.own
+
+    def exchange_streams(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            yield self.torch, self._compute, self._side
+
+        return ctx()
 
     def apply_table(self, table, dense_all) -> None:
         self.plan.step_apply_table(table.data_ptr(), dense_all.data_ptr())
@@ -172,7 +257,8 @@ def fit_distributed(model, interactions, group=None) -> float:
         raise RuntimeError("process rank does not match hp.device_rank")
     backend = HipBackend(model, interactions, world)
     try:
-        loss, _examples = run_fit(backend, int(model.hp.num_epochs), world, group)
+        loss, _examples = run_fit(backend, int(model.hp.num_epochs), world, group,
+                                  asynchronous=int(model.hp.parallelism) == 0)
     finally:
         backend.close()
     return loss

@@ -51,5 +51,5 @@ def synthetic_interactions(num_users, num_items, max_len, seed=7, min_len=3, zip
 
 
 def hparams(num_items, T, dim, model, loss, lr=0.16, l2=0.0004, epochs=1, B=8, seed=bytes([42] * 16), ndev=1, rank=0,
-            opt=OPT_ADAGRAD):
-    return make_hparams(num_items, T, dim, lr, l2, model, loss, opt, PAR_SYNC, seed, epochs, ndev, rank, B)
+            opt=OPT_ADAGRAD, par=PAR_SYNC):
+    return make_hparams(num_items, T, dim, lr, l2, model, loss, opt, par, seed, epochs, ndev, rank, B)

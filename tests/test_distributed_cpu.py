@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import LOSS_HINGE, LOSS_WARP, hparams, synthetic_interactions
+from helpers import LOSS_HINGE, LOSS_WARP, PAR_ASYNC, PAR_SYNC, hparams, synthetic_interactions
 from oracle.oracle import OracleModel
 from sbr_rs_amd._abi import ModelKind, Param
 from sbr_rs_amd.distributed import run_fit
@@ -59,15 +59,15 @@ PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, P
           0: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B]}
 
 
-def _worker(rank, world, port, kind, loss, out_dir):
+def _worker(rank, world, port, kind, loss, par, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
-        hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank)
+        hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank, par=par)
         m = OracleModel(hp)
-        loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world)
+        loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world, asynchronous=par == PAR_ASYNC)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v, ex=ex,
                  **{p.name: m.get_param(p) for p in PARAMS[kind]})
     finally:
@@ -80,15 +80,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind,loss", [(int(ModelKind.EWMA), LOSS_WARP), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE)])
-def test_two_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss):
+@pytest.mark.parametrize("kind,loss,par", [(int(ModelKind.EWMA), LOSS_WARP, PAR_SYNC), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC),
+                                           (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_ASYNC)])
+def test_two_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss, par):
+    """par = Asynchronous: the driver's pipelined step (compute k+1 before update k lands) must equal
+    the oracle's staleness-one emulation."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, loss, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, par, str(tmp_path)), nprocs=world, join=True)
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     # single process, both devices emulated
     ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
-    hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=0)
+    hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=0, par=par)
     ref = OracleModel(hp)
     ref_loss = ref.fit(ptr, items)
     for p in PARAMS[kind]:
@@ -97,6 +100,19 @@ def test_two_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, los
         assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"distributed != single-process on {p.name}"
     assert float(r0["loss"]) == float(r1["loss"]) == pytest.approx(ref_loss, rel=1e-6)
     assert int(r0["ex"]) == int(r1["ex"]) > 0
+
+
+def test_asynchronous_differs_from_synchronous_only_with_peers(oracle_lib):
+    """Staleness exists only between workers: one device trains identically in both modes, two do not."""
+    ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
+    out = {}
+    for ndev in (1, 2):
+        for par in (PAR_SYNC, PAR_ASYNC):
+            m = OracleModel(hparams(90, 10, 16, int(ModelKind.LSTM_NORMAL), LOSS_HINGE, epochs=2, B=4, ndev=ndev, par=par))
+            m.fit(ptr, items)
+            out[ndev, par] = m.get_param(Param.ITEM_EMBEDDING)
+    assert np.array_equal(out[1, PAR_SYNC], out[1, PAR_ASYNC])
+    assert not np.array_equal(out[2, PAR_SYNC], out[2, PAR_ASYNC])
 
 
 def test_partitioning_drops_remainder_and_shards_disjointly(oracle_lib):

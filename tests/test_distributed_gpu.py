@@ -18,7 +18,7 @@ PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, P
 CASE = dict(users=70, items=157, T=12, B=5, d=32, epochs=2, seed=9)
 
 
-def _worker(rank, world, port, kind, loss, out_dir):
+def _worker(rank, world, port, kind, loss, par, out_dir):
     import torch
     import torch.distributed as dist
 
@@ -39,7 +39,7 @@ def _worker(rank, world, port, kind, loss, out_dir):
             h = sbr.lstm.Hyperparameters.new(c["items"], c["T"]).lstm_variant(sbr.LSTMVariant.Normal)
         model = (h.from_seed(bytes([42] * 16)).embedding_dim(c["d"]).learning_rate(0.16).l2_penalty(0.0004)
                  .loss(sbr.Loss(loss)).optimizer(sbr.Optimizer.Adagrad).num_epochs(c["epochs"]).num_threads(world)
-                 .batch_sequences(c["B"]).build(device_rank=rank))
+                 .parallelism(sbr.Parallelism(par)).batch_sequences(c["B"]).build(device_rank=rank))
         loss_v = model.fit(comp)  # -> fit_distributed: a process group is initialised
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v,
                  **{p.name: model.params.get_param(p) for p in PARAMS[kind]})
@@ -54,17 +54,18 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,loss", [(int(ModelKind.LSTM_NORMAL), LOSS_WARP), (int(ModelKind.EWMA), LOSS_HINGE)])
-def test_two_processes_share_one_gpu(tmp_path, oracle_lib, kind, loss):
+@pytest.mark.parametrize("kind,loss,par", [(int(ModelKind.LSTM_NORMAL), LOSS_WARP, 1), (int(ModelKind.EWMA), LOSS_HINGE, 1),
+                                           (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, 0)])
+def test_two_processes_share_one_gpu(tmp_path, oracle_lib, kind, loss, par):
     import torch.multiprocessing as mp
 
     from oracle.oracle import OracleModel
 
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), kind, loss, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, par, str(tmp_path)), nprocs=world, join=True)
     c = CASE
     ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
-    ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world))
+    ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world, par=par))
     ref_loss = ref.fit(ptr, items)
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")

@@ -6,7 +6,8 @@ order-free in f64 and is compared with rtol 1e-6."""
 import numpy as np
 import pytest
 
-from helpers import (LOSS_BPR, LOSS_HINGE, LOSS_WARP, OPT_ADAM, hparams, movielens_protocol, synthetic_interactions)
+from helpers import (LOSS_BPR, LOSS_HINGE, LOSS_WARP, OPT_ADAM, PAR_ASYNC, PAR_SYNC, hparams, movielens_protocol,
+                     synthetic_interactions)
 from oracle.oracle import OracleError, OracleModel
 from sbr_rs_amd._abi import Debug, ModelKind, Param, Status
 from sbr_rs_amd.engine import Model
@@ -220,12 +221,15 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
         assert lg == pytest.approx(lo, rel=1e-6)
 
 
-@pytest.mark.parametrize("kind,loss,d,world,opt", [
-    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 2, 0),
-    (ModelKind.EWMA, LOSS_HINGE, 64, 3, 0),
-    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 4, OPT_ADAM),
+@pytest.mark.parametrize("kind,loss,d,world,opt,par", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 2, 0, PAR_SYNC),
+    (ModelKind.EWMA, LOSS_HINGE, 64, 3, 0, PAR_SYNC),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 4, OPT_ADAM, PAR_SYNC),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 64, 2, 0, PAR_ASYNC),   # staleness-one pipeline on an exchange stream
+    (ModelKind.EWMA, LOSS_WARP, 32, 3, 0, PAR_ASYNC),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 128, 4, OPT_ADAM, PAR_ASYNC),
 ])
-def test_group_fit_single_process(kind, loss, d, world, opt):
+def test_group_fit_single_process(kind, loss, d, world, opt, par):
     """sbr_group_fit: `world` replicas driven from ONE process, the exchange as event-ordered peer
     copies between the replicas' streams (here all on one GPU).  ≙ fit with num_threads(world);
     must equal the oracle with num_devices = world bit for bit, on every replica, and a second
@@ -235,7 +239,7 @@ def test_group_fit_single_process(kind, loss, d, world, opt):
     items, T, B = 211, 12, 5
     ptr, it = synthetic_interactions(100, items, T + 5, seed=23, zipf=True)
     mk = lambda q: hparams(items, T, d, int(kind), loss, epochs=3, B=B, ndev=world, rank=q, opt=opt,
-                           lr=0.02 if opt == OPT_ADAM else 0.16)
+                           lr=0.02 if opt == OPT_ADAM else 0.16, par=par)
     models = [Model(mk(q)) for q in range(world)]
     o = OracleModel(mk(0))
     for call in range(2):

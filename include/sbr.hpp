@@ -389,8 +389,10 @@ struct ImplicitUser {
 enum class Loss { BPR = SBR_LOSS_BPR, Hinge = SBR_LOSS_HINGE, WARP = SBR_LOSS_WARP };
 /// Optimizer used to train the model (mod.rs:26-32).
 enum class Optimizer { Adagrad = SBR_OPT_ADAGRAD, Adam = SBR_OPT_ADAM };
-/// Type of parallelism (mod.rs:35-41).  The engine's multi-device step is the deterministic
-/// rendezvous of Synchronous; Asynchronous is accepted and trained the same way.
+/// Type of parallelism (mod.rs:35-41).  Synchronous: every replica sees every update before its
+/// next minibatch.  Asynchronous: the deterministic analogue of Hogwild — with more than one replica,
+/// minibatch k+1 is computed on parameters that lack update k (staleness exactly one step), so the
+/// exchange runs underneath the computation.
 enum class Parallelism { Asynchronous = SBR_PAR_ASYNCHRONOUS, Synchronous = SBR_PAR_SYNCHRONOUS };
 
 namespace detail {

@@ -39,6 +39,10 @@ typedef enum sbr_status {
 typedef enum sbr_model_kind { SBR_MODEL_LSTM_NORMAL = 0, SBR_MODEL_LSTM_COUPLED = 1, SBR_MODEL_EWMA = 2 } sbr_model_kind;
 typedef enum sbr_loss { SBR_LOSS_BPR = 0, SBR_LOSS_HINGE = 1, SBR_LOSS_WARP = 2 } sbr_loss;
 typedef enum sbr_optimizer { SBR_OPT_ADAGRAD = 0, SBR_OPT_ADAM = 1 } sbr_optimizer;
+/* Asynchronous with num_devices > 1 = staleness-one pipeline: minibatch k+1 is computed on parameters
+ * that lack update k (the deterministic analogue of Hogwild); with one device both are
+ * the same step.  sbr_group_fit honours it; a host driving the step halves itself orders them
+ * [scatter k, dense k] -> {exchange k || step_local k+1} -> apply_table k. */
 typedef enum sbr_parallelism { SBR_PAR_ASYNCHRONOUS = 0, SBR_PAR_SYNCHRONOUS = 1 } sbr_parallelism;
 
 /* ---- hyper-parameters: lstm::Hyperparameters (lstm.rs:39-52) / ewma::Hyperparameters

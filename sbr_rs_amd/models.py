@@ -23,8 +23,10 @@ class Optimizer(enum.IntEnum):
 
 
 class Parallelism(enum.IntEnum):
-    """Type of parallelism (mod.rs:35-41).  On the GPU engine: Synchronous = deterministic
-    sorted sparse merge, the only mode built so far."""
+    """Type of parallelism (mod.rs:35-41).  Synchronous = every device sees every update before its
+    next minibatch (deterministic owner-reduce rendezvous).  Asynchronous = the deterministic analogue
+    of Hogwild: with more than one device, minibatch k+1 is computed on parameters that lack update k
+    (staleness exactly one step), which hides the exchange under the computation."""
 
     Asynchronous = 0
     Synchronous = 1

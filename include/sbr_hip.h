@@ -174,6 +174,20 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                          uint64_t num_users, float* out_loss);
 sbr_status sbr_device_count(int32_t* out_count);
 
+/* Builds the n replicas of a single-process group in one call (replica r on HIP device r mod device
+ * count; destroy each with sbr_model_destroy).  flags = 0: n full parameter replicas, exactly what n
+ * sbr_model_create calls give.  SBR_GROUP_PARTITION_ITEM_TABLE (BASELINE configs[4]): the
+ * item table (embeddings, biases and their optimiser state) exists ONCE — rows [r*S, (r+1)*S),
+ * S = ceil(num_items / n), live on replica r's device and are mapped into every replica's address space
+ * (HIP virtual memory management; remote rows are read over xGMI by the unchanged gather kernels).  In
+ * sbr_group_fit each row is then updated by its owner only, from the devices' gradient lists merged in
+ * device order: bitwise the same result as the replicated Synchronous exchange, with per-step traffic
+ * proportional to the batch instead of to the table.  Prediction / mrr_score / get_param work on any
+ * replica.  Parallelism::Asynchronous is not available for a partitioned table. */
+#define SBR_GROUP_PARTITION_ITEM_TABLE 1u
+sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, sbr_model** out_models);
+sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out);
+
 /* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
 sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);
 sbr_status sbr_model_synchronize(sbr_model* m);

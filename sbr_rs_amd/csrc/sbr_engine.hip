@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -73,12 +74,97 @@ struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
 }  // namespace
 
+/* The item table of a partitioned group: ONE virtual address range per array (hipMemAddressReserve)
+ * whose physical pages live on the owners' devices (hipMemCreate per run of pages, hipMemMap), readable
+ * and writable from every device of the group (hipMemSetAccess; remote pages travel over xGMI).  All
+ * replicas therefore use the same table pointers and the same global row ids — the kernels of the hot
+ * path are unchanged — while each row is stored once and updated only by its owner. */
+struct SharedTable {
+    struct Part { hipMemGenericAllocationHandle_t h; size_t off, bytes; };
+    void* base = nullptr;
+    size_t total = 0;
+    std::vector<Part> parts;
+    float *E = nullptr, *Eacc = nullptr, *Em = nullptr, *b = nullptr, *bacc = nullptr, *bm = nullptr;
+
+    ~SharedTable() {
+        for (auto& pt : parts) {
+            (void)hipMemUnmap(reinterpret_cast<char*>(base) + pt.off, pt.bytes);
+            (void)hipMemRelease(pt.h);
+        }
+        if (base) (void)hipMemAddressFree(base, total);
+    }
+
+    /* devices[r] = HIP device of replica r; rows [r*S, (r+1)*S) belong to replica r */
+    sbr_status create(uint64_t num_items, uint64_t d, bool adam, const std::vector<int>& devices, uint64_t S) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = devices[0];
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
+            return SBR_ERR_UNSUPPORTED;
+        struct Arr { float** ptr; uint64_t row_bytes; bool on; };
+        Arr arrs[6] = {{&E, d * 4, true}, {&Eacc, d * 4, true}, {&Em, d * 4, adam}, {&b, 4, true}, {&bacc, 4, true}, {&bm, 4, adam}};
+        size_t off[6], bytes[6];
+        total = 0;
+        for (int a = 0; a < 6; ++a) {
+            off[a] = total;
+            bytes[a] = arrs[a].on ? ((size_t)(num_items * arrs[a].row_bytes) + gran - 1) / gran * gran : 0;
+            total += bytes[a];
+        }
+        if (hipMemAddressReserve(&base, total, gran, nullptr, 0) != hipSuccess) { base = nullptr; return SBR_ERR_OUT_OF_MEMORY; }
+        for (int a = 0; a < 6; ++a) {
+            if (!arrs[a].on) continue;
+            *arrs[a].ptr = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off[a]);
+            /* a page goes to the device of the replica that owns its first row; runs of pages with the
+             * same home become one physical allocation */
+            const size_t npages = bytes[a] / gran;
+            size_t run_begin = 0;
+            auto home = [&](size_t page) {
+                const uint64_t row = (uint64_t)(page * gran) / arrs[a].row_bytes;
+                uint64_t owner = row / S;
+                if (owner >= devices.size()) owner = devices.size() - 1;
+                return devices[owner];
+            };
+            while (run_begin < npages) {
+                const int dev = home(run_begin);
+                size_t run_end = run_begin + 1;
+                while (run_end < npages && home(run_end) == dev) ++run_end;
+                Part pt;
+                pt.off = off[a] + run_begin * gran;
+                pt.bytes = (run_end - run_begin) * gran;
+                prop.location.id = dev;
+                if (hipMemCreate(&pt.h, pt.bytes, &prop, 0) != hipSuccess) return SBR_ERR_OUT_OF_MEMORY;
+                if (hipMemMap(reinterpret_cast<char*>(base) + pt.off, pt.bytes, 0, pt.h, 0) != hipSuccess) {
+                    (void)hipMemRelease(pt.h);
+                    return SBR_ERR_HIP;
+                }
+                parts.push_back(pt);
+                run_begin = run_end;
+            }
+        }
+        std::vector<int> uniq(devices);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        std::vector<hipMemAccessDesc> acc(uniq.size());
+        for (size_t i = 0; i < uniq.size(); ++i) {
+            acc[i].location.type = hipMemLocationTypeDevice;
+            acc[i].location.id = uniq[i];
+            acc[i].flags = hipMemAccessFlagsProtReadWrite;
+        }
+        if (hipMemSetAccess(base, total, acc.data(), acc.size()) != hipSuccess) return SBR_ERR_UNSUPPORTED;
+        return SBR_OK;
+    }
+};
+
 struct sbr_model {
     sbr_hparams hp;
+    std::shared_ptr<SharedTable> shared; /* partitioned group: the table arrays belong to this object */
     int d = 0, ng = 0;
     int device = 0;
     sbr::ModelView mv;
     sbr_xorshift rng;
+    sbr_xorshift rng_after_table; /* RNG state right after the item-table initialisation */
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     hipStream_t stream = nullptr;
@@ -282,6 +368,14 @@ struct sbr_fit_plan {
     double* loss_acc = nullptr;
     unsigned long long* ex_acc = nullptr;
     bool dense_pending = false; /* the side stream still owes blk.dense */
+    /* partitioned item table: this device's gradient list (addressed by sorted-key position), the owner
+     * bounds, and the owner-side merge buffers */
+    float *glist = nullptr, *gblist = nullptr;
+    uint32_t *gfl = nullptr, *bounds_dev = nullptr;
+    uint64_t *mkeys = nullptr, *mkeys_sorted = nullptr;
+    void* msort_temp = nullptr;
+    size_t msort_temp_bytes = 0;
+    uint64_t mcap = 0;
     /* last step (debug) */
     int last_R = 0;
     const void* last_block = nullptr;
@@ -357,7 +451,10 @@ sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out
     return SBR_OK;
 }
 
-sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
+/* shared != null: the table arrays are the group's SharedTable; only the replica with write_table
+ * initialises them, the others take the RNG state that follows the table initialisation */
+static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<SharedTable> shared, bool write_table,
+                                    const sbr_xorshift* rng_after_table, sbr_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 || hp->num_devices == 0 ||
@@ -393,28 +490,39 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     const uint64_t I = hp->num_items, d = (uint64_t)m->d;
     sbr_status st = SBR_OK;
     auto fail = [&](sbr_status s) { sbr_model_destroy(m); return s; };
-    if ((st = dmalloc(&v.E, I * d)) != SBR_OK) return fail(st);
-    if ((st = dmalloc(&v.Eacc, I * d)) != SBR_OK) return fail(st);
-    if ((st = dmalloc(&v.b, I)) != SBR_OK) return fail(st);
-    if ((st = dmalloc(&v.bacc, I)) != SBR_OK) return fail(st);
-    if (adam) {
-        if ((st = dmalloc(&v.Em, I * d)) != SBR_OK) return fail(st);
-        if ((st = dmalloc(&v.bm, I)) != SBR_OK) return fail(st);
-        hipMemsetAsync(v.Em, 0, I * d * 4, m->stream);
-        hipMemsetAsync(v.bm, 0, I * 4, m->stream);
+    m->shared = shared;
+    if (shared) {
+        v.E = shared->E; v.Eacc = shared->Eacc; v.b = shared->b; v.bacc = shared->bacc;
+        v.Em = shared->Em; v.bm = shared->bm;
+    } else {
+        if ((st = dmalloc(&v.E, I * d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.Eacc, I * d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.b, I)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.bacc, I)) != SBR_OK) return fail(st);
+        if (adam) {
+            if ((st = dmalloc(&v.Em, I * d)) != SBR_OK) return fail(st);
+            if ((st = dmalloc(&v.bm, I)) != SBR_OK) return fail(st);
+        }
     }
-    hipMemsetAsync(v.Eacc, 0, I * d * 4, m->stream);
-    hipMemsetAsync(v.b, 0, I * 4, m->stream);
-    hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
     /* ≙ build_params (lstm.rs:174-194): embeddings first, then the recurrent weights, same RNG */
     sbr_xs_seed(&m->rng, hp->seed);
-    {
+    if (!shared || write_table) {
+        if (adam) {
+            hipMemsetAsync(v.Em, 0, I * d * 4, m->stream);
+            hipMemsetAsync(v.bm, 0, I * 4, m->stream);
+        }
+        hipMemsetAsync(v.Eacc, 0, I * d * 4, m->stream);
+        hipMemsetAsync(v.b, 0, I * 4, m->stream);
+        hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
         std::vector<float> host(I * d);
         Normal nrm{&m->rng};
         const double std_e = 1.0 / (double)d;
         for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_e);
         if (hipMemcpy(v.E, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
+    } else {
+        m->rng = *rng_after_table;
     }
+    m->rng_after_table = m->rng;
     if (m->ng) {
         const uint64_t nw = 2 * d * (uint64_t)m->ng * d, nb = (uint64_t)m->ng * d;
         if ((st = dmalloc(&v.W, nw)) != SBR_OK) return fail(st);
@@ -453,15 +561,19 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
     return SBR_OK;
 }
 
+sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
+    return model_create_impl(hp, nullptr, true, nullptr, out);
+}
+
 void sbr_model_destroy(sbr_model* m) {
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
     sbr::ModelView& v = m->mv;
-    hipFree(v.E); hipFree(v.Eacc); hipFree(v.b); hipFree(v.bacc);
+    if (!m->shared) { hipFree(v.E); hipFree(v.Eacc); hipFree(v.b); hipFree(v.bacc); hipFree(v.Em); hipFree(v.bm); }
     hipFree(v.W); hipFree(v.Wacc); hipFree(v.bW); hipFree(v.bWacc); hipFree(v.Wp); hipFree(v.WTp);
     hipFree(v.alpha); hipFree(v.alpha_acc);
-    hipFree(v.Em); hipFree(v.bm); hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
+    hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
@@ -688,6 +800,8 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     p->wb.release();
     hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
     hipFree(p->loss_acc); hipFree(p->ex_acc);
+    hipFree(p->glist); hipFree(p->gblist); hipFree(p->gfl); hipFree(p->bounds_dev);
+    hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
     delete p;
 }
 
@@ -961,10 +1075,10 @@ sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, v
     return SBR_OK;
 }
 
-sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all) {
-    if (!p || !device_table || !device_dense_all) return SBR_ERR_INVALID_ARGUMENT;
+/* the part of an exchanged step that every device applies identically: step counter, loss header,
+ * dense parameters (device-order sum of the gathered dense blocks) */
+static sbr_status apply_dense_blocks(sbr_fit_plan* p, const void* device_dense_all) {
     sbr_model* m = p->m;
-    SBRCHK(ensure_device(m));
     const uint64_t db = (8 + dense_count(m)) * 4;
     const uint8_t* dall = reinterpret_cast<const uint8_t*>(device_dense_all);
     begin_optimizer_step(m);
@@ -973,9 +1087,78 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
         sbr::launch_dense_apply(m->mv, dall, db, 32, p->ndev, m->stream);
     }
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all) {
+    if (!p || !device_table || !device_dense_all) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    if (m->shared) return SBR_ERR_INVALID_ARGUMENT; /* a partitioned table is updated by its owners (sbr_group_fit) */
+    SBRCHK(ensure_device(m));
+    SBRCHK(apply_dense_blocks(p, device_dense_all));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         sbr::launch_table_apply(m->mv, device_table, slice_rows(p), m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* ---- partitioned item table (sbr_group_create flag SBR_GROUP_PARTITION_ITEM_TABLE) ------------------ */
+static sbr_status partition_buffers(sbr_fit_plan* p) {
+    if (p->glist) return SBR_OK;
+    const uint64_t cap = 3 * p->rmax;
+    if (cap >= (1ull << 28)) return SBR_ERR_UNSUPPORTED; /* list positions are 28-bit in the merge keys */
+    SBRCHK(dmalloc(&p->glist, cap * (uint64_t)p->m->d));
+    SBRCHK(dmalloc(&p->gblist, cap));
+    SBRCHK(dmalloc(&p->gfl, cap));
+    SBRCHK(dmalloc(&p->bounds_dev, 17));
+    return SBR_OK;
+}
+
+static sbr_status merge_capacity(sbr_fit_plan* p, uint64_t total) {
+    if (total <= p->mcap) return SBR_OK;
+    sbr_model* m = p->m;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
+    p->mkeys = p->mkeys_sorted = nullptr; p->msort_temp = nullptr; p->mcap = 0;
+    const uint64_t cap = total + total / 4 + 1024;
+    SBRCHK(dmalloc(&p->mkeys, cap));
+    SBRCHK(dmalloc(&p->mkeys_sorted, cap));
+    p->msort_temp_bytes = sbr::sparse_sort_temp_bytes(cap, 64);
+    uint8_t* tmp = nullptr;
+    SBRCHK(dmalloc(&tmp, p->msort_temp_bytes));
+    p->msort_temp = tmp;
+    p->mcap = cap;
+    return SBR_OK;
+}
+
+/* this device's own entries reduced per row into its list + the owner bounds (after sbr_fit_step_local) */
+static sbr_status partition_reduce_own(sbr_fit_plan* p, uint64_t minibatch) {
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    SBRCHK(partition_buffers(p));
+    const sbr::BlockView bv = block_view(m, p->block, p->rmax);
+    const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
+    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_reduce_list(m->mv, bv, R, p->ndev, slice_rows(p), p->keys_sorted, p->glist, p->gblist, p->gfl, p->bounds_dev,
+                                m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* owner side: merge the peers' lists over this device's row range (device order) and update its rows */
+static sbr_status partition_owner_apply(sbr_fit_plan* p, const sbr::PeerLists& pl, uint32_t total) {
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    SBRCHK(merge_capacity(p, total));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_owner_list_apply(m->mv, pl, p->ndev, total, p->mkeys, p->mkeys_sorted, p->msort_temp, p->msort_temp_bytes,
+                                     m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1041,6 +1224,7 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             return SBR_ERR_INVALID_ARGUMENT;
     }
     if (n == 1) return sbr_model_fit(models[0], user_ptr, item_ids, num_users, out_loss);
+    if (n > 16) return SBR_ERR_INVALID_ARGUMENT;
 
     struct Dev {
         sbr_fit_plan* plan = nullptr;
@@ -1049,6 +1233,10 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
         hipStream_t xs = nullptr; /* exchange stream (Asynchronous) */
     };
     const bool async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS;
+    const bool partitioned = models[0]->shared != nullptr;
+    for (uint32_t r = 0; r < n; ++r)
+        if (models[r]->shared != models[0]->shared) return SBR_ERR_INVALID_ARGUMENT;
+    if (partitioned && async) return SBR_ERR_UNSUPPORTED;
     std::vector<Dev> dev(n);
     uint64_t chunk = 0, db = 0;
     auto cleanup = [&]() {
@@ -1098,6 +1286,48 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                 HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, models[q]->stream));
             }
             SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+            HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+        }
+        first = false;
+        return SBR_OK;
+    };
+    /* Partitioned item table: every row is stored once (on its owner) and read by everybody through the
+     * shared mapping.  A step: all devices compute on the current table; each reduces its own entries into
+     * a list; after a host-side rendezvous (the owners need the list bounds to size their merge) every
+     * owner merges the peers' lists over its rows in device order and updates them in place.  Bitwise the
+     * same result as the replicated Synchronous exchange. */
+    std::vector<uint32_t> hbounds((size_t)n * (n + 1));
+    auto partitioned_step = [&](uint64_t mb) -> sbr_status {
+        for (uint32_t r = 0; r < n; ++r) {
+            if (!first) /* no owner may still be writing rows of the previous step */
+                for (uint32_t q = 0; q < n; ++q)
+                    if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
+            SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
+            SBRCHK(partition_reduce_own(dev[r].plan, mb));
+            SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
+        }
+        for (uint32_t r = 0; r < n; ++r) { /* rendezvous: every device has finished READING the table */
+            SBRCHK(ensure_device(models[r]));
+            HIPCHK(hipStreamSynchronize(models[r]->stream));
+            HIPCHK(hipMemcpy(&hbounds[(size_t)r * (n + 1)], dev[r].plan->bounds_dev, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        for (uint32_t q = 0; q < n; ++q) {
+            SBRCHK(ensure_device(models[q]));
+            sbr::PeerLists pl;
+            std::memset(&pl, 0, sizeof(pl));
+            uint32_t total = 0;
+            for (uint32_t r = 0; r < n; ++r) {
+                const sbr_fit_plan* pr = dev[r].plan;
+                pl.keys[r] = pr->keys_sorted; pl.G[r] = pr->glist; pl.gb[r] = pr->gblist; pl.fl[r] = pr->gfl;
+                pl.lo[r] = hbounds[(size_t)r * (n + 1) + q];
+                pl.base[r] = total;
+                total += hbounds[(size_t)r * (n + 1) + q + 1] - pl.lo[r];
+            }
+            for (uint32_t r = n; r <= 16; ++r) pl.base[r] = total;
+            for (uint32_t r = 0; r < n; ++r)
+                HIPCHK(hipMemcpyAsync(dev[q].dense_all + r * db, dev[r].dense, db, hipMemcpyDefault, models[q]->stream));
+            SBRCHK(apply_dense_blocks(dev[q].plan, dev[q].dense_all));
+            SBRCHK(partition_owner_apply(dev[q].plan, pl, total));
             HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
         }
         first = false;
@@ -1163,8 +1393,11 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                         (void)hipDeviceEnablePeerAccess(models[q]->device, 0); /* already-enabled is fine */
                 }
             (void)hipGetLastError();
-            SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.recv, n * chunk));
-            SBRCHK(dmalloc(&v.own, chunk)); SBRCHK(dmalloc(&v.table, n * chunk)); SBRCHK(dmalloc(&v.dense_all, n * db));
+            SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.dense_all, n * db));
+            if (!partitioned) { /* the replicated exchange moves table-sized chunks; the partitioned one needs none */
+                SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.recv, n * chunk));
+                SBRCHK(dmalloc(&v.own, chunk)); SBRCHK(dmalloc(&v.table, n * chunk));
+            }
             HIPCHK(hipEventCreateWithFlags(&v.scattered, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&v.reduced, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&v.applied, hipEventDisableTiming));
@@ -1181,7 +1414,9 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                 nmb = k;
                 if (e + 1 < epochs) SBRCHK(sbr_fit_epoch_prefetch(dev[r].plan));
             }
-            if (async) SBRCHK(async_epoch(nmb));
+            if (partitioned)
+                for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(partitioned_step(mb));
+            else if (async) SBRCHK(async_epoch(nmb));
             else
                 for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(sync_step(mb));
         }
@@ -1191,6 +1426,44 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
     const sbr_status st = run();
     cleanup();
     return st;
+}
+
+/* n replicas of one model (num_devices = n, device_rank = r, replica r on HIP device r mod device count).
+ * SBR_GROUP_PARTITION_ITEM_TABLE: instead of n full copies, the item table (embeddings, biases and their
+ * optimiser state) exists once, rows [r*S, (r+1)*S), S = ceil(num_items / n), on replica r's device, mapped
+ * into every replica's address space. */
+sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, sbr_model** out_models) {
+    if (!hp || !out_models || n == 0 || n > 16) return SBR_ERR_INVALID_ARGUMENT;
+    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0) return SBR_ERR_INVALID_ARGUMENT;
+    int ndevices = 0;
+    if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
+    for (uint32_t r = 0; r < n; ++r) out_models[r] = nullptr;
+    std::vector<int> devices(n);
+    for (uint32_t r = 0; r < n; ++r) devices[r] = (int)(r % (uint32_t)ndevices);
+    std::shared_ptr<SharedTable> shared;
+    sbr_status st = SBR_OK;
+    if (flags & SBR_GROUP_PARTITION_ITEM_TABLE) {
+        shared = std::make_shared<SharedTable>();
+        const uint64_t S = ((uint64_t)hp->num_items + n - 1) / n;
+        st = shared->create(hp->num_items, hp->embedding_dim, hp->optimizer == SBR_OPT_ADAM, devices, S);
+    }
+    for (uint32_t r = 0; r < n && st == SBR_OK; ++r) {
+        sbr_hparams h = *hp;
+        h.num_devices = n;
+        h.device_rank = r;
+        if (hipSetDevice(devices[r]) != hipSuccess) { st = SBR_ERR_HIP; break; }
+        st = model_create_impl(&h, shared, r == 0, r ? &out_models[0]->rng_after_table : nullptr, &out_models[r]);
+    }
+    (void)hipSetDevice(devices[0]);
+    if (st != SBR_OK)
+        for (uint32_t r = 0; r < n; ++r) { sbr_model_destroy(out_models[r]); out_models[r] = nullptr; }
+    return st;
+}
+
+sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out) {
+    if (!m || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = m->shared ? 1 : 0;
+    return SBR_OK;
 }
 
 sbr_status sbr_device_count(int32_t* out_count) {

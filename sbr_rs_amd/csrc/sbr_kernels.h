@@ -61,6 +61,16 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     unsigned int* part_tries;
 };
 
+/* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
+struct PeerLists {
+    const uint64_t* keys[16];
+    const float* G[16];
+    const float* gb[16];
+    const uint32_t* fl[16];
+    uint32_t lo[16];   /* first position of the owner's row range in device r's sorted keys */
+    uint32_t base[17]; /* exclusive prefix sum of the range lengths */
+};
+
 /* recurrent forward over all steps of the minibatch (LSTM: one launch per step) */
 void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
                               const int* off_host, hipStream_t s);
@@ -98,6 +108,12 @@ void launch_scatter_sorted(const ModelView& m, const BlockView& blk, uint32_t ro
                            void* send, const uint64_t* keys_sorted, hipStream_t s);
 void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
 void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s);
+/* partitioned item table (owner-computes): own entries -> position-addressed list + owner bounds; the owner
+ * merges the peers' lists (read through peer mappings) in device order and updates its rows */
+void launch_reduce_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                        const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, hipStream_t s);
+void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
+                             uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 /* accumulate loss/examples headers of all blocks into the plan accumulators */
 void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                             unsigned long long* ex_acc, hipStream_t s);

@@ -1368,6 +1368,113 @@ __global__ void build_own_keys_kernel(BlockView blk, uint32_t R, uint64_t* keys)
     }
 }
 
+// ---- partitioned item table: owner-computes over peer-readable gradient lists -----
+// Every device reduces its own entries per table row exactly as sparse_scatter_kernel does, but into a
+// LIST addressed by the position of the row's first key in the device's sorted key array
+// (G[p][D], gb[p], fl[p]; fl = 0 at non-head positions).  The owner of a row range then reads the
+// peers' lists directly (peer mappings over xGMI) and adds the devices' contributions in device
+// order — the same association order as the replicated owner-reduce exchange.
+template <int D>
+__global__ __launch_bounds__(256) void sparse_reduce_list_kernel(BlockView blk, const uint64_t* keys, uint64_t n, float* G,
+                                                                 float* gbl, uint32_t* fl) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
+        const uint64_t key = keys[p];
+        const uint32_t row = (uint32_t)(key >> 32);
+        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) {
+            if (lg == 0) fl[p] = 0u;
+            continue;
+        }
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+        float gb = 0.0f;
+        bool has_b = false, first = true;
+        for (uint64_t e = p; e < n; ++e) {
+            const uint64_t ke = keys[e];
+            if ((uint32_t)(ke >> 32) != row) break;
+            const uint32_t src = (uint32_t)ke;
+            const uint32_t r = src / 3, kind = src % 3;
+            const float* srcp = (kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg;
+            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
+            const float4 v = ld4(srcp);
+            if (first) {
+                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
+                first = false;
+            } else {
+                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
+                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
+            }
+            if (kind != 0) {
+                gb = has_b ? gb + scale : scale;
+                has_b = true;
+            }
+        }
+        st4(G + p * D + 4 * lg, make_float4(gs[0], gs[1], gs[2], gs[3]));
+        if (lg == 0) {
+            gbl[p] = gb;
+            fl[p] = 1u | (has_b ? 2u : 0u);
+        }
+    }
+}
+
+// bounds[q] = first position of the sorted keys whose row is >= q * S (q = 0..ndev)
+__global__ void owner_bounds_kernel(const uint64_t* keys, uint32_t n, int ndev, uint64_t S, uint32_t* bounds) {
+    const int q = threadIdx.x;
+    if (q > ndev) return;
+    const uint64_t target = ((uint64_t)q * S) << 32;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    bounds[q] = q == ndev ? n : lo;
+}
+
+// merge keys of one owner: (row, device, position) of every list head in its row range
+__global__ void merge_keys_kernel(PeerLists pl, int ndev, uint32_t total, uint64_t* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int r = 0;
+        while (r + 1 < ndev && i >= pl.base[r + 1]) ++r;
+        const uint32_t p = pl.lo[r] + (i - pl.base[r]);
+        out[i] = (pl.fl[r][p] & 1u) ? ((pl.keys[r][p] >> 32) << 32) | ((uint64_t)r << 28) | (uint64_t)p : ~0ull;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, PeerLists pl, const uint64_t* mkeys, uint64_t n) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave * GPW + grp; i < n; i += nwaves * GPW) {
+        const uint64_t key = mkeys[i];
+        if (key == ~0ull) continue; /* padding sorts to the end */
+        const uint32_t row = (uint32_t)(key >> 32);
+        if (i > 0 && (uint32_t)(mkeys[i - 1] >> 32) == row) continue;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gb = 0.0f;
+        bool has_b = false, first = true;
+        for (uint64_t e = i; e < n; ++e) { /* devices in ascending order; the first toucher initialises */
+            const uint64_t ke = mkeys[e];
+            if (ke == ~0ull || (uint32_t)(ke >> 32) != row) break;
+            const int r = (int)((ke >> 28) & 15u);
+            const uint32_t p = (uint32_t)(ke & 0x0FFFFFFFu);
+            const float4 v = ld4(pl.G[r] + (size_t)p * D + 4 * lg);
+            if (first) { g = v; first = false; }
+            else { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
+            if (pl.fl[r][p] & 2u) {
+                gb = has_b ? gb + pl.gb[r][p] : pl.gb[r][p];
+                has_b = true;
+            }
+        }
+        row_update<D>(m, row, lg, g, has_b, gb);
+    }
+}
+
 __global__ void accumulate_loss_kernel(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                                        unsigned long long* ex_acc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1847,6 +1954,29 @@ void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_ro
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((table_apply_kernel<DD>), dim3(grid_for_groups((long long)m.num_items, gpb)), dim3(256), 0, s, m, table, slice_rows);
+    });
+}
+
+void launch_reduce_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                        const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, hipStream_t s) {
+    const uint64_t total = 3ull * rows_host;
+    if (total) {
+        DISPATCH_D(m.d, {
+            const int gpb = 4 * (64 / (DD / 4));
+            hipLaunchKernelGGL((sparse_reduce_list_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, G, gbl, fl);
+        });
+    }
+    hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys_sorted, (uint32_t)total, ndev, slice_rows, bounds);
+}
+
+void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
+                             uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
+    if (total == 0) return;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3(grid_for_groups(total, 256)), dim3(256), 0, s, pl, ndev, total, mkeys);
+    (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, mkeys, mkeys_sorted, total, 0, 64, s, false);
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((owner_list_apply_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, m, pl, mkeys_sorted, (uint64_t)total);
     });
 }
 

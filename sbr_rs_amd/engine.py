@@ -44,6 +44,26 @@ def device_count() -> int:
     return n.value
 
 
+GROUP_PARTITION_ITEM_TABLE = 1
+
+
+def group_create(hp: SbrHparams, n: int, partition_item_table: bool = False):
+    """The n replicas of a single-process group (sbr_group_create): replica r on HIP device r mod device
+    count.  ``partition_item_table``: the item table exists once, row range r on replica r's device,
+    mapped into every replica (BASELINE configs[4]); results equal the replicated group bit for bit."""
+    import copy
+
+    L = _lib.load()
+    handles = (C.c_void_p * n)()
+    _check(L.sbr_group_create(C.byref(hp), n, GROUP_PARTITION_ITEM_TABLE if partition_item_table else 0, handles))
+    out = []
+    for r in range(n):
+        h = copy.copy(hp)
+        h.num_devices, h.device_rank = n, r
+        out.append(Model._from_handle(h, C.c_void_p(handles[r])))
+    return out
+
+
 def group_fit(models, user_ptr, item_ids) -> float:
     """Single-process multi-device fit (sbr_group_fit): models[r] built with num_devices = len(models),
     device_rank = r and the same seed.  ≙ fit with num_threads(n) in one process."""
@@ -158,6 +178,20 @@ class Model:
         h = C.c_void_p()
         _check(self._L.sbr_model_create(C.byref(hp), C.byref(h)))
         self._h = h
+
+    @classmethod
+    def _from_handle(cls, hp: SbrHparams, handle) -> "Model":
+        m = cls.__new__(cls)
+        m._L = _lib.load()
+        m.hp = hp
+        m.dim = int(hp.embedding_dim)
+        m._h = handle
+        return m
+
+    def is_partitioned(self) -> bool:
+        v = C.c_int32()
+        _check(self._L.sbr_model_is_partitioned(self._h, C.byref(v)))
+        return bool(v.value)
 
     def dense_count(self) -> int:
         d = self.dim

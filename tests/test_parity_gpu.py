@@ -250,6 +250,55 @@ def test_group_fit_single_process(kind, loss, d, world, opt, par):
             assert_params_equal(models[q], o, kind, f"group_fit call {call} rank {q} of {world}")
 
 
+@pytest.mark.parametrize("kind,loss,d,world,opt", [
+    (ModelKind.EWMA, LOSS_HINGE, 256, 2, 0),          # BASELINE configs[4] in miniature: EWMA + hinge, d = 256
+    (ModelKind.EWMA, LOSS_WARP, 32, 3, 0),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 64, 4, 0),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 2, OPT_ADAM),
+    (ModelKind.EWMA, LOSS_HINGE, 128, 1, 0),          # a group of one: the table is just mapped memory
+])
+def test_partitioned_item_table_group_fit(kind, loss, d, world, opt):
+    """sbr_group_create(SBR_GROUP_PARTITION_ITEM_TABLE): the item table exists once (row range r on
+    replica r's device, one virtual range mapped into every replica), every replica reads it with the
+    unchanged kernels, each row is updated by its owner from the devices' gradient lists merged in
+    device order.  Must equal the oracle's replicated num_devices = world run bit for bit — table,
+    optimiser state and dense parameters — and prediction / MRR must work from any replica."""
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    items, T, B = 1237, 12, 5   # 1237 rows over `world` owners: uneven last slice, several 4 KiB pages
+    ptr, it = synthetic_interactions(110, items, T + 5, seed=29, zipf=True)
+    tptr, tit = synthetic_interactions(30, items, T, seed=31)
+    hp = hparams(items, T, d, int(kind), loss, epochs=3, B=B, ndev=world, opt=opt, lr=0.02 if opt == OPT_ADAM else 0.16)
+    models = group_create(hp, world, partition_item_table=True)
+    assert all(m.is_partitioned() for m in models)
+    o = OracleModel(hp)
+    for call in range(2):
+        lg = group_fit(models, ptr, it)
+        lo = o.fit(ptr, it)
+        assert lg == pytest.approx(lo, rel=1e-6)
+        for q in range(world):
+            assert_params_equal(models[q], o, kind, f"partitioned call {call} replica {q} of {world}")
+    mo, ro = o.mrr_score(tptr, tit)
+    for q in (0, world - 1):
+        mg, rg = models[q].mrr_score(tptr, tit)
+        assert np.array_equal(rg, ro) and mg == mo
+
+
+def test_group_create_replicated_matches_individual_models():
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    ptr, it = synthetic_interactions(60, 150, 14, seed=3, zipf=True)
+    hp = hparams(150, 12, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, epochs=2, B=4, ndev=2)
+    a = group_create(hp, 2)
+    assert not a[0].is_partitioned()
+    b = [Model(hparams(150, 12, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, epochs=2, B=4, ndev=2, rank=q)) for q in range(2)]
+    group_fit(a, ptr, it)
+    group_fit(b, ptr, it)
+    for q in range(2):
+        for p in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.LSTM_W, Param.ITEM_BIAS):
+            assert_same_bits(a[q].get_param(p), b[q].get_param(p), f"replica {q} {p.name}")
+
+
 ADAM_BLOCKS = {
     ModelKind.EWMA: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.EWMA_ALPHA_M],
     ModelKind.LSTM_NORMAL: [Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M, Param.LSTM_W_M, Param.LSTM_B_M],

@@ -408,24 +408,18 @@ inline std::vector<std::uint32_t> narrow(const std::vector<ItemId>& ids) {
 }
 
 /// Owner of the device replicas behind one model object: `num_threads` replicas (≙ the worker
-/// threads of sequence_model.rs:90-102), replica r on HIP device r mod device_count.
+/// threads of sequence_model.rs:90-102), replica r on HIP device r mod device_count
+/// (sbr_group_create).
 class Replicas {
   public:
-    Replicas(sbr_hparams hp) : hp_(hp) {
-        std::int32_t ndev = 0;
-        check(sbr_device_count(&ndev), "sbr_device_count");
-        const std::uint32_t n = hp.num_devices;
-        handles_.assign(n, nullptr);
-        for (std::uint32_t r = 0; r < n; ++r) {
-            hp.device_rank = r;
-            sbr_status st = sbr_set_device((std::int32_t)(r % (std::uint32_t)ndev));
-            if (st == SBR_OK) st = sbr_model_create(&hp, &handles_[r]);
-            if (st != SBR_OK) {
-                release();
-                throw EngineError(st, "sbr_model_create");
-            }
+    Replicas(sbr_hparams hp, bool partition_item_table) : hp_(hp) {
+        handles_.assign(hp.num_devices, nullptr);
+        const sbr_status st = sbr_group_create(&hp, hp.num_devices, partition_item_table ? SBR_GROUP_PARTITION_ITEM_TABLE : 0u,
+                                               handles_.data());
+        if (st != SBR_OK) {
+            handles_.clear();
+            throw EngineError(st, "sbr_group_create");
         }
-        sbr_set_device(0);
     }
     Replicas(const Replicas&) = delete;
     Replicas& operator=(const Replicas&) = delete;
@@ -458,7 +452,8 @@ class Replicas {
 /// (lstm.rs:391-416, ewma.rs:404-429 → sequence_model.rs:70-232).
 class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
   public:
-    explicit ImplicitSequenceModel(const sbr_hparams& hp) : replicas_(std::make_unique<Replicas>(hp)) {}
+    ImplicitSequenceModel(const sbr_hparams& hp, bool partition_item_table)
+        : replicas_(std::make_unique<Replicas>(hp, partition_item_table)) {}
 
     /// Fit the model; re-callable (training continues).  Err(NoInteractions) when no subsequence
     /// of more than two items exists (sequence_model.rs:86-88).
@@ -536,6 +531,9 @@ class HyperparametersBase {
     /// Subsequences per optimiser step and device (engine extension; 1 = the reference's
     /// per-sequence SGD).
     Derived& batch_sequences(std::size_t v) { batch_sequences_ = v; return self(); }
+    /// With num_threads(n) > 1: store the item table once, row range r on replica r's device, instead
+    /// of n full copies (engine extension for catalogues in the 1e7 range; results are identical).
+    Derived& partition_item_table(bool v) { partition_item_table_ = v; return self(); }
 
   protected:
     Derived& self() { return static_cast<Derived&>(*this); }
@@ -584,6 +582,7 @@ class HyperparametersBase {
     std::size_t num_threads_ = 1;
     std::size_t num_epochs_ = 10;
     std::size_t batch_sequences_ = 32;
+    bool partition_item_table_ = false;
 };
 
 } // namespace detail
@@ -623,7 +622,8 @@ class Hyperparameters : public detail::HyperparametersBase<Hyperparameters> {
     /// Build a model out of the chosen hyperparameters: parameters are initialised on the device
     /// from the builder's RNG (lstm.rs:174-201).
     ImplicitLSTMModel build() const {
-        return ImplicitLSTMModel(hparams(lstm_type_ == LSTMVariant::Normal ? SBR_MODEL_LSTM_NORMAL : SBR_MODEL_LSTM_COUPLED));
+        return ImplicitLSTMModel(hparams(lstm_type_ == LSTMVariant::Normal ? SBR_MODEL_LSTM_NORMAL : SBR_MODEL_LSTM_COUPLED),
+                                 partition_item_table_);
     }
 
   private:
@@ -656,7 +656,7 @@ class Hyperparameters : public detail::HyperparametersBase<Hyperparameters> {
         return h;
     }
     /// Build the implicit EWMA model (ewma.rs:201-205).
-    ImplicitEWMAModel build() const { return ImplicitEWMAModel(hparams(SBR_MODEL_EWMA)); }
+    ImplicitEWMAModel build() const { return ImplicitEWMAModel(hparams(SBR_MODEL_EWMA), partition_item_table_); }
 };
 
 } // namespace ewma

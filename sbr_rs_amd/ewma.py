@@ -27,7 +27,7 @@ class Hyperparameters(_HyperparametersBase):
 
     def build(self, device_rank: int = 0) -> "ImplicitEWMAModel":
         """Build the implicit EWMA model (ewma.rs:201-205)."""
-        return ImplicitEWMAModel(Model(self._hparams(int(ModelKind.EWMA), device_rank)))
+        return ImplicitEWMAModel(*self._build_engine(int(ModelKind.EWMA), device_rank))
 
 
 class ImplicitEWMAModel(_ImplicitSequenceModel):

@@ -78,6 +78,23 @@ class _HyperparametersBase:
         self._batch_sequences = int(batch_sequences)
         return self
 
+    def partition_item_table(self, flag: bool = True):
+        """With ``num_threads(n) > 1`` in one process: store the item table once, row range r on replica
+        r's device, instead of n full copies (engine extension; results are identical)."""
+        self._partition = bool(flag)
+        return self
+
+    def _build_engine(self, model_kind: int, device_rank: int):
+        """Model handle(s) for build(): one handle, or the whole single-process group when the item
+        table is partitioned (the replicas must then be created together)."""
+        hp = self._hparams(model_kind, device_rank)
+        if getattr(self, "_partition", False):
+            from .engine import group_create
+
+            group = group_create(hp, self._num_threads, partition_item_table=True)
+            return group[0], group
+        return Model(hp), None
+
     def _hparams(self, model_kind: int, device_rank: int = 0):
         return make_hparams(self._num_items, self._max_sequence_length, self._item_embedding_dim, self._learning_rate,
                             self._l2_penalty, model_kind, int(self._loss), int(self._optimizer), int(self._parallelism),
@@ -127,14 +144,15 @@ class Hyperparameters(_HyperparametersBase):
         """Build a model out of the chosen hyperparameters (lstm.rs:197-201): parameters are
         initialised from the builder's RNG on the device."""
         kind = ModelKind.LSTM_NORMAL if self._lstm_type == LSTMVariant.Normal else ModelKind.LSTM_COUPLED
-        return ImplicitLSTMModel(Model(self._hparams(int(kind), device_rank)))
+        return ImplicitLSTMModel(*self._build_engine(int(kind), device_rank))
 
 
 class _ImplicitSequenceModel:
     """fit / OnlineRankingModel surface shared by both models (lstm.rs:391-416, ewma.rs:404-429)."""
 
-    def __init__(self, engine_model: Model):
+    def __init__(self, engine_model: Model, group=None):
         self.params = engine_model
+        self._peers = group[1:] if group else None
 
     def fit(self, interactions: CompressedInteractions) -> float:
         """Fit the model; returns the loss value.  Raises FittingError.NoInteractions
@@ -144,7 +162,7 @@ class _ImplicitSequenceModel:
             return self.params.fit(interactions.user_pointers, interactions.item_ids)
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized():
+        if dist.is_available() and dist.is_initialized() and not self.params.is_partitioned():
             # one process per GPU (torchrun): this process drives replica hp.device_rank
             from .distributed import fit_distributed
 

@@ -286,6 +286,29 @@ static void defaults_and_predict() {
     std::printf("defaults=ok loss=%.9g\n", loss);
 }
 
+// num_threads(3) with the item table stored once (partition_item_table): same numbers as three full
+// replicas, from the façade
+static void partitioned_equals_replicated() {
+    const std::size_t num_users = 90, num_items = 1500;
+    XorShiftRng rng = XorShiftRng::from_seed(seed42());
+    Interactions all(num_users, num_items);
+    for (std::size_t u = 0; u < num_users; ++u) {
+        const std::size_t n = 3 + rng.below(20);
+        for (std::size_t t = 0; t < n; ++t) all.push(Interaction(u, rng.below(num_items), t));
+    }
+    const CompressedInteractions train = all.to_compressed();
+    auto hyper = models::ewma::Hyperparameters::new_(num_items, 16).from_seed(seed42()).embedding_dim(64).loss(Loss::Hinge)
+                     .optimizer(Optimizer::Adagrad).learning_rate(0.16f).num_epochs(2).num_threads(3).batch_sequences(7);
+    auto replicated = hyper.build();
+    auto partitioned = hyper.partition_item_table(true).build();
+    const float l0 = replicated.fit(train).unwrap(), l1 = partitioned.fit(train).unwrap();
+    CHECK(bits(l0) == bits(l1));
+    CHECK(replicated.parameter(SBR_PARAM_ITEM_EMBEDDING) == partitioned.parameter(SBR_PARAM_ITEM_EMBEDDING));
+    CHECK(replicated.parameter(SBR_PARAM_ITEM_BIAS_ACC) == partitioned.parameter(SBR_PARAM_ITEM_BIAS_ACC));
+    CHECK(bits(mrr_score(replicated, train).unwrap()) == bits(mrr_score(partitioned, train).unwrap()));
+    std::printf("partitioned=ok loss=%.9g\n", l1);
+}
+
 static void no_device() {
     // without a GPU the engine must refuse, not fall back
     try {
@@ -307,6 +330,7 @@ int main(int argc, char** argv) {
         else if (which == "no_device") no_device();
         else if (which == "empty_interactions") empty_interactions();
         else if (which == "defaults_and_predict") defaults_and_predict();
+        else if (which == "partitioned_equals_replicated") partitioned_equals_replicated();
         else if (which == "mrr_test_single_thread") mrr_test_single_thread(arg);
         else if (which == "mrr_test_two_threads") mrr_test_two_threads(arg);
         else if (which == "mrr_test_warp") mrr_test_warp(arg);

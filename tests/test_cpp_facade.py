@@ -105,6 +105,7 @@ def test_build_without_device_raises(facade):
 def test_empty_interactions_and_defaults(facade):
     run(facade, "empty_interactions")    # lstm.rs:520-530
     run(facade, "defaults_and_predict")
+    run(facade, "partitioned_equals_replicated")
 
 
 @pytest.mark.gpu

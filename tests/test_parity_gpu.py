@@ -408,6 +408,20 @@ def test_num_threads_two_through_the_python_api():
     assert_params_equal(model.params, o, ModelKind.LSTM_NORMAL, "num_threads(2)")
 
 
+def test_partition_item_table_through_the_python_api():
+    import sbr_rs_amd as sbr
+
+    ptr, it = synthetic_interactions(70, 900, 18, seed=4, zipf=True)
+    comp = sbr.data.CompressedInteractions(70, 900, ptr, it, np.zeros(len(it), dtype=np.uint64))
+    mk = lambda: (sbr.ewma.Hyperparameters.new(900, 16).from_seed(bytes([9] * 16)).embedding_dim(256).loss(sbr.Loss.Hinge)
+                  .optimizer(sbr.Optimizer.Adagrad).learning_rate(0.16).num_epochs(2).num_threads(3).batch_sequences(6))
+    rep, part = mk().build(), mk().partition_item_table().build()
+    assert part.params.is_partitioned() and not rep.params.is_partitioned()
+    assert rep.fit(comp) == part.fit(comp)
+    assert_params_equal(part.params, rep.params, ModelKind.EWMA, "partitioned vs replicated")
+    assert sbr.evaluation.mrr_score(part, comp) == sbr.evaluation.mrr_score(rep, comp)
+
+
 def test_save_load_resumes_training_bit_exactly(tmp_path):
     """≙ the serde derives (lstm.rs:204,386): parameters + optimiser state + counters round-trip, and
     training continues exactly as if it had never been interrupted (given the same next-fit seed)."""

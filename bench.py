@@ -334,15 +334,18 @@ def main():
                 out["test_mrr"] = {"error": repr(e)}
         line = json.dumps(out)
     backend.close()
+    # RCCL writes a version banner through C stdio, which is only flushed at exit when stdout is a pipe:
+    # every rank flushes it now, and rank 0 prints after a barrier, so the JSON line is the last line
+    import ctypes
+
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(line, flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    if rank == 0:
-        # RCCL writes a version banner through C stdio, which is flushed at exit when stdout is a pipe:
-        # flush it now so that the JSON line is the last line of stdout
-        import ctypes
-
-        ctypes.CDLL(None).fflush(None)
-        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend; gloo (host-staged) lets several ranks share one GPU for testing the N > 1 path")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
@@ -186,6 +188,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # ranks may share a device
     torch.cuda.set_device(local_rank)
     from sbr_rs_amd import engine
     from sbr_rs_amd._abi import Debug
@@ -199,7 +203,10 @@ def main():
         if world == 1:  # --force-exchange without a launcher
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     model_kind = {"lstm": 0, "lstm-coupled": 1, "ewma": 2}[args.model]
     loss_kind = {"bpr": 0, "hinge": 1, "warp": 2}[args.loss]
@@ -255,10 +262,11 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        rdev = "cpu" if args.backend == "gloo" else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rows_timed], dtype=torch.int64, device="cuda")
+        r = torch.tensor([rows_timed], dtype=torch.int64, device=rdev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rows_total = int(r.item())
         dist.barrier()
@@ -320,7 +328,7 @@ def main():
                        "users_per_gpu": args.users, "items": args.items, "max_len": args.max_len, "dim": args.dim,
                        "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": args.item_distribution,
                        "parallelism": (f"user-sharded dp{world}, {'staleness-one pipelined (Asynchronous)' if args.parallelism == 'async' else 'synchronous'} "
-                                       "owner-reduce exchange over RCCL") if world > 1 else "single device"},
+                                       f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
             "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,

@@ -71,7 +71,7 @@ struct PeerLists {
     uint32_t base[17]; /* exclusive prefix sum of the range lengths */
 };
 
-/* recurrent forward over all steps of the minibatch (LSTM: one launch per step) */
+/* recurrent forward over all steps of the minibatch (LSTM d <= 128: one sequence-resident launch; d = 256: one launch per step) */
 void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
                               const int* off_host, hipStream_t s);
 /* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */

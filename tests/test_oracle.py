@@ -4,11 +4,12 @@ conservation property, FittingError::NoInteractions, and the MovieLens-100K MRR 
 known-answer tests for the pieces the oracle restates from published algorithms (xorshift128,
 SipHash-2-4) and accuracy bounds for the contract's own exp/sigmoid/tanh kernels."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
-from helpers import (LOSS_BPR, LOSS_HINGE, LOSS_WARP, hparams, load_movielens, movielens_protocol,
+from helpers import (GOLDEN, LOSS_BPR, LOSS_HINGE, LOSS_WARP, hparams, load_movielens, movielens_protocol,
                      synthetic_interactions)
 from oracle.oracle import OracleError, OracleModel
 from sbr_rs_amd._abi import Debug, ModelKind, Param, Status
@@ -273,3 +274,30 @@ def test_dataset_loader_reads_fixture_and_csv(tmp_path):
     small = datasets.load_csv(str(p))
     assert small.len() == 2 and small.num_users() == 197 and small.num_items() == 303
     assert [x.timestamp() for x in small.data()] == [881250949, 891717742]
+
+
+# ---- committed golden vectors (tests/golden/oracle_vectors.npz) -----------------------------------
+def _golden_cases():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(GOLDEN, "make_oracle_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", ["ewma_hinge_d32", "lstm_warp_d32", "coupled_bpr_adam_d16", "lstm_hinge_two_devices",
+                                  "ewma_warp_three_devices_async"])
+def test_oracle_reproduces_committed_vectors(oracle_lib, name):
+    """The oracle's outputs for the committed inputs have not drifted: parameters, optimiser state,
+    user representation bit for bit; ranks exactly; loss / MRR as f32 values."""
+    mod = _golden_cases()
+    want = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    got = mod.run_case(OracleModel, name)
+    keys = [k.split("/", 1)[1] for k in want.files if k.startswith(name + "/")]
+    assert sorted(keys) == sorted(got)
+    for k in keys:
+        a, b = np.asarray(got[k]), want[f"{name}/{k}"]
+        assert a.dtype == b.dtype and a.shape == b.shape, (name, k)
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), (name, k)

@@ -577,3 +577,43 @@ def test_movielens_fit_bit_exact_and_mrr(kind, loss, B, bound):
     mo, ro = o.mrr_score(test.user_pointers, test.item_ids)
     assert np.array_equal(rg, ro) and mg == mo
     assert mg > bound
+
+
+# ---- committed golden vectors: the engine against numbers on disk, no oracle in the loop ------------
+class _EngineGroup:
+    """Engine-side adapter with the oracle's model surface: one handle, or a single-process group."""
+
+    def __init__(self, hp):
+        from sbr_rs_amd.engine import group_create
+
+        self.models = group_create(hp, int(hp.num_devices))
+
+    def fit(self, ptr, it):
+        from sbr_rs_amd.engine import group_fit
+
+        return group_fit(self.models, ptr, it)
+
+    def __getattr__(self, name):
+        return getattr(self.models[0], name)
+
+
+@pytest.mark.parametrize("name", ["ewma_hinge_d32", "lstm_warp_d32", "coupled_bpr_adam_d16", "lstm_hinge_two_devices",
+                                  "ewma_warp_three_devices_async"])
+def test_engine_reproduces_committed_vectors(name):
+    import importlib.util
+    import os
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(golden, "make_oracle_vectors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = np.load(os.path.join(golden, "oracle_vectors.npz"))
+    got = mod.run_case(_EngineGroup, name)
+    for k in [k.split("/", 1)[1] for k in want.files if k.startswith(name + "/")]:
+        a, b = np.asarray(got[k]), want[f"{name}/{k}"]
+        if k == "loss":  # f64 sum on the device, order-free: 1e-6 relative
+            assert float(a) == pytest.approx(float(b), rel=1e-6)
+            continue
+        assert a.shape == b.shape, (name, k)
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                              b.view(np.uint32) if b.dtype == np.float32 else b), (name, k)

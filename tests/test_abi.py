@@ -79,3 +79,43 @@ def test_python_surface_mirrors_reference_names():
     assert issubclass(sbr.PredictionError.InvalidPredictionValue, sbr.PredictionError)
     r = sbr.lstm.Hyperparameters.random(50, sbr.XorShiftRng.from_seed(bytes([1] * 16)))
     assert 16 <= r._item_embedding_dim <= 128 and 16 <= r._max_sequence_length <= 128
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 on its own (no C++, no HIP, no torch types)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "sbr_hip.h"\n'
+                   "int probe(void) { sbr_hparams hp; sbr_model* m = 0; (void)m; return (int)sizeof(hp); }\n"
+                   "sbr_status (*const fit_ptr)(sbr_model*, const uint64_t*, const uint32_t*, uint64_t, float*) = sbr_model_fit;\n")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "abi.o")])
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/ (it is the
+    checker); nothing under sbr_rs_amd/ or include/ may mention it, and nothing the GPU runs reads
+    /root/reference."""
+    offenders = []
+    for base in ("sbr_rs_amd", "include"):
+        for dirpath, _dirs, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".hip", ".h", ".hpp")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "libsbr_oracle" in text or "orc_" in text:
+                    offenders.append(os.path.join(base, f))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle", bench)]
+    lo, hi = bench.index("def cpu_baseline"), bench.index("def movielens_mrr")
+    assert uses and all(lo < u < hi for u in uses), "bench.py may use the oracle only inside cpu_baseline()"
+    for f in ("bench.py", "__graft_entry__.py"):
+        code = re.sub(r'""".*?"""', "", open(os.path.join(ROOT, f)).read(), flags=re.S)
+        code = re.sub(r"#.*", "", code)
+        assert "/root/reference" not in code, f

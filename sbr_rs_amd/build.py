@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libsbr_hip.so")
 SOURCES = ["sbr_kernels.hip", "sbr_engine.hip"]
 HEADERS = ["sbr_kernels.h", "sbr_numerics.h", os.path.join("..", "..", "include", "sbr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SBR_EXTRA_FLAGS", "").split()
 
 
 def hipcc() -> str:

@@ -672,6 +672,33 @@ static int orc_entry_cmp(const void* a, const void* b) {
     return 0;
 }
 
+/* One row's sparse gradient from its sorted entries ent[i..j): chunked in-order reduction, see
+ * SBR_SEG_CHUNK in sbr_numerics.h.  Every entry is (source vector, scale, bias flag): input row -> dX,
+ * target row -> -g*h, negative row -> +g*h; target/negative entries also carry the bias gradient
+ * (= scale).  `part` is scratch for one chunk partial [d]. */
+typedef struct { const float* H; const float* dX; const float* coef; } orc_entry_src;
+static void orc_reduce_row(const orc_entry* ent, uint64_t i, uint64_t j, int d, const orc_entry_src* s, uint32_t src_mod,
+                           float* g, float* part, float* gb_out, int* has_b_out) {
+    float gb = 0.0f; int has_b = 0, first_chunk = 1;
+    for (uint64_t c0 = i; c0 < j; c0 += SBR_SEG_CHUNK) {
+        uint64_t c1 = c0 + SBR_SEG_CHUNK < j ? c0 + SBR_SEG_CHUNK : j;
+        float pb = 0.0f; int phb = 0, first = 1;
+        for (uint64_t e = c0; e < c1; ++e) {
+            uint32_t src = src_mod ? ent[e].src % src_mod : ent[e].src;
+            uint32_t r = src / 3, kind = src % 3;
+            const float* srcv = kind == 0 ? s->dX + (size_t)r * d : s->H + (size_t)r * d;
+            float scale = kind == 0 ? 1.0f : kind == 1 ? -s->coef[r] : s->coef[r];
+            if (first) { for (int k = 0; k < d; ++k) part[k] = scale * srcv[k]; first = 0; }
+            else for (int k = 0; k < d; ++k) part[k] = part[k] + scale * srcv[k];
+            if (kind != 0) { pb = phb ? pb + scale : scale; phb = 1; }
+        }
+        if (first_chunk) { for (int k = 0; k < d; ++k) g[k] = part[k]; first_chunk = 0; }
+        else for (int k = 0; k < d; ++k) g[k] = g[k] + part[k];
+        if (phb) { gb = has_b ? gb + pb : pb; has_b = 1; }
+    }
+    *gb_out = gb; *has_b_out = has_b;
+}
+
 /* Optimiser step from the gathered exchange blocks of all devices
  * (≙ optimizer.step / sync_optim.step, sequence_model.rs:163-169; wyrm Adagrad as recalled):
  *  dense: gradients of the devices added in device order, then Adagrad on every element;
@@ -715,27 +742,21 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
     }
     qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
     float* gsum = (float*)malloc(sizeof(float) * d);
+    float* part = (float*)malloc(sizeof(float) * d);
+    const uint32_t* w0 = (const uint32_t*)all_blocks; /* ndev == 1: the device's own block */
+    orc_entry_src es = { (const float*)(w0 + 8 + 4 * Rmax), (const float*)(w0 + 8 + 4 * Rmax) + Rmax * (uint64_t)d,
+                         (const float*)(w0 + 8 + 3 * Rmax) };
     uint64_t i = 0;
     while (i < ne) {
         uint32_t row = ent[i].row;
-        float gb = 0.0f; int has_b = 0, first = 1;
         uint64_t j = i;
-        for (; j < ne && ent[j].row == row; ++j) {
-            uint32_t src = ent[j].src;
-            uint32_t q = (uint32_t)(src / (3 * Rmax)), rem = (uint32_t)(src % (3 * Rmax)), r = rem / 3, kind = rem % 3;
-            const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
-            const float* coef = (const float*)(w + 8 + 3 * Rmax);
-            const float* H = (const float*)(w + 8 + 4 * Rmax);
-            const float* dX = H + Rmax * (uint64_t)d;
-            const float* srcv = kind == 0 ? dX + (size_t)r * d : H + (size_t)r * d;
-            float scale = kind == 0 ? 1.0f : kind == 1 ? -coef[r] : coef[r];
-            if (first) { for (int k = 0; k < d; ++k) gsum[k] = scale * srcv[k]; first = 0; }
-            else for (int k = 0; k < d; ++k) gsum[k] = gsum[k] + scale * srcv[k];
-            if (kind != 0) { gb = has_b ? gb + scale : scale; has_b = 1; }
-        }
+        while (j < ne && ent[j].row == row) ++j;
+        float gb; int has_b;
+        orc_reduce_row(ent, i, j, d, &es, 0, gsum, part, &gb, &has_b);
         orc_row_update(m, row, gsum, 1, has_b, gb);
         i = j;
     }
+    free(part);
     free(gsum); free(ent);
     return SBR_OK;
 }
@@ -784,6 +805,8 @@ int orc_fit_scatter(orc_plan* p, int q, void* send) {
         ent[3 * r + 2].row = L->neg[r]; ent[3 * r + 2].src = 3u * r + 2;
     }
     qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
+    orc_entry_src es = { L->H, L->dX, L->coef };
+    float* part = (float*)malloc(sizeof(float) * d);
     uint64_t i = 0;
     while (i < ne) {
         uint32_t row = ent[i].row;
@@ -792,20 +815,15 @@ int orc_fit_scatter(orc_plan* p, int q, void* send) {
         float* g = chunk + lr * d;
         float* gb = chunk + S * d + lr;
         uint32_t* fl = (uint32_t*)(chunk + S * d + S) + lr;
-        int first = 1, has_b = 0;
         uint64_t j = i;
-        for (; j < ne && ent[j].row == row; ++j) {
-            uint32_t r = ent[j].src / 3, kind = ent[j].src % 3;
-            const float* srcv = kind == 0 ? L->dX + (size_t)r * d : L->H + (size_t)r * d;
-            float scale = kind == 0 ? 1.0f : kind == 1 ? -L->coef[r] : L->coef[r];
-            if (first) { for (int k = 0; k < d; ++k) g[k] = scale * srcv[k]; first = 0; }
-            else for (int k = 0; k < d; ++k) g[k] = g[k] + scale * srcv[k];
-            if (kind != 0) { *gb = has_b ? *gb + scale : scale; has_b = 1; }
-        }
+        while (j < ne && ent[j].row == row) ++j;
+        int has_b; float gbv;
+        orc_reduce_row(ent, i, j, d, &es, 0, g, part, &gbv, &has_b);
+        if (has_b) *gb = gbv;
         *fl = 1u | (has_b ? 2u : 0u);
         i = j;
     }
-    free(ent);
+    free(ent); free(part);
     return SBR_OK;
 }
 

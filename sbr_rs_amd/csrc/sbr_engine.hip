@@ -367,6 +367,7 @@ struct sbr_fit_plan {
     int key_bits = 64;
     double* loss_acc = nullptr;
     unsigned long long* ex_acc = nullptr;
+    sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
     /* partitioned item table: this device's gradient list (addressed by sorted-key position), the owner
      * bounds, and the owner-side merge buffers */
@@ -773,6 +774,18 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         st = dmalloc(&tmp, p->sort_temp_bytes);
         p->sort_temp = tmp;
     }
+    {   /* a long segment has more than SBR_SEG_CHUNK entries: at most max_entries / chunk of them, and
+         * their chunks number at most max_entries / chunk + (number of long segments) */
+        const uint64_t cap = max_entries / SBR_SEG_CHUNK + 2, units = 2 * cap;
+        p->seg.cap = (uint32_t)cap;
+        if (st == SBR_OK) st = dmalloc(&p->seg.counters, 4);
+        if (st == SBR_OK) st = dmalloc(&p->seg.long_start, cap);
+        if (st == SBR_OK) st = dmalloc(&p->seg.long_end, cap);
+        if (st == SBR_OK) st = dmalloc(&p->seg.unit_base, cap + 1);
+        if (st == SBR_OK) st = dmalloc(&p->seg.P, units * (uint64_t)m->d);
+        if (st == SBR_OK) st = dmalloc(&p->seg.Pb, units);
+        if (st == SBR_OK) st = dmalloc(&p->seg.Pf, units);
+    }
     if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
@@ -800,6 +813,8 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     p->wb.release();
     hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
     hipFree(p->loss_acc); hipFree(p->ex_acc);
+    hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
+    hipFree(p->seg.P); hipFree(p->seg.Pb); hipFree(p->seg.Pf);
     hipFree(p->glist); hipFree(p->gblist); hipFree(p->gfl); hipFree(p->bounds_dev);
     hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
     delete p;
@@ -960,11 +975,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_scored, 0));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1, m->side);
-        if (p->ndev == 1)
-            sbr::launch_sparse_sort(m->mv, p->block, p->block_bytes, 1, p->rmax, ep.rows_of_dev.data() + minibatch, p->keys,
-                                    p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
-        else
-            sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
+        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
     }
     HIPCHK(hipEventRecord(m->ev_sorted, m->side));
     {
@@ -999,8 +1010,8 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
-        sbr::launch_sparse_apply_sorted(m->mv, all, p->block_bytes, 1, p->rmax, p->ep[p->cur].rows_of_dev.data() + minibatch,
-                                        p->keys_sorted, m->stream);
+        sbr::launch_seg_apply(m->mv, block_view(m, p->block, p->rmax), p->ep[p->cur].rows_of_dev[minibatch], p->keys_sorted, p->seg,
+                              m->stream);
     }
     SBRCHK(join_dense(p));
     {
@@ -1042,7 +1053,7 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
-        sbr::launch_scatter_sorted(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys_sorted, m->stream);
+        sbr::launch_seg_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys_sorted, p->seg, m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1143,8 +1154,8 @@ static sbr_status partition_reduce_own(sbr_fit_plan* p, uint64_t minibatch) {
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_reduce_list(m->mv, bv, R, p->ndev, slice_rows(p), p->keys_sorted, p->glist, p->gblist, p->gfl, p->bounds_dev,
-                                m->stream);
+        sbr::launch_seg_list(m->mv, bv, R, p->ndev, slice_rows(p), p->keys_sorted, p->glist, p->gblist, p->gfl, p->bounds_dev, p->seg,
+                             m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;

@@ -61,6 +61,18 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     unsigned int* part_tries;
 };
 
+/* scratch of the long-segment path of the sparse reduction */
+struct SegScratch {
+    uint32_t* counters;   /* [0] long segments, [1] chunk units */
+    uint32_t* long_start; /* first / one-past-last key position of every long segment */
+    uint32_t* long_end;
+    uint32_t* unit_base;  /* exclusive prefix of the long segments' chunk counts */
+    float* P;             /* chunk partials [units][D] */
+    float* Pb;
+    uint32_t* Pf;         /* 1 = the chunk has a bias contribution */
+    uint32_t cap;         /* capacity of the long-segment arrays */
+};
+
 /* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
 struct PeerLists {
     const uint64_t* keys[16];
@@ -86,32 +98,28 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
                                int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s);
 void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
                            int b_host, hipStream_t s);
-/* sparse update split in two so that the key sort can start early */
-void launch_sparse_sort(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                        const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                        size_t sort_temp_bytes, int key_bits, hipStream_t s);
-void launch_sparse_apply_sorted(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                                const uint32_t* rows_of_device_host, const uint64_t* keys_sorted, hipStream_t s);
 /* dense: sum over device blocks in device order + Adagrad (+ repack of the LSTM weights) */
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
                         int ndev, hipStream_t s);
 void launch_repack_lstm(const ModelView& m, hipStream_t s);
-/* sparse: keys -> sort -> per-row ordered reduction + Adagrad */
+/* sparse: keys of the device's own entries -> radix sort (needs only indices and negatives, so it runs
+ * underneath the backward pass) -> per-row reduction in the contract's chunked order -> one of three
+ * consumers: optimiser update (single device), the owners' dense send chunks (replicated multi-device),
+ * the position-addressed list + owner bounds (partitioned table) */
 size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits);
-void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                         size_t sort_temp_bytes, int key_bits, hipStream_t s);
-/* multi-device owner-reduce protocol: own entries -> dense send chunks; owner's ordered sum; global apply */
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
                      size_t sort_temp_bytes, int key_bits, hipStream_t s);
-void launch_scatter_sorted(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                           void* send, const uint64_t* keys_sorted, hipStream_t s);
+void launch_seg_apply(const ModelView& m, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted,
+                      const SegScratch& sc, hipStream_t s);
+void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                        void* send, const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
+void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                     const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, const SegScratch& sc,
+                     hipStream_t s);
 void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
 void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s);
-/* partitioned item table (owner-computes): own entries -> position-addressed list + owner bounds; the owner
- * merges the peers' lists (read through peer mappings) in device order and updates its rows */
-void launch_reduce_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                        const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, hipStream_t s);
+/* partitioned item table: the owner merges the peers' lists (read through peer mappings) in device order
+ * and updates its rows */
 void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
                              uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 /* accumulate loss/examples headers of all blocks into the plan accumulators */

@@ -1176,72 +1176,230 @@ __device__ __forceinline__ void row_update(const ModelView& m, uint64_t row, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6 sparse: (row, source) keys -> radix sort -> per-row in-order reduction + Adagrad
+// K6 sparse: (row, source) keys -> radix sort -> per-row reduction in the contract's chunked order
+// (SBR_SEG_CHUNK, sbr_numerics.h) -> Emit.  One lane group (D/4 lanes) owns a row segment of the sorted
+// keys.  Segments of at most SBR_SEG_CHUNK entries — all but the hot rows of a skewed catalogue — are
+// reduced in place by `seg_short_kernel`; longer ones are only registered there, their chunks are
+// reduced in parallel by `seg_chunk_kernel` (one lane group per chunk) and the chunk partials are
+// added in order by `seg_finish_kernel`.  The three consumers differ only in what happens to a
+// finished row (Emit): optimiser update, write into the owner's send chunk, or entry of the list.
 // ------------------------------------------------------------------------------------------------
-struct DevRows {
-    uint32_t rows[16];
-    uint32_t key_base[16];
+
+struct EmitApply {  // single device: one optimiser update per touched row
+    ModelView m;
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb) const {
+        row_update<D>(m, r, lg, g, has_b, gb);
+    }
+    __device__ __forceinline__ void not_head(uint64_t, int) const {}
+};
+struct EmitChunk {  // replicated multi-device: the row's sum goes into the owner's dense send chunk
+    void* send;
+    uint64_t S;
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb) const {
+        float* c = reinterpret_cast<float*>(send) + (r / S) * S * ((uint64_t)D + 2);
+        const uint64_t lr = r % S;
+        st4(c + lr * D + 4 * lg, g);
+        if (lg == 0) {
+            if (has_b) c[S * D + lr] = gb;
+            reinterpret_cast<uint32_t*>(c + S * D + S)[lr] = 1u | (has_b ? 2u : 0u);
+        }
+    }
+    __device__ __forceinline__ void not_head(uint64_t, int) const {}
+};
+struct EmitList {  // partitioned table: list entry addressed by the position of the row's first key
+    float* G;
+    float* gbl;
+    uint32_t* fl;
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t, uint64_t p, int lg, float4 g, bool has_b, float gb) const {
+        st4(G + p * D + 4 * lg, g);
+        if (lg == 0) {
+            gbl[p] = gb;
+            fl[p] = 1u | (has_b ? 2u : 0u);
+        }
+    }
+    __device__ __forceinline__ void not_head(uint64_t p, int lg) const {
+        if (lg == 0) fl[p] = 0u;
+    }
 };
 
-__global__ void build_keys_kernel(const uint8_t* all_blocks, uint64_t block_bytes, uint64_t rmax, DevRows dr,
-                                  uint64_t* keys) {
-    const int q = blockIdx.y;
-    const uint32_t R = dr.rows[q];
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
-    const uint32_t* in_idx = hdr + 8;
-    const uint32_t* out_idx = in_idx + rmax;
-    const uint32_t* neg = out_idx + rmax;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-        const uint64_t src = (uint64_t)q * 3 * rmax + 3ull * r;
-        uint64_t* k = keys + dr.key_base[q] + 3ull * r;
-        k[0] = ((uint64_t)in_idx[r] << 32) | src;
-        k[1] = ((uint64_t)out_idx[r] << 32) | (src + 1);
-        k[2] = ((uint64_t)neg[r] << 32) | (src + 2);
+// in-order sum of the entries keys[begin, end) of one row (the first one initialises); the row loads of
+// four consecutive entries are issued together, the adds stay in order
+template <int D>
+__device__ __forceinline__ void seg_accumulate(const BlockView& blk, const uint64_t* keys, uint64_t begin, uint64_t end, int lg,
+                                               float4* g_out, float* gb_out, bool* has_b_out) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gb = 0.0f;
+    bool has_b = false, first = true;
+    for (uint64_t e = begin; e < end; e += 4) {
+        float4 v[4];
+        float sc[4];
+        bool bias[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sc[i] = 0.0f;
+            bias[i] = false;
+            if (e + i < end) { /* no traffic for the slots past the segment (most segments have 1-3 entries) */
+                const uint32_t src = (uint32_t)keys[e + i];
+                const uint32_t r = src / 3, kind = src % 3;
+                v[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
+                sc[i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
+                bias[i] = kind != 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (e + i < end) {
+                if (first) {
+                    g = make_float4(sc[i] * v[i].x, sc[i] * v[i].y, sc[i] * v[i].z, sc[i] * v[i].w);
+                    first = false;
+                } else {
+                    g.x = g.x + sc[i] * v[i].x; g.y = g.y + sc[i] * v[i].y;
+                    g.z = g.z + sc[i] * v[i].z; g.w = g.w + sc[i] * v[i].w;
+                }
+                if (bias[i]) {
+                    gb = has_b ? gb + sc[i] : sc[i];
+                    has_b = true;
+                }
+            }
+        }
     }
+    *g_out = g; *gb_out = gb; *has_b_out = has_b;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void sparse_apply_kernel(ModelView m, const uint8_t* all_blocks, uint64_t block_bytes,
-                                                           uint64_t rmax, const uint64_t* keys, uint64_t n) {
+// first position in [lo, hi) whose row differs from `row` (keys are sorted by row)
+__device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, uint64_t hi, uint32_t row) {
+    while (lo < hi) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if ((uint32_t)(keys[mid] >> 32) == row) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int D, class Emit>
+__global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        const uint64_t key = keys[p];
-        const uint32_t row = (uint32_t)(key >> 32);
-        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) continue; /* not the head of its segment */
-        float gs[4] = {0.f, 0.f, 0.f, 0.f};
-        float gb = 0.0f;
-        bool has_b = false, first = true;
-        for (uint64_t e = p; e < n; ++e) {
-            const uint64_t ke = keys[e];
-            if ((uint32_t)(ke >> 32) != row) break;
-            const uint32_t src = (uint32_t)ke;
-            const uint32_t q = (uint32_t)(src / (3 * rmax));
-            const uint32_t rem = (uint32_t)(src % (3 * rmax));
-            const uint32_t r = rem / 3, kind = rem % 3;
-            const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
-            const float* coef = reinterpret_cast<const float*>(hdr + 8 + 3 * rmax);
-            const float* H = reinterpret_cast<const float*>(hdr + 8 + 4 * rmax);
-            const float* dX = H + rmax * (uint64_t)D;
-            const float* srcp = (kind == 0 ? dX : H) + (size_t)r * D + 4 * lg;
-            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -coef[r] : coef[r]);
-            const float4 v = ld4(srcp);
-            if (first) {
-                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
-                first = false;
-            } else {
-                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
-                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
-            }
-            if (kind != 0) {
-                gb = has_b ? gb + scale : scale;
-                has_b = true;
+        const uint32_t row = (uint32_t)(keys[p] >> 32);
+        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) {
+            emit.not_head(p, lg);
+            continue;
+        }
+        // most segments hold a handful of entries: probe linearly first, then bisect up to the chunk size
+        uint64_t end = p + 1;
+        while (end < n && end < p + 4 && (uint32_t)(keys[end] >> 32) == row) ++end;
+        if (end == p + 4 && end < n && (uint32_t)(keys[end] >> 32) == row) {
+            const uint64_t hi = p + SBR_SEG_CHUNK + 1 < n ? p + SBR_SEG_CHUNK + 1 : n;
+            end = seg_end(keys, end, hi, row);
+            if (end - p > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
+                if (lg == 0) {
+                    const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
+                    if (slot < sc.cap) {
+                        sc.long_start[slot] = (uint32_t)p;
+                        sc.long_end[slot] = (uint32_t)seg_end(keys, end, n, row);
+                    }
+                }
+                continue;
             }
         }
-        row_update<D>(m, row, lg, make_float4(gs[0], gs[1], gs[2], gs[3]), has_b, gb);
+        float4 g;
+        float gb;
+        bool has_b;
+        seg_accumulate<D>(blk, keys, p, end, lg, &g, &gb, &has_b);
+        emit.template row<D>(row, p, lg, g, has_b, gb);
+    }
+}
+
+// prefix of the long segments' chunk counts (a few thousand entries at most: one workgroup)
+__global__ void seg_units_kernel(SegScratch sc) {
+    __shared__ uint32_t s_sum[256];
+    const uint32_t nlong = sc.counters[0] < sc.cap ? sc.counters[0] : sc.cap;
+    const uint32_t per = (nlong + 255) / 256;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < nlong ? lo + per : nlong;
+    uint32_t local = 0;
+    for (uint32_t i = lo; i < hi; ++i) local += (sc.long_end[i] - sc.long_start[i] + SBR_SEG_CHUNK - 1) / SBR_SEG_CHUNK;
+    s_sum[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 256; ++t) { const uint32_t v = s_sum[t]; s_sum[t] = run; run += v; }
+        sc.counters[1] = run;
+        sc.unit_base[nlong] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_sum[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) {
+        sc.unit_base[i] = run;
+        run += (sc.long_end[i] - sc.long_start[i] + SBR_SEG_CHUNK - 1) / SBR_SEG_CHUNK;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void seg_chunk_kernel(BlockView blk, const uint64_t* keys, SegScratch sc) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t nlong = sc.counters[0] < sc.cap ? sc.counters[0] : sc.cap;
+    const uint32_t units = sc.counters[1];
+    for (uint64_t u = wave * GPW + grp; u < units; u += nwaves * GPW) {
+        uint32_t lo = 0, hi = nlong; /* last segment whose unit_base <= u */
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (sc.unit_base[mid] <= u) lo = mid; else hi = mid;
+        }
+        const uint64_t begin = (uint64_t)sc.long_start[lo] + (u - sc.unit_base[lo]) * SBR_SEG_CHUNK;
+        const uint64_t end = begin + SBR_SEG_CHUNK < sc.long_end[lo] ? begin + SBR_SEG_CHUNK : sc.long_end[lo];
+        float4 g;
+        float gb;
+        bool has_b;
+        seg_accumulate<D>(blk, keys, begin, end, lg, &g, &gb, &has_b);
+        st4(sc.P + u * D + 4 * lg, g);
+        if (lg == 0) {
+            sc.Pb[u] = gb;
+            sc.Pf[u] = has_b ? 1u : 0u;
+        }
+    }
+}
+
+template <int D, class Emit>
+__global__ __launch_bounds__(256) void seg_finish_kernel(const uint64_t* keys, SegScratch sc, Emit emit) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t nlong = sc.counters[0] < sc.cap ? sc.counters[0] : sc.cap;
+    for (uint64_t sidx = wave * GPW + grp; sidx < nlong; sidx += nwaves * GPW) {
+        const uint32_t u0 = sc.unit_base[sidx], u1 = sc.unit_base[sidx + 1];
+        float4 g = ld4(sc.P + (uint64_t)u0 * D + 4 * lg);
+        bool has_b = sc.Pf[u0] != 0;
+        float gb = has_b ? sc.Pb[u0] : 0.0f;
+        for (uint32_t u = u0 + 1; u < u1; u += 4) { /* chunk partials in order; four loads in flight */
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ld4(sc.P + (uint64_t)(u + i < u1 ? u + i : u1 - 1) * D + 4 * lg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (u + i < u1) {
+                    g.x = g.x + v[i].x; g.y = g.y + v[i].y; g.z = g.z + v[i].z; g.w = g.w + v[i].w;
+                    if (sc.Pf[u + i]) {
+                        gb = has_b ? gb + sc.Pb[u + i] : sc.Pb[u + i];
+                        has_b = true;
+                    }
+                }
+            }
+        }
+        const uint64_t p = sc.long_start[sidx];
+        emit.template row<D>((uint32_t)(keys[p] >> 32), p, lg, g, has_b, gb);
     }
 }
 
@@ -1259,52 +1417,6 @@ __global__ void clear_chunk_flags_kernel(void* buf, int nchunks, uint64_t S, int
     if (i >= (uint64_t)nchunks * S) return;
     float* c = chunk_ptr(buf, i / S, S, D);
     reinterpret_cast<uint32_t*>(c + S * D + S)[i % S] = 0u;
-}
-
-// scatter: per-row ordered reduction of THIS device's entries into the send chunks
-template <int D>
-__global__ __launch_bounds__(256) void sparse_scatter_kernel(BlockView blk, const uint64_t* keys, uint64_t n, void* send,
-                                                             uint64_t S) {
-    constexpr int L = D / 4;
-    constexpr int GPW = 64 / L;
-    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        const uint64_t key = keys[p];
-        const uint32_t row = (uint32_t)(key >> 32);
-        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) continue;
-        float gs[4] = {0.f, 0.f, 0.f, 0.f};
-        float gb = 0.0f;
-        bool has_b = false, first = true;
-        for (uint64_t e = p; e < n; ++e) {
-            const uint64_t ke = keys[e];
-            if ((uint32_t)(ke >> 32) != row) break;
-            const uint32_t src = (uint32_t)ke;
-            const uint32_t r = src / 3, kind = src % 3;
-            const float* srcp = (kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg;
-            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
-            const float4 v = ld4(srcp);
-            if (first) {
-                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
-                first = false;
-            } else {
-                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
-                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
-            }
-            if (kind != 0) {
-                gb = has_b ? gb + scale : scale;
-                has_b = true;
-            }
-        }
-        float* c = chunk_ptr(send, row / S, S, D);
-        const uint64_t lr = row % S;
-        st4(c + lr * D + 4 * lg, make_float4(gs[0], gs[1], gs[2], gs[3]));
-        if (lg == 0) {
-            if (has_b) c[S * D + lr] = gb;
-            reinterpret_cast<uint32_t*>(c + S * D + S)[lr] = 1u | (has_b ? 2u : 0u);
-        }
-    }
 }
 
 // owner: contributions of the devices added in device order (first toucher initialises)
@@ -1374,52 +1486,6 @@ __global__ void build_own_keys_kernel(BlockView blk, uint32_t R, uint64_t* keys)
 // (G[p][D], gb[p], fl[p]; fl = 0 at non-head positions).  The owner of a row range then reads the
 // peers' lists directly (peer mappings over xGMI) and adds the devices' contributions in device
 // order — the same association order as the replicated owner-reduce exchange.
-template <int D>
-__global__ __launch_bounds__(256) void sparse_reduce_list_kernel(BlockView blk, const uint64_t* keys, uint64_t n, float* G,
-                                                                 float* gbl, uint32_t* fl) {
-    constexpr int L = D / 4;
-    constexpr int GPW = 64 / L;
-    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        const uint64_t key = keys[p];
-        const uint32_t row = (uint32_t)(key >> 32);
-        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) {
-            if (lg == 0) fl[p] = 0u;
-            continue;
-        }
-        float gs[4] = {0.f, 0.f, 0.f, 0.f};
-        float gb = 0.0f;
-        bool has_b = false, first = true;
-        for (uint64_t e = p; e < n; ++e) {
-            const uint64_t ke = keys[e];
-            if ((uint32_t)(ke >> 32) != row) break;
-            const uint32_t src = (uint32_t)ke;
-            const uint32_t r = src / 3, kind = src % 3;
-            const float* srcp = (kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg;
-            const float scale = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
-            const float4 v = ld4(srcp);
-            if (first) {
-                gs[0] = scale * v.x; gs[1] = scale * v.y; gs[2] = scale * v.z; gs[3] = scale * v.w;
-                first = false;
-            } else {
-                gs[0] = gs[0] + scale * v.x; gs[1] = gs[1] + scale * v.y;
-                gs[2] = gs[2] + scale * v.z; gs[3] = gs[3] + scale * v.w;
-            }
-            if (kind != 0) {
-                gb = has_b ? gb + scale : scale;
-                has_b = true;
-            }
-        }
-        st4(G + p * D + 4 * lg, make_float4(gs[0], gs[1], gs[2], gs[3]));
-        if (lg == 0) {
-            gbl[p] = gb;
-            fl[p] = 1u | (has_b ? 2u : 0u);
-        }
-    }
-}
-
 // bounds[q] = first position of the sorted keys whose row is >= q * S (q = 0..ndev)
 __global__ void owner_bounds_kernel(const uint64_t* keys, uint32_t n, int ndev, uint64_t S, uint32_t* bounds) {
     const int q = threadIdx.x;
@@ -1873,47 +1939,25 @@ size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits) {
     return bytes;
 }
 
-static uint64_t sparse_layout(int ndev, const uint32_t* rows_of_device_host, DevRows* dr, uint32_t* maxr) {
-    uint64_t total = 0;
-    *maxr = 0;
-    for (int q = 0; q < 16; ++q) { dr->rows[q] = 0; dr->key_base[q] = 0; }
-    for (int q = 0; q < ndev; ++q) {
-        dr->rows[q] = rows_of_device_host[q];
-        dr->key_base[q] = (uint32_t)total;
-        total += 3ull * rows_of_device_host[q];
-        if (rows_of_device_host[q] > *maxr) *maxr = rows_of_device_host[q];
-    }
-    return total;
-}
-
-void launch_sparse_sort(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                        const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                        size_t sort_temp_bytes, int key_bits, hipStream_t s) {
-    DevRows dr;
-    uint32_t maxr = 0;
-    const uint64_t total = sparse_layout(ndev, rows_of_device_host, &dr, &maxr);
-    if (total == 0) return;
-    hipLaunchKernelGGL(build_keys_kernel, dim3(grid_for_groups(maxr, 256), ndev), dim3(256), 0, s, all_blocks, block_bytes, rmax, dr, keys);
-    (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
-}
-
-void launch_sparse_apply_sorted(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                                const uint32_t* rows_of_device_host, const uint64_t* keys_sorted, hipStream_t s) {
-    DevRows dr;
-    uint32_t maxr = 0;
-    const uint64_t total = sparse_layout(ndev, rows_of_device_host, &dr, &maxr);
-    if (total == 0) return;
-    DISPATCH_D(m.d, {
+// sorted keys -> per-row reduction (chunked order) -> Emit: short segments, then the long ones
+template <class Emit>
+static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted, const SegScratch& sc,
+                              const Emit& emit, hipStream_t s) {
+    if (rows_host == 0) return;
+    const uint64_t total = 3ull * rows_host;
+    (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
+    DISPATCH_D(d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((sparse_apply_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, m, all_blocks, block_bytes, rmax, keys_sorted, total);
+        hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
+        hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
+        hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
+        hipLaunchKernelGGL((seg_finish_kernel<DD, Emit>), dim3(64), dim3(256), 0, s, keys_sorted, sc, emit);
     });
 }
 
-void launch_sparse_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, int ndev, uint64_t rmax,
-                         const uint32_t* rows_of_device_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                         size_t sort_temp_bytes, int key_bits, hipStream_t s) {
-    launch_sparse_sort(m, all_blocks, block_bytes, ndev, rmax, rows_of_device_host, keys, keys_sorted, sort_temp, sort_temp_bytes, key_bits, s);
-    launch_sparse_apply_sorted(m, all_blocks, block_bytes, ndev, rmax, rows_of_device_host, keys_sorted, s);
+void launch_seg_apply(const ModelView& m, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted,
+                      const SegScratch& sc, hipStream_t s) {
+    launch_seg_reduce(m.d, blk, rows_host, keys_sorted, sc, EmitApply{m}, s);
 }
 
 void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
@@ -1931,16 +1975,11 @@ void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, u
     (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
 }
 
-void launch_scatter_sorted(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                           void* send, const uint64_t* keys_sorted, hipStream_t s) {
+void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                        void* send, const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s) {
     const uint64_t nflags = (uint64_t)ndev * slice_rows;
     hipLaunchKernelGGL(clear_chunk_flags_kernel, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, s, send, ndev, slice_rows, m.d);
-    if (rows_host == 0) return;
-    const uint64_t total = 3ull * rows_host;
-    DISPATCH_D(m.d, {
-        const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((sparse_scatter_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, send, slice_rows);
-    });
+    launch_seg_reduce(m.d, blk, rows_host, keys_sorted, sc, EmitChunk{send, slice_rows}, s);
 }
 
 void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s) {
@@ -1957,16 +1996,11 @@ void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_ro
     });
 }
 
-void launch_reduce_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
-                        const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, hipStream_t s) {
-    const uint64_t total = 3ull * rows_host;
-    if (total) {
-        DISPATCH_D(m.d, {
-            const int gpb = 4 * (64 / (DD / 4));
-            hipLaunchKernelGGL((sparse_reduce_list_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, G, gbl, fl);
-        });
-    }
-    hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys_sorted, (uint32_t)total, ndev, slice_rows, bounds);
+void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
+                     const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, const SegScratch& sc,
+                     hipStream_t s) {
+    launch_seg_reduce(m.d, blk, rows_host, keys_sorted, sc, EmitList{G, gbl, fl}, s);
+    hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys_sorted, (uint32_t)(3ull * rows_host), ndev, slice_rows, bounds);
 }
 
 void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,

@@ -35,7 +35,13 @@
 /* ---- fixed constants of the contract ------------------------------------------------------ */
 #define SBR_WARP_MAX_TRIES 5            /* sequence_model.rs:58 */
 #define SBR_ADAGRAD_EPS 1e-10f          /* wyrm Adagrad eps (recalled) */
-#define SBR_DW_CHUNK_ROWS 1024          /* split-K chunk (rows of the packed minibatch) for dense grads */
+#define SBR_DW_CHUNK_ROWS 1024
+/* Per-row reduction of sparse gradient entries: a row's entries (sorted by packed row, kind) are cut into
+ * chunks of SBR_SEG_CHUNK counted from the row's first entry; a chunk partial is the in-order sum of its
+ * entries (the first one initialises), the row total the in-order sum of the chunk partials.  A row with
+ * at most SBR_SEG_CHUNK entries is therefore a plain in-order sum; the hot rows of a skewed catalogue get
+ * chunk-level parallelism with the same bits everywhere. */
+#define SBR_SEG_CHUNK 256          /* split-K chunk (rows of the packed minibatch) for dense grads */
 #define SBR_F32_MIN (-3.40282347e+38f)  /* Rust std::f32::MIN, evaluation.rs:31 */
 
 /* ---- primitive helpers ---------------------------------------------------------------------- */

@@ -579,6 +579,37 @@ def test_movielens_fit_bit_exact_and_mrr(kind, loss, B, bound):
     assert mg > bound
 
 
+@pytest.mark.parametrize("kind,loss,d,mode", [
+    (ModelKind.EWMA, LOSS_HINGE, 32, "single"),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "single"),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, "replicated"),
+    (ModelKind.EWMA, LOSS_WARP, 64, "partitioned"),
+])
+def test_hot_rows_take_the_chunked_reduction(kind, loss, d, mode):
+    """A tiny catalogue under a big minibatch: every row collects far more than SBR_SEG_CHUNK (256)
+    entries per step, some thousands — the long-segment path (parallel chunk partials, in-order
+    combination) of all three consumers of the sparse reduction, bit for bit against the oracle's
+    sequential statement of the same chunked order."""
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    items, T, users = 9, 14, 700
+    ptr, it = synthetic_interactions(users, items, T + 3, seed=41, zipf=True)
+    world = 1 if mode == "single" else 3
+    hp = hparams(items, T, d, int(kind), loss, epochs=2, B=400, ndev=world)
+    o = OracleModel(hp)
+    lo = o.fit(ptr, it)
+    if mode == "single":
+        g = Model(hp)
+        lg = g.fit(ptr, it)
+        models = [g]
+    else:
+        models = group_create(hp, world, partition_item_table=mode == "partitioned")
+        lg = group_fit(models, ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    for q, m in enumerate(models):
+        assert_params_equal(m, o, kind, f"hot rows {mode} replica {q}")
+
+
 # ---- committed golden vectors: the engine against numbers on disk, no oracle in the loop ------------
 class _EngineGroup:
     """Engine-side adapter with the oracle's model surface: one handle, or a single-process group."""

@@ -1287,15 +1287,56 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        const uint32_t row = (uint32_t)(keys[p] >> 32);
-        if (p > 0 && (uint32_t)(keys[p - 1] >> 32) == row) {
+        // the kernel is bound by dependent memory round trips: fetch the neighbouring keys in ONE trip
+        // (previous key for the head test, the next four for the length of the typical short segment)
+        uint64_t kk[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) kk[i] = keys[p + i < n ? p + i : n - 1];
+        const uint64_t kprev = keys[p > 0 ? p - 1 : 0];
+        const uint32_t row = (uint32_t)(kk[0] >> 32);
+        if (p > 0 && (uint32_t)(kprev >> 32) == row) {
             emit.not_head(p, lg);
             continue;
         }
-        // most segments hold a handful of entries: probe linearly first, then bisect up to the chunk size
         uint64_t end = p + 1;
-        while (end < n && end < p + 4 && (uint32_t)(keys[end] >> 32) == row) ++end;
-        if (end == p + 4 && end < n && (uint32_t)(keys[end] >> 32) == row) {
+#pragma unroll
+        for (int i = 1; i < 5; ++i)
+            if (end == p + i && p + i < n && (uint32_t)(kk[i] >> 32) == row) end = p + i + 1;
+        float4 g;
+        float gb;
+        bool has_b;
+        if (end - p <= 4) { /* the common case: all keys are already in registers, the row loads go out together */
+            float4 v[4];
+            float scl[4];
+            bool bias[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                scl[i] = 0.0f;
+                bias[i] = false;
+                if (p + i < end) {
+                    const uint32_t src = (uint32_t)kk[i];
+                    const uint32_t r = src / 3, kind = src % 3;
+                    v[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
+                    scl[i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
+                    bias[i] = kind != 0;
+                }
+            }
+            g = make_float4(scl[0] * v[0].x, scl[0] * v[0].y, scl[0] * v[0].z, scl[0] * v[0].w);
+            has_b = bias[0];
+            gb = bias[0] ? scl[0] : 0.0f;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                if (p + i < end) {
+                    g.x = g.x + scl[i] * v[i].x; g.y = g.y + scl[i] * v[i].y;
+                    g.z = g.z + scl[i] * v[i].z; g.w = g.w + scl[i] * v[i].w;
+                    if (bias[i]) {
+                        gb = has_b ? gb + scl[i] : scl[i];
+                        has_b = true;
+                    }
+                }
+            }
+        } else {
             const uint64_t hi = p + SBR_SEG_CHUNK + 1 < n ? p + SBR_SEG_CHUNK + 1 : n;
             end = seg_end(keys, end, hi, row);
             if (end - p > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
@@ -1308,11 +1349,8 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
                 }
                 continue;
             }
+            seg_accumulate<D>(blk, keys, p, end, lg, &g, &gb, &has_b);
         }
-        float4 g;
-        float gb;
-        bool has_b;
-        seg_accumulate<D>(blk, keys, p, end, lg, &g, &gb, &has_b);
         emit.template row<D>(row, p, lg, g, has_b, gb);
     }
 }

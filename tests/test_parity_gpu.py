@@ -610,6 +610,71 @@ def test_hot_rows_take_the_chunked_reduction(kind, loss, d, mode):
         assert_params_equal(m, o, kind, f"hot rows {mode} replica {q}")
 
 
+@pytest.mark.parametrize("kind,loss,d", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64),
+    (ModelKind.EWMA, LOSS_WARP, 256),
+])
+def test_many_tiles_per_minibatch(kind, loss, d):
+    """A minibatch of 9 000 sequences = 282 tiles of 32 sequences: more than the 256 slots over which the
+    sequence-resident kernels fold their length-sorted tile list (second fold group reversed), 40+ chunks of
+    1 024 packed rows in the dense-gradient GEMM, and a sparse update with ~10^5 keys — the regime the
+    benchmark runs in, at a size the oracle still finishes in seconds.  Whole-fit parity, bit for bit."""
+    users, items, T, B = 9500, 4001, 7, 9000
+    ptr, it = synthetic_interactions(users, items, T, seed=53, min_len=3)
+    hp = hparams(items, T, d, int(kind), loss, epochs=1, B=B)
+    g, o = make_pair(hp)
+    lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    assert_params_equal(g, o, kind, "many tiles")
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[2] at full size (100 000 users x 1 000 000 items, len <= 64, d = 128, LSTM +
+    WARP, 50 000 sequences per step) is far beyond what the oracle can run, so the checks are
+    size-independent properties: the fit is deterministic (two runs, identical bits of the 488 MiB table),
+    interactions are conserved (examples == sum(len - 1) over the subsequences), the WARP search scores
+    between 1 and 5 negatives per interaction, the same fit over a table held in mapped (virtual-memory)
+    pages gives the same bits, and rows that nothing can have touched keep their initial value."""
+    import zlib
+
+    from bench import synthetic_csr
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    users, items, T, d, B = 100_000, 1_000_000, 64, 128, 50_000
+    ptr, it = synthetic_csr(users, items, T)
+    hp = hparams(items, T, d, int(ModelKind.LSTM_NORMAL), LOSS_WARP, epochs=1, B=B)
+
+    def run():
+        m = Model(hp)
+        e0 = m.get_param(Param.ITEM_EMBEDDING)
+        plan = m.fit_begin(ptr, it)
+        nmb = plan.epoch_prepare()
+        for mb in range(nmb):
+            plan.step(mb)
+        ex, neg = plan.counters()
+        loss, ex_end = plan.end()
+        plan.close()
+        e1 = m.get_param(Param.ITEM_EMBEDDING)
+        m.close()
+        return e0, e1, ex, neg, loss, nmb
+
+    e0, e1, ex, neg, loss, nmb = run()
+    lens = np.diff(ptr.astype(np.int64))
+    assert nmb == 2 and ex == int((lens - 1).sum())            # every user is one subsequence here (len <= T)
+    assert ex <= neg <= 5 * ex and np.isfinite(loss) and loss > 0
+    changed = np.flatnonzero((e0.reshape(items, d) != e1.reshape(items, d)).any(axis=1))
+    assert 0.5 * items < len(changed) <= items                  # ~3.2 M + negatives entries over 1 M rows
+    _, e1b, ex_b, neg_b, loss_b, _ = run()
+    assert (ex_b, neg_b) == (ex, neg) and loss_b == pytest.approx(loss, rel=1e-6)
+    assert zlib.crc32(e1b.tobytes()) == zlib.crc32(e1.tobytes()), "two identical fits differ"
+    # one replica whose table lives in a mapped virtual range (the partitioned layout with a single owner)
+    g = group_create(hp, 1, partition_item_table=True)
+    group_fit(g, ptr, it)
+    assert zlib.crc32(g[0].get_param(Param.ITEM_EMBEDDING).tobytes()) == zlib.crc32(e1.tobytes())
+    g[0].close()
+
+
 # ---- committed golden vectors: the engine against numbers on disk, no oracle in the loop ------------
 class _EngineGroup:
     """Engine-side adapter with the oracle's model surface: one handle, or a single-process group."""

@@ -236,6 +236,32 @@ static void mrr_test_ewma(const std::string& csv) { // ewma.rs:455-487
     CHECK(test_mrr > 0.05f);
 }
 
+// ---- the crate's doctest (lib.rs:22-58): max_sequence_length 32, WARP, builder defaults otherwise ----
+static void crate_doctest(const std::string& csv) {
+    Interactions data = datasets::download_movielens_100k(csv);
+    XorShiftRng rng = XorShiftRng::from_seed(seed42());
+    auto [train, test] = user_based_split(data, rng, 0.2f);
+    const CompressedInteractions train_mat = train.to_compressed(), test_mat = test.to_compressed();
+    std::printf("train_len=%zu test_len=%zu\n", train.len(), test.len());
+    auto model = models::lstm::Hyperparameters::new_(data.num_items(), 32)
+                     .embedding_dim(32)
+                     .learning_rate(0.16f)
+                     .l2_penalty(0.0004f)
+                     .lstm_variant(models::lstm::LSTMVariant::Normal)
+                     .loss(Loss::WARP)
+                     .optimizer(Optimizer::Adagrad)
+                     .num_epochs(10)
+                     .rng(rng)
+                     .build();
+    const float loss = model.fit(train_mat).unwrap();
+    const float train_mrr = mrr_score(model, train_mat).unwrap();
+    std::vector<std::uint32_t> ranks;
+    const float test_mrr = mrr_score(model, test_mat, &ranks).unwrap();
+    std::printf("loss=%.9g loss_bits=%08x train_mrr=%.9g test_mrr=%.9g test_mrr_bits=%08x ranks=%zu ranks_hash=%" PRIu64 "\n",
+                loss, bits(loss), train_mrr, test_mrr, bits(test_mrr), ranks.size(), fnv(ranks.data(), ranks.size() * 4));
+    CHECK(test_mrr > 0.03f && train_mrr > 0.03f); // far above chance (1/1683)
+}
+
 // ---- lstm.rs:520-530 --------------------------------------------------------------------------
 static void empty_interactions() {
     const CompressedInteractions data = Interactions(100, 100).to_compressed();
@@ -335,6 +361,7 @@ int main(int argc, char** argv) {
         else if (which == "mrr_test_two_threads") mrr_test_two_threads(arg);
         else if (which == "mrr_test_warp") mrr_test_warp(arg);
         else if (which == "mrr_test_ewma") mrr_test_ewma(arg);
+        else if (which == "crate_doctest") crate_doctest(arg);
         else {
             std::fprintf(stderr, "unknown case '%s'\n", which.c_str());
             return 2;

@@ -109,18 +109,19 @@ def test_empty_interactions_and_defaults(facade):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,kind,loss,threads", [
-    ("mrr_test_single_thread", ModelKind.LSTM_NORMAL, LOSS_HINGE, 1),  # lstm.rs:451-473
-    ("mrr_test_two_threads", ModelKind.LSTM_NORMAL, LOSS_HINGE, 2),    # lstm.rs:475-497
-    ("mrr_test_warp", ModelKind.LSTM_NORMAL, LOSS_WARP, 1),            # lstm.rs:499-520
-    ("mrr_test_ewma", ModelKind.EWMA, LOSS_HINGE, 1),                  # ewma.rs:455-487
+@pytest.mark.parametrize("case,kind,loss,threads,T,B", [
+    ("mrr_test_single_thread", ModelKind.LSTM_NORMAL, LOSS_HINGE, 1, 128, 8),  # lstm.rs:451-473
+    ("mrr_test_two_threads", ModelKind.LSTM_NORMAL, LOSS_HINGE, 2, 128, 8),    # lstm.rs:475-497
+    ("mrr_test_warp", ModelKind.LSTM_NORMAL, LOSS_WARP, 1, 128, 8),            # lstm.rs:499-520
+    ("mrr_test_ewma", ModelKind.EWMA, LOSS_HINGE, 1, 128, 8),                  # ewma.rs:455-487
+    ("crate_doctest", ModelKind.LSTM_NORMAL, LOSS_WARP, 1, 32, 32),            # lib.rs:22-58 (builder-default minibatch)
 ])
-def test_reference_mrr_tests_in_cpp_match_oracle(facade, movielens_csv, oracle_lib, case, kind, loss, threads):
+def test_reference_mrr_tests_in_cpp_match_oracle(facade, movielens_csv, oracle_lib, case, kind, loss, threads, T, B):
     from oracle.oracle import OracleModel
 
     _, o = run(facade, case, movielens_csv)
     data, train, test, rng = movielens_protocol()
-    hp = hparams(data.num_items(), 128, 32, int(kind), loss, epochs=10, B=8, seed=rng.state_seed(), ndev=threads)
+    hp = hparams(data.num_items(), T, 32, int(kind), loss, epochs=10, B=B, seed=rng.state_seed(), ndev=threads)
     orc = OracleModel(hp)
     loss_o = orc.fit(train.user_pointers, train.item_ids)
     mrr_o, ranks_o = orc.mrr_score(test.user_pointers, test.item_ids)

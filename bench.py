@@ -169,9 +169,12 @@ def main():
     ap.add_argument("--parallelism", choices=["sync", "async"], default="sync",
                     help="multi-GPU step: sync = Parallelism::Synchronous (the reference default); async = the "
                          "staleness-one pipeline (Parallelism::Asynchronous): compute k+1 under the exchange of step k")
-    ap.add_argument("--cpu-threads", type=int, default=32,
-                    help="worker threads of the CPU baseline (capped at the host's cores; each owns a ~1 GB model)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="worker threads of the CPU baseline (capped at the host's cores; each owns a ~1 GB model; "
+                         "on the 256-core GPU host 16 threads gave 416 K interactions/s, 32 threads 322 K)")
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
+    ap.add_argument("--standalone-steps", type=int, default=6,
+                    help="extra untimed steps with stream overlap disabled, for standalone per-kernel times (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -276,8 +279,20 @@ def main():
     else:
         rows_total = rows_timed
     timing = model.timing_read()
-    model.timing_enable(False)
     ex1, neg1 = plan.counters()
+    # Second, UNTIMED pass (single GPU): the same steps with the side-stream work queued on the main stream,
+    # so that every kernel family runs alone — the times behind the per-kernel roofline figures below.  The
+    # timed region above keeps the overlapped schedule and is what `value` reports.
+    standalone, rows_standalone = None, 0
+    if world == 1 and not args.force_exchange and args.standalone_steps > 0:
+        model.set_overlap(False)
+        model.timing_read()
+        for _ in range(args.standalone_steps):
+            rows_standalone += one_step(False)
+        sync()
+        standalone = model.timing_read()
+        model.set_overlap(True)
+    model.timing_enable(False)
 
     if rank == 0:
         d, ng = args.dim, {0: 4, 1: 3, 2: 0}[model_kind]
@@ -312,6 +327,24 @@ def main():
                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
                         "avg_launch_ms": score["ms_per_launch"]}
+        # standalone kernel times (second pass): HBM figure of the sparse update (3 rows x
+        # (gradient source 4d, w and G read, w and G written) + biases = 36d + 24 B per interaction) and MFMA
+        # figures of the three GEMM-shaped kernels without their stream partners
+        kernels_sa = None
+        if standalone:
+            per_row = rows_standalone and {n: ms / rows_standalone for n, (ms, c) in standalone.items() if c}
+            kernels_sa = {"steps": args.standalone_steps, "interactions": rows_standalone,
+                          "ms_per_step": {n: ms / args.standalone_steps for n, (ms, c) in standalone.items() if c}}
+            if "SPARSE_UPDATE" in per_row:
+                gbs = (36 * d + 24) / (per_row["SPARSE_UPDATE"] * 1e-3) / 1e9
+                kernels_sa["sparse_update_hbm"] = {"kernel": "seg_short_kernel (+ hot-row path): per-row reduction + Adagrad read-modify-write",
+                                                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                                   "algorithmic_bytes_per_interaction": 36 * d + 24}
+            if ng:
+                gemm_sa = 2 * 2 * d * ng * d
+                kernels_sa["mfma"] = {fam: {"achieved": gemm_sa / (per_row[fam] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                            "frac": gemm_sa / (per_row[fam] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+                                      for fam in ("RECURRENT_FWD", "RECURRENT_BWD", "DENSE_GRAD") if fam in per_row}
         mfma = []
         if ng:
             gemm = 2 * 2 * d * ng * d  # flop per packed row of one [x;h] x W sized GEMM
@@ -334,7 +367,7 @@ def main():
                                        f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
-            "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels,
+            "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

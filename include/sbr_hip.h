@@ -231,9 +231,13 @@ typedef enum sbr_kernel_family {
     SBR_K_DENSE_UPDATE = 4,
     SBR_K_SPARSE_UPDATE = 5,
     SBR_K_RANK = 6,
-    SBR_K_FAMILIES = 7
+    SBR_K_SPARSE_SORT = 7, /* key build + radix sort of the sparse update (side stream, under the backward pass) */
+    SBR_K_FAMILIES = 8
 } sbr_kernel_family;
 sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable);
+/* enable = 0 queues the side-stream work (key sort, dense-gradient GEMM) on the main stream, so that every
+ * kernel family is timed running alone; results are identical.  Default: overlap on. */
+sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable);
 sbr_status sbr_model_timing_read(sbr_model* m, double* out_ms /*[SBR_K_FAMILIES]*/, uint64_t* out_launches /*[SBR_K_FAMILIES]*/);
 
 

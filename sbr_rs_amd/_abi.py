@@ -61,10 +61,11 @@ class KernelFamily(enum.IntEnum):
     DENSE_UPDATE = 4
     SPARSE_UPDATE = 5
     RANK = 6
+    SPARSE_SORT = 7
 
 
-NUM_KERNEL_FAMILIES = 7
-ABI_VERSION = 2
+NUM_KERNEL_FAMILIES = 8
+ABI_VERSION = 3
 
 
 class SbrHparams(C.Structure):

@@ -58,6 +58,7 @@ def load():
         "sbr_model_set_counters": [vp, C.c_uint64, C.c_uint64],
         "sbr_device_info": [C.c_char_p, C.c_uint64, u32p, u64p],
         "sbr_model_timing_enable": [vp, C.c_int32],
+        "sbr_model_set_overlap": [vp, C.c_int32],
         "sbr_model_timing_read": [vp, C.POINTER(C.c_double), u64p],
         "sbr_set_device": [C.c_int32],
         "sbr_group_fit": [C.POINTER(vp), C.c_uint32, vp, vp, C.c_uint64, fp],
@@ -94,6 +95,6 @@ DECLARED_SYMBOLS = [
     "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_fit_step_scatter", "sbr_fit_step_dense", "sbr_fit_step_owner_reduce", "sbr_fit_step_apply_table", "sbr_model_set_stream", "sbr_model_synchronize",
     "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
     "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_model_get_counters", "sbr_model_set_counters", "sbr_device_info", "sbr_status_string",
-    "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_timing_read", "sbr_set_device", "sbr_group_fit", "sbr_device_count", "sbr_group_create", "sbr_model_is_partitioned", "sbr_selftest_math",
+    "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_set_overlap", "sbr_model_timing_read", "sbr_set_device", "sbr_group_fit", "sbr_device_count", "sbr_group_create", "sbr_model_is_partitioned", "sbr_selftest_math",
     "sbr_selftest_dot_tree", "sbr_selftest_mfma",
 ]

@@ -173,6 +173,7 @@ struct sbr_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scored = nullptr, ev_sorted = nullptr;
     std::mutex mu;
     bool timing = false;
+    bool overlap = true; /* false: the side-stream work is queued on the main stream (standalone kernel timing) */
     std::vector<TimingPair> pending;
     double ms[SBR_K_FAMILIES] = {0};
     uint64_t launches[SBR_K_FAMILIES] = {0};
@@ -349,6 +350,10 @@ struct sbr_fit_plan {
         std::vector<uint32_t> rows_of_dev; /* [num_mb][ndev] */
         DevicePacked dp;
         uint64_t rows_cap = 0, off_cap = 0, seq_cap = 0;
+        /* pinned host staging of the packed index arrays (written directly by the packer, one DMA each) */
+        uint32_t *h_in = nullptr, *h_out = nullptr, *h_ctr = nullptr;
+        int *h_prev = nullptr, *h_steps = nullptr;
+        uint64_t h_rows_cap = 0, h_seq_cap = 0;
         hipEvent_t free_event = nullptr;   /* recorded on the compute stream when the GPU is done with dp */
         bool free_recorded = false;
     } ep[2];
@@ -421,7 +426,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 2; }
+uint32_t sbr_abi_version(void) { return 3; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -678,6 +683,15 @@ sbr_status sbr_model_set_counters(sbr_model* m, uint64_t global_epoch, uint64_t 
     return SBR_OK;
 }
 
+sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipStreamSynchronize(m->side));
+    m->overlap = enable != 0;
+    return SBR_OK;
+}
+
 sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
     m->timing = enable != 0;
@@ -808,6 +822,8 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
         if (p->ep[i].free_event) hipEventDestroy(p->ep[i].free_event);
+        hipHostFree(p->ep[i].h_in); hipHostFree(p->ep[i].h_out); hipHostFree(p->ep[i].h_ctr);
+        hipHostFree(p->ep[i].h_prev); hipHostFree(p->ep[i].h_steps);
     }
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     p->wb.release();
@@ -848,37 +864,89 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
     const uint32_t* ln = p->seq_len.data() + (size_t)p->rank * p->part_len;
     e.mbs.resize(nmb);
     e.off_host.clear();
-    std::vector<int> steps_all, prev_all;
-    std::vector<uint32_t> in_all, out_all, ctr_all;
     uint64_t total_rows = 0;
     for (uint64_t i = 0; i < p->part_len; ++i) total_rows += ln[i] - 1;
-    steps_all.reserve(p->part_len); prev_all.reserve(total_rows);
-    in_all.reserve(total_rows); out_all.reserve(total_rows); ctr_all.reserve(total_rows);
+    if (total_rows > e.h_rows_cap || p->part_len > e.h_seq_cap) {
+        hipHostFree(e.h_in); hipHostFree(e.h_out); hipHostFree(e.h_ctr); hipHostFree(e.h_prev); hipHostFree(e.h_steps);
+        e.h_in = e.h_out = e.h_ctr = nullptr; e.h_prev = e.h_steps = nullptr;
+        e.h_rows_cap = e.h_seq_cap = 0;
+        const size_t rb = (size_t)(total_rows ? total_rows : 1) * 4, sb = (size_t)(p->part_len ? p->part_len : 1) * 4;
+        if (hipHostMalloc(reinterpret_cast<void**>(&e.h_in), rb, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&e.h_out), rb, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&e.h_ctr), rb, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&e.h_prev), rb, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&e.h_steps), sb, hipHostMallocDefault) != hipSuccess)
+            return SBR_ERR_OUT_OF_MEMORY;
+        e.h_rows_cap = total_rows; e.h_seq_cap = p->part_len;
+    }
+    /* The staging buffers are read by the DMA of two epochs ago at the latest, which was waited for below
+     * before that epoch's build returned: they are free.  Packing (time-major, sequences by length
+     * descending, stable): counting sort of the minibatch, then the rows are written in row order — step t
+     * outer, sequence inner — so every output array is filled sequentially; the t range is cut into pieces
+     * of about equal row count for a few worker threads. */
     uint64_t row_base = 0, seq_base = 0;
-    Packed pk;
-    std::vector<const uint32_t*> first;
-    std::vector<int> nsteps;
-    std::vector<uint64_t> ctr_base;
+    const int T = p->T;
+    std::vector<int> cnt(T + 2), pos(T + 2), order;
     for (uint64_t mb = 0; mb < nmb; ++mb) {
         const uint64_t p0 = mb * B, p1 = std::min(p0 + B, p->part_len);
-        first.clear(); nsteps.clear(); ctr_base.clear();
-        for (uint64_t i = p0; i < p1; ++i) {
-            first.push_back(p->items.data() + st[i]);
-            nsteps.push_back((int)ln[i] - 1);
-            ctr_base.push_back(i * (uint64_t)p->T);
+        const int nb = (int)(p1 - p0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int i = 0; i < nb; ++i) cnt[ln[p0 + i] - 1]++;
+        int acc = 0;
+        for (int l = T; l >= 0; --l) { pos[l] = acc; acc += cnt[l]; }
+        order.resize(nb);
+        for (int i = 0; i < nb; ++i) order[pos[ln[p0 + i] - 1]++] = i;
+        int* steps = e.h_steps + seq_base;
+        for (int b = 0; b < nb; ++b) steps[b] = (int)ln[p0 + order[b]] - 1;
+        const int Tm = nb ? steps[0] : 0;
+        const size_t off_base = e.off_host.size();
+        e.off_host.resize(off_base + Tm + 1);
+        int* off = e.off_host.data() + off_base;
+        off[0] = 0;
+        {
+            int alive = nb;
+            for (int t = 0; t < Tm; ++t) {
+                while (alive > 0 && steps[alive - 1] <= t) --alive;
+                off[t + 1] = off[t] + alive;
+            }
         }
-        pack_sequences(first, nsteps, true, &ctr_base, p->T, &pk);
+        const int R = off[Tm];
+        uint32_t *in_idx = e.h_in + row_base, *out_idx = e.h_out + row_base, *ctr = e.h_ctr + row_base;
+        int* prev_row = e.h_prev + row_base;
+        auto fill = [&](int t0, int t1) {
+            for (int t = t0; t < t1; ++t) {
+                const int alive = off[t + 1] - off[t];
+                const int r0 = off[t], rp = t ? off[t - 1] : 0;
+                for (int b = 0; b < alive; ++b) {
+                    const uint64_t src = p0 + (uint64_t)order[b];
+                    const uint32_t* it = p->items.data() + st[src];
+                    in_idx[r0 + b] = it[t];
+                    out_idx[r0 + b] = it[t + 1];
+                    ctr[r0 + b] = (uint32_t)(src * (uint64_t)T + (uint64_t)t);
+                    prev_row[r0 + b] = t ? rp + b : -1;
+                }
+            }
+        };
+        const int nthreads = R > (1 << 18) ? 4 : 1;
+        if (nthreads == 1) fill(0, Tm);
+        else {
+            std::vector<std::thread> workers;
+            int t0 = 0;
+            for (int k = 0; k < nthreads; ++k) {
+                int t1 = t0;
+                const long long target = (long long)R * (k + 1) / nthreads;
+                while (t1 < Tm && off[t1] < target) ++t1;
+                if (k == nthreads - 1) t1 = Tm;
+                if (t1 > t0) workers.emplace_back(fill, t0, t1);
+                t0 = t1;
+            }
+            for (auto& w : workers) w.join();
+        }
         sbr_fit_plan::Mb& d = e.mbs[mb];
-        d.R = pk.R; d.B = pk.B; d.Tm = pk.Tm;
-        d.row_base = row_base; d.seq_base = seq_base; d.off_base = e.off_host.size();
-        e.off_host.insert(e.off_host.end(), pk.off.begin(), pk.off.end());
-        steps_all.insert(steps_all.end(), pk.steps.begin(), pk.steps.end());
-        prev_all.insert(prev_all.end(), pk.prev_row.begin(), pk.prev_row.end());
-        in_all.insert(in_all.end(), pk.in_idx.begin(), pk.in_idx.end());
-        out_all.insert(out_all.end(), pk.out_idx.begin(), pk.out_idx.end());
-        ctr_all.insert(ctr_all.end(), pk.ctr.begin(), pk.ctr.end());
-        row_base += (uint64_t)pk.R;
-        seq_base += (uint64_t)pk.B;
+        d.R = R; d.B = nb; d.Tm = Tm;
+        d.row_base = row_base; d.seq_base = seq_base; d.off_base = off_base;
+        row_base += (uint64_t)R;
+        seq_base += (uint64_t)nb;
     }
     /* the GPU may still be reading this buffer's previous contents (two epochs ago) */
     if (e.free_recorded) {
@@ -896,12 +964,12 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
         e.rows_cap = row_base; e.off_cap = e.off_host.size(); e.seq_cap = seq_base;
     }
     hipStream_t cs = p->copy_stream;
-    HIPCHK(hipMemcpyAsync(e.dp.in_idx, in_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
-    HIPCHK(hipMemcpyAsync(e.dp.out_idx, out_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
-    HIPCHK(hipMemcpyAsync(e.dp.ctr, ctr_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
-    HIPCHK(hipMemcpyAsync(e.dp.prev_row, prev_all.data(), row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.in_idx, e.h_in, row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.out_idx, e.h_out, row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.ctr, e.h_ctr, row_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.prev_row, e.h_prev, row_base * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(hipMemcpyAsync(e.dp.off, e.off_host.data(), e.off_host.size() * 4, hipMemcpyHostToDevice, cs));
-    HIPCHK(hipMemcpyAsync(e.dp.steps, steps_all.data(), seq_base * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(e.dp.steps, e.h_steps, seq_base * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(hipStreamSynchronize(cs));
     return SBR_OK;
 }
@@ -971,27 +1039,28 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
     /* the sort of the sparse-update keys needs only the index arrays and the sampled negatives: it runs
      * on the side stream underneath the backward pass (joined by step_apply / step_scatter) */
+    hipStream_t side = m->overlap ? m->side : m->stream;
     HIPCHK(hipEventRecord(m->ev_scored, m->stream));
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_scored, 0));
+    HIPCHK(hipStreamWaitEvent(side, m->ev_scored, 0));
     {
-        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1, m->side);
-        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, m->side);
+        ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, side);
+        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, side);
     }
-    HIPCHK(hipEventRecord(m->ev_sorted, m->side));
+    HIPCHK(hipEventRecord(m->ev_sorted, side));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }
     /* the dense-gradient GEMM (MFMA-bound, reads dZ / X / H only) goes to the side stream so that the
      * HBM-bound sparse update that follows on the main stream overlaps it; joined in step_apply /
-     * step_scatter before anything reads blk.dense */
+     * step_dense before anything reads blk.dense */
     HIPCHK(hipEventRecord(m->ev_fork, m->stream));
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
     {
-        ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, m->side);
-        sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, m->side);
+        ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
+        sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side);
     }
-    HIPCHK(hipEventRecord(m->ev_join, m->side));
+    HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = true;
     p->last_R = mb.R;
     p->last_block = block;

@@ -1286,59 +1286,70 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int gbase = grp * L;
     for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        // the kernel is bound by dependent memory round trips: fetch the neighbouring keys in ONE trip
-        // (previous key for the head test, the next four for the length of the typical short segment)
-        uint64_t kk[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) kk[i] = keys[p + i < n ? p + i : n - 1];
+        // The kernel is bound by dependent memory round trips, so the keys are fetched cooperatively: lane
+        // lg of the group reads key p + lg (one coalesced load for the whole window of L keys), the group
+        // learns the segment length from a ballot, and the sources of the entries are then broadcast from
+        // the lanes that hold them.  Segments longer than the window fall back to bisection.
+        const bool inb = p + lg < n;
+        const uint64_t kmine = keys[inb ? p + lg : n - 1];
         const uint64_t kprev = keys[p > 0 ? p - 1 : 0];
-        const uint32_t row = (uint32_t)(kk[0] >> 32);
+        const uint32_t hi = (uint32_t)(kmine >> 32), lo = (uint32_t)kmine;
+        const uint32_t row = (uint32_t)__shfl((int)hi, gbase, 64);
+        const unsigned long long bal = __ballot(inb && hi == row);
         if (p > 0 && (uint32_t)(kprev >> 32) == row) {
             emit.not_head(p, lg);
             continue;
         }
-        uint64_t end = p + 1;
-#pragma unroll
-        for (int i = 1; i < 5; ++i)
-            if (end == p + i && p + i < n && (uint32_t)(kk[i] >> 32) == row) end = p + i + 1;
+        const unsigned long long full = L == 64 ? ~0ull : ((1ull << L) - 1ull);
+        const unsigned long long gm = L == 64 ? bal : ((bal >> gbase) & full);
+        const int cnt = gm == full ? L : __ffsll((long long)~gm) - 1; /* leading entries of the window in this row */
         float4 g;
         float gb;
         bool has_b;
-        if (end - p <= 4) { /* the common case: all keys are already in registers, the row loads go out together */
-            float4 v[4];
-            float scl[4];
-            bool bias[4];
+        if ((cnt < L || p + L >= n) && cnt <= SBR_SEG_CHUNK) { /* the whole segment is in the window */
+            g = make_float4(0.f, 0.f, 0.f, 0.f);
+            gb = 0.0f;
+            has_b = false;
+            bool first = true;
+            for (int e = 0; e < cnt; e += 4) {
+                float4 v[4];
+                float scl[4];
+                bool bias[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                scl[i] = 0.0f;
-                bias[i] = false;
-                if (p + i < end) {
-                    const uint32_t src = (uint32_t)kk[i];
-                    const uint32_t r = src / 3, kind = src % 3;
-                    v[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
-                    scl[i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
-                    bias[i] = kind != 0;
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    scl[i] = 0.0f;
+                    bias[i] = false;
+                    if (e + i < cnt) {
+                        const uint32_t src = (uint32_t)__shfl((int)lo, gbase + e + i, 64);
+                        const uint32_t r = src / 3, kind = src % 3;
+                        v[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
+                        scl[i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
+                        bias[i] = kind != 0;
+                    }
                 }
-            }
-            g = make_float4(scl[0] * v[0].x, scl[0] * v[0].y, scl[0] * v[0].z, scl[0] * v[0].w);
-            has_b = bias[0];
-            gb = bias[0] ? scl[0] : 0.0f;
 #pragma unroll
-            for (int i = 1; i < 4; ++i) {
-                if (p + i < end) {
-                    g.x = g.x + scl[i] * v[i].x; g.y = g.y + scl[i] * v[i].y;
-                    g.z = g.z + scl[i] * v[i].z; g.w = g.w + scl[i] * v[i].w;
-                    if (bias[i]) {
-                        gb = has_b ? gb + scl[i] : scl[i];
-                        has_b = true;
+                for (int i = 0; i < 4; ++i) {
+                    if (e + i < cnt) {
+                        if (first) {
+                            g = make_float4(scl[i] * v[i].x, scl[i] * v[i].y, scl[i] * v[i].z, scl[i] * v[i].w);
+                            first = false;
+                        } else {
+                            g.x = g.x + scl[i] * v[i].x; g.y = g.y + scl[i] * v[i].y;
+                            g.z = g.z + scl[i] * v[i].z; g.w = g.w + scl[i] * v[i].w;
+                        }
+                        if (bias[i]) {
+                            gb = has_b ? gb + scl[i] : scl[i];
+                            has_b = true;
+                        }
                     }
                 }
             }
         } else {
-            const uint64_t hi = p + SBR_SEG_CHUNK + 1 < n ? p + SBR_SEG_CHUNK + 1 : n;
-            end = seg_end(keys, end, hi, row);
+            const uint64_t hi_pos = p + SBR_SEG_CHUNK + 1 < n ? p + SBR_SEG_CHUNK + 1 : n;
+            const uint64_t end = seg_end(keys, p + cnt, hi_pos, row);
             if (end - p > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
                 if (lg == 0) {
                     const uint32_t slot = atomicAdd(&sc.counters[0], 1u);

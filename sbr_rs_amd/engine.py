@@ -235,6 +235,10 @@ class Model:
     def timing_enable(self, on: bool = True):
         _check(self._L.sbr_model_timing_enable(self._h, 1 if on else 0))
 
+    def set_overlap(self, on: bool = True):
+        """False: side-stream work runs on the main stream, so kernel families are timed standalone."""
+        _check(self._L.sbr_model_set_overlap(self._h, 1 if on else 0))
+
     def timing_read(self):
         ms = (C.c_double * NUM_KERNEL_FAMILIES)()
         n = (C.c_uint64 * NUM_KERNEL_FAMILIES)()

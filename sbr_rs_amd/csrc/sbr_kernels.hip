@@ -34,6 +34,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_FWD_RT
 #define SBR_FWD_RT 2   /* 16-row tiles per sequence-resident workgroup */
 #endif
+#ifndef SBR_FWD_WPE
+#define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
+#endif
 #ifndef SBR_FWD_UPW
 #define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
 #endif
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
 // another's MFMAs (per-step launches start every workgroup in lockstep and serialise the phases).
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG, int RT, int UPW>
-__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : 3) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles) {
+__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles) {
     constexpr int K2 = 2 * D;
     constexpr int LDA = K2 + 2;
     constexpr int NS = K2 / 16;

@@ -18,10 +18,16 @@ tests/test_parity_gpu.py.)  With N GPUs the user count scales with N (weak scali
 sharded, every GPU runs its own partition, and per step one all-to-all + one all-gather (RCCL)
 of dense per-owner gradient chunks realise the synchronised optimiser step.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the gather + WARP-score kernel against the
-HBM roofline; `kernels` lists every kernel family's measured time; `cpu_baseline` is the CPU
-oracle (a scalar C port of the same algorithm; the Rust reference cannot be built here) timed on
-the host, on a bounded sample of the same workload, rank 0, N = 1 only.
+Prints ONE JSON line (rank 0, the last line of stdout).  `roofline` describes the gather +
+WARP-score kernel against the HBM roofline (`traffic` = PMC bytes, profiles/score_kernel_pmc.json);
+`kernels` lists every kernel family's time inside the timed region (HIP events on the engine's
+streams; concurrent families include each other's contention); `kernels_standalone` comes from a
+second, UNTIMED pass with stream overlap off (N = 1): every family alone, with the sparse update's
+HBM figure and the GEMM-shaped kernels' MFMA figures; `roofline_mfma` are the in-region MFMA
+figures; `cpu_baseline` is the CPU oracle (a scalar C port of the same algorithm; the Rust
+reference cannot be built here) timed on the host, single-thread and on independent worker
+threads, on a bounded sample of the same workload, rank 0, N = 1 only; `test_mrr` is configs[1]
+(MovieLens-100K), untimed.
 """
 from __future__ import annotations
 

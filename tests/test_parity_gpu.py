@@ -675,6 +675,55 @@ def test_full_size_properties():
     g[0].close()
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SBR_FUZZ_SEEDS", "24"))))
+def test_randomised_configurations(seed):
+    """Seeded sweep over the configuration space the fixed cases only sample: model kind, loss, optimiser,
+    dimension, sequence cap, minibatch, catalogue size (tiny = hot rows, large = sparse), number of
+    devices and how they are driven (single model, replicated group, partitioned group), parallelism,
+    hyper-parameters.  Whole-fit parity, bit for bit, plus ranks."""
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    rs = np.random.RandomState(1000 + seed)
+    kind = [ModelKind.EWMA, ModelKind.LSTM_NORMAL, ModelKind.LSTM_COUPLED][rs.randint(3)]
+    loss = [LOSS_BPR, LOSS_HINGE, LOSS_WARP][rs.randint(3)]
+    opt = OPT_ADAM if rs.rand() < 0.3 else 0
+    d = [16, 32, 64, 128, 256][rs.randint(5)]
+    T = int(rs.randint(3, 20))
+    B = int(rs.choice([1, 3, 8, 37, 200]))
+    items = int(rs.choice([5, 40, 300, 5000]))
+    users = int(rs.randint(20, 140))
+    world = int(rs.choice([1, 1, 2, 3]))
+    mode = "single" if world == 1 else ["replicated", "partitioned"][rs.randint(2)]
+    par = PAR_ASYNC if (mode == "replicated" and rs.rand() < 0.5) else PAR_SYNC
+    lr = float(rs.choice([0.01, 0.05, 0.16])) if opt == 0 else 0.01
+    l2 = float(rs.choice([0.0, 1e-4, 4e-4]))
+    epochs = int(rs.randint(1, 4))
+    ptr, it = synthetic_interactions(users, items, T + int(rs.randint(0, 6)), seed=seed, min_len=int(rs.randint(1, 4)),
+                                     zipf=bool(rs.randint(2)))
+    tptr, tit = synthetic_interactions(12, items, T + 2, seed=seed + 77, min_len=1)
+    hp = hparams(items, T, d, int(kind), loss, lr=lr, l2=l2, epochs=epochs, B=B, ndev=world, opt=opt, par=par)
+    what = f"seed {seed}: {kind.name} loss {loss} opt {opt} d {d} T {T} B {B} items {items} users {users} {mode} x{world} par {par}"
+    o = OracleModel(hp)
+    try:
+        lo = o.fit(ptr, it)
+    except OracleError as e:  # e.g. fewer subsequences than devices, or none longer than two items
+        with pytest.raises((EngineError, FittingError)):
+            (Model(hp).fit(ptr, it) if mode == "single" else group_fit(group_create(hp, world, mode == "partitioned"), ptr, it))
+        return
+    if mode == "single":
+        models = [Model(hp)]
+        lg = models[0].fit(ptr, it)
+    else:
+        models = group_create(hp, world, partition_item_table=mode == "partitioned")
+        lg = group_fit(models, ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6, abs=1e-9), what
+    for m in models:
+        assert_params_equal(m, o, kind, what)
+    mg, rg = models[-1].mrr_score(tptr, tit)
+    mo, ro = o.mrr_score(tptr, tit)
+    assert np.array_equal(rg, ro) and mg == mo, what
+
+
 # ---- committed golden vectors: the engine against numbers on disk, no oracle in the loop ------------
 class _EngineGroup:
     """Engine-side adapter with the oracle's model surface: one handle, or a single-process group."""

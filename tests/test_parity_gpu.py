@@ -675,6 +675,20 @@ def test_full_size_properties():
     g[0].close()
 
 
+@pytest.mark.parametrize("kind,d", [(ModelKind.LSTM_NORMAL, 128), (ModelKind.EWMA, 32), (ModelKind.LSTM_COUPLED, 256)])
+def test_long_sequences(kind, d):
+    """max_sequence_length 300 with users of up to 700 interactions: several chunks per user (short chunk
+    first, data.rs:406-431), 299 dependent time steps inside one kernel launch, minibatches whose tiles differ
+    in length by two orders of magnitude."""
+    ptr, it = synthetic_interactions(40, 500, 700, seed=61, min_len=1, zipf=True)
+    hp = hparams(500, 300, d, int(kind), LOSS_WARP, epochs=1, B=16)
+    g, o = make_pair(hp)
+    assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+    assert_params_equal(g, o, kind, "long sequences")
+    hist = it[int(ptr[3]):int(ptr[4])]
+    assert_same_bits(g.user_representation(hist), o.user_representation(hist), "user_representation of a long history")
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SBR_FUZZ_SEEDS", "24"))))
 def test_randomised_configurations(seed):
     """Seeded sweep over the configuration space the fixed cases only sample: model kind, loss, optimiser,

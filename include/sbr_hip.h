@@ -188,6 +188,29 @@ sbr_status sbr_device_count(int32_t* out_count);
 sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, sbr_model** out_models);
 sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out);
 
+/* The partitioned item table under ONE PROCESS PER GPU (the launcher model of bench.py --gpus N).  Every
+ * process creates its model with the same hyper-parameters (num_devices = world, device_rank = its rank) on
+ * its own device; the shared virtual range is planned identically everywhere and the parts (runs of pages)
+ * homed on this rank are allocated.  The host then passes file descriptors between the processes
+ * (SCM_RIGHTS over a Unix socket; sbr_rs_amd/partitioned.py): every part is exported by its home rank and
+ * imported by all the others; sbr_partition_finalize then writes this rank's rows (the seeded initial
+ * embeddings, zeroed optimiser state).  The fit is sequenced by the host:
+ *   sbr_fit_lists_export / _import   once per plan: the ranks' gradient lists become readable by their peers
+ *   per step: sbr_fit_step_local -> sbr_fit_step_reduce_own (returns this rank's owner bounds; stream
+ *   drained) -> all-gather of the bounds and of the dense blocks -> sbr_fit_step_owner_apply (stream
+ *   drained) -> barrier.
+ * Same bits as sbr_group_fit over a partitioned group and as the replicated Synchronous exchange. */
+sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out);
+sbr_status sbr_partition_num_parts(const sbr_model* m, uint32_t* out);
+sbr_status sbr_partition_part_info(const sbr_model* m, uint32_t part, uint32_t* out_home_rank, uint64_t* out_bytes);
+sbr_status sbr_partition_export_part(sbr_model* m, uint32_t part, int32_t* out_fd);
+sbr_status sbr_partition_import_part(sbr_model* m, uint32_t part, int32_t fd);
+sbr_status sbr_partition_finalize(sbr_model* m);
+sbr_status sbr_fit_lists_export(sbr_fit_plan* p, int32_t out_fds[4], uint64_t out_bytes[4]);
+sbr_status sbr_fit_lists_import(sbr_fit_plan* p, uint32_t peer_rank, const int32_t fds[4], const uint64_t bytes[4]);
+sbr_status sbr_fit_step_reduce_own(sbr_fit_plan* p, uint64_t minibatch, uint32_t* host_bounds, void* device_dense_out);
+sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds, const void* device_dense_all);
+
 /* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
 sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);
 sbr_status sbr_model_synchronize(sbr_model* m);

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -74,35 +75,107 @@ struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
 }  // namespace
 
-/* The item table of a partitioned group: ONE virtual address range per array (hipMemAddressReserve)
+/* hipMemImportFromShareableHandle takes the POSIX file descriptor in its `void* osHandle` argument, and
+ * the two HIP runtimes this library meets disagree on how: the runtime PyTorch bundles (ROCm 7.0) reads an
+ * int THROUGH the pointer, the system runtime (ROCm 7.2) takes the descriptor VALUE cast to a pointer.
+ * Passing a pointer is safe on both (7.2 rejects it with hipErrorInvalidValue), passing the value crashes
+ * 7.0 — so: pointer first, value only after a clean rejection. */
+static hipError_t import_shareable_fd(hipMemGenericAllocationHandle_t* handle, int fd) {
+    int fd_copy = fd;
+    hipError_t e = hipMemImportFromShareableHandle(handle, &fd_copy, hipMemHandleTypePosixFileDescriptor);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    return hipMemImportFromShareableHandle(handle, reinterpret_cast<void*>(static_cast<uintptr_t>(fd)), hipMemHandleTypePosixFileDescriptor);
+}
+
+/* A device buffer made of one HIP virtual-memory allocation, so that it can be handed to another process
+ * as a file descriptor (hipMemExportToShareableHandle) and mapped there. */
+struct VmmBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipMemGenericAllocationHandle_t h{};
+    bool have = false;
+
+    static size_t granularity(int device) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        prop.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+        size_t g = 0;
+        if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess) return 0;
+        return g;
+    }
+    sbr_status map_access(int device) {
+        if (hipMemAddressReserve(&ptr, bytes, 0, nullptr, 0) != hipSuccess) { ptr = nullptr; return SBR_ERR_OUT_OF_MEMORY; }
+        if (hipMemMap(ptr, bytes, 0, h, 0) != hipSuccess) return SBR_ERR_HIP;
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = device;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (hipMemSetAccess(ptr, bytes, &acc, 1) != hipSuccess) return SBR_ERR_UNSUPPORTED;
+        return SBR_OK;
+    }
+    sbr_status alloc(size_t want, int device) {
+        const size_t g = granularity(device);
+        if (!g) return SBR_ERR_UNSUPPORTED;
+        bytes = (want + g - 1) / g * g;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        prop.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+        if (hipMemCreate(&h, bytes, &prop, 0) != hipSuccess) return SBR_ERR_OUT_OF_MEMORY;
+        have = true;
+        return map_access(device);
+    }
+    sbr_status export_fd(int* fd) const {
+        if (!have) return SBR_ERR_INVALID_ARGUMENT;
+        if (hipMemExportToShareableHandle(fd, h, hipMemHandleTypePosixFileDescriptor, 0) != hipSuccess) return SBR_ERR_HIP;
+        return SBR_OK;
+    }
+    sbr_status import_fd(int fd, size_t nbytes, int device) {
+        if (import_shareable_fd(&h, fd) != hipSuccess) return SBR_ERR_HIP;
+        have = true;
+        bytes = nbytes;
+        return map_access(device);
+    }
+    void release() {
+        if (ptr) { (void)hipMemUnmap(ptr, bytes); (void)hipMemAddressFree(ptr, bytes); ptr = nullptr; }
+        if (have) { (void)hipMemRelease(h); have = false; }
+    }
+};
+
+/* The item table of a partitioned model: ONE virtual address range per array (hipMemAddressReserve)
  * whose physical pages live on the owners' devices (hipMemCreate per run of pages, hipMemMap), readable
- * and writable from every device of the group (hipMemSetAccess; remote pages travel over xGMI).  All
- * replicas therefore use the same table pointers and the same global row ids — the kernels of the hot
- * path are unchanged — while each row is stored once and updated only by its owner. */
+ * and writable from every device (hipMemSetAccess; remote pages travel over xGMI).  All replicas therefore
+ * use the same table layout and the same global row ids — the kernels of the hot path are unchanged — while
+ * each row is stored once and updated only by its owner.  Two deployments: a single-process group creates
+ * every part itself (local_rank < 0); under one process per GPU each process creates the parts homed on its
+ * rank and maps the others from file descriptors its peers exported. */
 struct SharedTable {
-    struct Part { hipMemGenericAllocationHandle_t h; size_t off, bytes; };
+    struct Part { hipMemGenericAllocationHandle_t h{}; size_t off = 0, bytes = 0; int home = 0; bool have = false, mapped = false; };
     void* base = nullptr;
     size_t total = 0;
     std::vector<Part> parts;
     float *E = nullptr, *Eacc = nullptr, *Em = nullptr, *b = nullptr, *bacc = nullptr, *bm = nullptr;
+    int local_rank = -1;
+    uint64_t slice = 0;
 
     ~SharedTable() {
         for (auto& pt : parts) {
-            (void)hipMemUnmap(reinterpret_cast<char*>(base) + pt.off, pt.bytes);
-            (void)hipMemRelease(pt.h);
+            if (pt.mapped) (void)hipMemUnmap(reinterpret_cast<char*>(base) + pt.off, pt.bytes);
+            if (pt.have) (void)hipMemRelease(pt.h);
         }
         if (base) (void)hipMemAddressFree(base, total);
     }
 
-    /* devices[r] = HIP device of replica r; rows [r*S, (r+1)*S) belong to replica r */
-    sbr_status create(uint64_t num_items, uint64_t d, bool adam, const std::vector<int>& devices, uint64_t S) {
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = devices[0];
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
-            return SBR_ERR_UNSUPPORTED;
+    /* layout: identical on every rank.  A page goes to the rank that owns its first row (rows [r*S, (r+1)*S)
+     * belong to rank r); runs of pages with the same home are one part. */
+    sbr_status plan(uint64_t num_items, uint64_t d, bool adam, int nranks, uint64_t S, int device) {
+        slice = S;
+        const size_t gran = VmmBuf::granularity(device);
+        if (!gran) return SBR_ERR_UNSUPPORTED;
         struct Arr { float** ptr; uint64_t row_bytes; bool on; };
         Arr arrs[6] = {{&E, d * 4, true}, {&Eacc, d * 4, true}, {&Em, d * 4, adam}, {&b, 4, true}, {&bacc, 4, true}, {&bm, 4, adam}};
         size_t off[6], bytes[6];
@@ -116,33 +189,59 @@ struct SharedTable {
         for (int a = 0; a < 6; ++a) {
             if (!arrs[a].on) continue;
             *arrs[a].ptr = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off[a]);
-            /* a page goes to the device of the replica that owns its first row; runs of pages with the
-             * same home become one physical allocation */
             const size_t npages = bytes[a] / gran;
-            size_t run_begin = 0;
             auto home = [&](size_t page) {
                 const uint64_t row = (uint64_t)(page * gran) / arrs[a].row_bytes;
                 uint64_t owner = row / S;
-                if (owner >= devices.size()) owner = devices.size() - 1;
-                return devices[owner];
+                if (owner >= (uint64_t)nranks) owner = (uint64_t)nranks - 1;
+                return (int)owner;
             };
+            size_t run_begin = 0;
             while (run_begin < npages) {
-                const int dev = home(run_begin);
+                const int hm = home(run_begin);
                 size_t run_end = run_begin + 1;
-                while (run_end < npages && home(run_end) == dev) ++run_end;
+                while (run_end < npages && home(run_end) == hm) ++run_end;
                 Part pt;
                 pt.off = off[a] + run_begin * gran;
                 pt.bytes = (run_end - run_begin) * gran;
-                prop.location.id = dev;
-                if (hipMemCreate(&pt.h, pt.bytes, &prop, 0) != hipSuccess) return SBR_ERR_OUT_OF_MEMORY;
-                if (hipMemMap(reinterpret_cast<char*>(base) + pt.off, pt.bytes, 0, pt.h, 0) != hipSuccess) {
-                    (void)hipMemRelease(pt.h);
-                    return SBR_ERR_HIP;
-                }
+                pt.home = hm;
                 parts.push_back(pt);
                 run_begin = run_end;
             }
         }
+        return SBR_OK;
+    }
+
+    /* physical allocation + mapping of the parts this process is responsible for */
+    sbr_status create_parts(const std::vector<int>& device_of_rank) {
+        for (auto& pt : parts) {
+            if (local_rank >= 0 && pt.home != local_rank) continue;
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = device_of_rank[pt.home];
+            prop.requestedHandleTypes = hipMemHandleTypePosixFileDescriptor;
+            if (hipMemCreate(&pt.h, pt.bytes, &prop, 0) != hipSuccess) return SBR_ERR_OUT_OF_MEMORY;
+            pt.have = true;
+            if (hipMemMap(reinterpret_cast<char*>(base) + pt.off, pt.bytes, 0, pt.h, 0) != hipSuccess) return SBR_ERR_HIP;
+            pt.mapped = true;
+        }
+        return SBR_OK;
+    }
+
+    sbr_status import_part(uint32_t i, int fd) {
+        if (i >= parts.size() || parts[i].mapped) return SBR_ERR_INVALID_ARGUMENT;
+        Part& pt = parts[i];
+        if (import_shareable_fd(&pt.h, fd) != hipSuccess) return SBR_ERR_HIP;
+        pt.have = true;
+        if (hipMemMap(reinterpret_cast<char*>(base) + pt.off, pt.bytes, 0, pt.h, 0) != hipSuccess) return SBR_ERR_HIP;
+        pt.mapped = true;
+        return SBR_OK;
+    }
+
+    sbr_status set_access(const std::vector<int>& devices) {
+        for (const auto& pt : parts)
+            if (!pt.mapped) return SBR_ERR_INVALID_ARGUMENT; /* a peer's part has not been imported yet */
         std::vector<int> uniq(devices);
         std::sort(uniq.begin(), uniq.end());
         uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
@@ -155,6 +254,13 @@ struct SharedTable {
         if (hipMemSetAccess(base, total, acc.data(), acc.size()) != hipSuccess) return SBR_ERR_UNSUPPORTED;
         return SBR_OK;
     }
+
+    /* single-process group: devices[r] = HIP device of replica r */
+    sbr_status create(uint64_t num_items, uint64_t d, bool adam, const std::vector<int>& devices, uint64_t S) {
+        SBRCHK(plan(num_items, d, adam, (int)devices.size(), S, devices[0]));
+        SBRCHK(create_parts(devices));
+        return set_access(devices);
+    }
 };
 
 struct sbr_model {
@@ -165,6 +271,8 @@ struct sbr_model {
     sbr::ModelView mv;
     sbr_xorshift rng;
     sbr_xorshift rng_after_table; /* RNG state right after the item-table initialisation */
+    std::vector<float> pending_E;  /* process-per-GPU partitioned table: this rank's rows until sbr_partition_finalize */
+    bool partition_finalized = true;
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     hipStream_t stream = nullptr;
@@ -378,6 +486,11 @@ struct sbr_fit_plan {
      * bounds, and the owner-side merge buffers */
     float *glist = nullptr, *gblist = nullptr;
     uint32_t *gfl = nullptr, *bounds_dev = nullptr;
+    /* one process per GPU: the list (and the sorted keys) live in exportable allocations, the peers' lists
+     * are mapped from the file descriptors they exported: [0] keys_sorted [1] glist [2] gblist [3] gfl */
+    bool exportable_lists = false;
+    VmmBuf own_x[4];
+    std::vector<std::array<VmmBuf, 4>> peer_x;
     uint64_t *mkeys = nullptr, *mkeys_sorted = nullptr;
     void* msort_temp = nullptr;
     size_t msort_temp_bytes = 0;
@@ -459,7 +572,8 @@ sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out
 
 /* shared != null: the table arrays are the group's SharedTable; only the replica with write_table
  * initialises them, the others take the RNG state that follows the table initialisation */
-static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<SharedTable> shared, bool write_table,
+enum TableInit { TABLE_WRITE_ALL = 0, TABLE_WRITE_NONE = 1, TABLE_OWN_ROWS_DEFERRED = 2 };
+static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<SharedTable> shared, int table_init,
                                     const sbr_xorshift* rng_after_table, sbr_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -512,7 +626,7 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
     }
     /* ≙ build_params (lstm.rs:174-194): embeddings first, then the recurrent weights, same RNG */
     sbr_xs_seed(&m->rng, hp->seed);
-    if (!shared || write_table) {
+    if (!shared || table_init == TABLE_WRITE_ALL) {
         if (adam) {
             hipMemsetAsync(v.Em, 0, I * d * 4, m->stream);
             hipMemsetAsync(v.bm, 0, I * 4, m->stream);
@@ -525,6 +639,19 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         const double std_e = 1.0 / (double)d;
         for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_e);
         if (hipMemcpy(v.E, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
+    } else if (table_init == TABLE_OWN_ROWS_DEFERRED) {
+        /* every rank walks the whole initialisation stream (the RNG has no skip-ahead through the normal
+         * sampler's rejections) and keeps the rows it owns; they are written once the peers' parts are mapped */
+        const uint64_t S = shared->slice, r0 = std::min<uint64_t>(I, (uint64_t)hp->device_rank * S), r1 = std::min<uint64_t>(I, r0 + S);
+        m->pending_E.resize((size_t)((r1 - r0) * d));
+        Normal nrm{&m->rng};
+        const double std_e = 1.0 / (double)d;
+        for (uint64_t i = 0; i < I * d; ++i) {
+            const float val = (float)(nrm.next() * std_e);
+            const uint64_t row = i / d;
+            if (row >= r0 && row < r1) m->pending_E[(size_t)(i - r0 * d)] = val;
+        }
+        m->partition_finalized = false;
     } else {
         m->rng = *rng_after_table;
     }
@@ -568,7 +695,7 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
 }
 
 sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
-    return model_create_impl(hp, nullptr, true, nullptr, out);
+    return model_create_impl(hp, nullptr, TABLE_WRITE_ALL, nullptr, out);
 }
 
 void sbr_model_destroy(sbr_model* m) {
@@ -781,7 +908,15 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     while ((1ull << item_bits) < (uint64_t)m->hp.num_items) ++item_bits;
     p->key_bits = 32 + item_bits;
     if (st == SBR_OK) st = dmalloc(&p->keys, max_entries);
-    if (st == SBR_OK) st = dmalloc(&p->keys_sorted, max_entries);
+    p->exportable_lists = m->shared && m->shared->local_rank >= 0;
+    if (st == SBR_OK) {
+        if (p->exportable_lists) {
+            st = p->own_x[0].alloc(max_entries * sizeof(uint64_t), m->device);
+            p->keys_sorted = reinterpret_cast<uint64_t*>(p->own_x[0].ptr);
+        } else {
+            st = dmalloc(&p->keys_sorted, max_entries);
+        }
+    }
     if (st == SBR_OK) {
         p->sort_temp_bytes = sbr::sparse_sort_temp_bytes(max_entries, p->key_bits);
         uint8_t* tmp = nullptr;
@@ -827,6 +962,11 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     }
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     p->wb.release();
+    if (p->exportable_lists) { /* the sorted keys and the list are virtual-memory allocations, not hipMalloc'ed */
+        for (auto& px : p->peer_x) for (auto& b : px) b.release();
+        for (auto& b : p->own_x) b.release();
+        p->keys_sorted = nullptr; p->glist = p->gblist = nullptr; p->gfl = nullptr;
+    }
     hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
     hipFree(p->loss_acc); hipFree(p->ex_acc);
     hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
@@ -1189,9 +1329,19 @@ static sbr_status partition_buffers(sbr_fit_plan* p) {
     if (p->glist) return SBR_OK;
     const uint64_t cap = 3 * p->rmax;
     if (cap >= (1ull << 28)) return SBR_ERR_UNSUPPORTED; /* list positions are 28-bit in the merge keys */
-    SBRCHK(dmalloc(&p->glist, cap * (uint64_t)p->m->d));
-    SBRCHK(dmalloc(&p->gblist, cap));
-    SBRCHK(dmalloc(&p->gfl, cap));
+    if (p->exportable_lists) {
+        const int dev = p->m->device;
+        SBRCHK(p->own_x[1].alloc(cap * (uint64_t)p->m->d * 4, dev));
+        SBRCHK(p->own_x[2].alloc(cap * 4, dev));
+        SBRCHK(p->own_x[3].alloc(cap * 4, dev));
+        p->glist = reinterpret_cast<float*>(p->own_x[1].ptr);
+        p->gblist = reinterpret_cast<float*>(p->own_x[2].ptr);
+        p->gfl = reinterpret_cast<uint32_t*>(p->own_x[3].ptr);
+    } else {
+        SBRCHK(dmalloc(&p->glist, cap * (uint64_t)p->m->d));
+        SBRCHK(dmalloc(&p->gblist, cap));
+        SBRCHK(dmalloc(&p->gfl, cap));
+    }
     SBRCHK(dmalloc(&p->bounds_dev, 17));
     return SBR_OK;
 }
@@ -1286,6 +1436,71 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
     sbr_fit_plan_destroy(p);
     return st;
+}
+
+/* ---- one process per GPU over a partitioned table: the step halves the host sequences -----------------
+ *   sbr_fit_step_local; sbr_fit_step_reduce_own (list + dense block; returns the owner bounds on the host,
+ *   stream drained: this process has finished READING the table)  -> host: all-gather of the bounds and of
+ *   the dense blocks (a rendezvous: every process has finished reading)  -> sbr_fit_step_owner_apply (merge
+ *   of the peers' lists over this rank's rows, in-place update, stream drained)  -> host: barrier. */
+sbr_status sbr_fit_lists_export(sbr_fit_plan* p, int32_t out_fds[4], uint64_t out_bytes[4]) {
+    if (!p || !out_fds || !out_bytes || !p->exportable_lists) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    SBRCHK(partition_buffers(p));
+    for (int i = 0; i < 4; ++i) {
+        int fd = -1;
+        SBRCHK(p->own_x[i].export_fd(&fd));
+        out_fds[i] = fd;
+        out_bytes[i] = p->own_x[i].bytes;
+    }
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_lists_import(sbr_fit_plan* p, uint32_t peer_rank, const int32_t fds[4], const uint64_t bytes[4]) {
+    if (!p || !fds || !bytes || !p->exportable_lists || (int)peer_rank >= p->ndev || (int)peer_rank == p->rank)
+        return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    if (p->peer_x.empty()) p->peer_x.resize(p->ndev);
+    for (int i = 0; i < 4; ++i) SBRCHK(p->peer_x[peer_rank][i].import_fd(fds[i], bytes[i], p->m->device));
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_reduce_own(sbr_fit_plan* p, uint64_t minibatch, uint32_t* host_bounds, void* device_dense_out) {
+    if (!p || !host_bounds || !device_dense_out || !p->m->shared || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(partition_reduce_own(p, minibatch));
+    SBRCHK(sbr_fit_step_dense(p, device_dense_out));
+    HIPCHK(hipStreamSynchronize(p->m->stream));
+    HIPCHK(hipMemcpy(host_bounds, p->bounds_dev, (p->ndev + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds, const void* device_dense_all) {
+    if (!p || !all_bounds || !device_dense_all || !p->exportable_lists) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const int n = p->ndev, q = p->rank;
+    sbr::PeerLists pl;
+    std::memset(&pl, 0, sizeof(pl));
+    uint32_t total = 0;
+    for (int r = 0; r < n; ++r) {
+        if (r == q) {
+            pl.keys[r] = p->keys_sorted; pl.G[r] = p->glist; pl.gb[r] = p->gblist; pl.fl[r] = p->gfl;
+        } else {
+            if (p->peer_x.empty() || !p->peer_x[r][0].ptr) return SBR_ERR_INVALID_ARGUMENT; /* lists of rank r not imported */
+            pl.keys[r] = reinterpret_cast<const uint64_t*>(p->peer_x[r][0].ptr);
+            pl.G[r] = reinterpret_cast<const float*>(p->peer_x[r][1].ptr);
+            pl.gb[r] = reinterpret_cast<const float*>(p->peer_x[r][2].ptr);
+            pl.fl[r] = reinterpret_cast<const uint32_t*>(p->peer_x[r][3].ptr);
+        }
+        pl.lo[r] = all_bounds[(size_t)r * (n + 1) + q];
+        pl.base[r] = total;
+        total += all_bounds[(size_t)r * (n + 1) + q + 1] - pl.lo[r];
+    }
+    for (int r = n; r <= 16; ++r) pl.base[r] = total;
+    SBRCHK(apply_dense_blocks(p, device_dense_all));
+    SBRCHK(partition_owner_apply(p, pl, total));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return SBR_OK;
 }
 
 /* Single-process multi-device fit: the in-process analogue of fit with num_threads(n)
@@ -1532,7 +1747,8 @@ sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, s
         h.num_devices = n;
         h.device_rank = r;
         if (hipSetDevice(devices[r]) != hipSuccess) { st = SBR_ERR_HIP; break; }
-        st = model_create_impl(&h, shared, r == 0, r ? &out_models[0]->rng_after_table : nullptr, &out_models[r]);
+        st = model_create_impl(&h, shared, r == 0 ? TABLE_WRITE_ALL : TABLE_WRITE_NONE, r ? &out_models[0]->rng_after_table : nullptr,
+                               &out_models[r]);
     }
     (void)hipSetDevice(devices[0]);
     if (st != SBR_OK)
@@ -1543,6 +1759,84 @@ sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, s
 sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out) {
     if (!m || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = m->shared ? 1 : 0;
+    return SBR_OK;
+}
+
+/* ---- partitioned item table under ONE PROCESS PER GPU --------------------------------------------------
+ * Every process calls sbr_model_create_partitioned with the same hyper-parameters (num_devices = world,
+ * device_rank = its rank) on its own device: the layout of the shared virtual range is planned identically
+ * everywhere, the parts homed on this rank are allocated and mapped.  The host then moves file descriptors:
+ * sbr_partition_export_part for own parts -> the peers' sbr_partition_import_part (Unix-socket SCM_RIGHTS;
+ * sbr_rs_amd/partitioned.py), and sbr_partition_finalize writes this rank's rows. */
+sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out) {
+    if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->num_devices == 0 || hp->num_devices > 16 ||
+        hp->device_rank >= hp->num_devices)
+        return SBR_ERR_INVALID_ARGUMENT;
+    int ndevices = 0, device = 0;
+    if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
+    HIPCHK(hipGetDevice(&device));
+    auto shared = std::make_shared<SharedTable>();
+    shared->local_rank = (int)hp->device_rank;
+    const uint64_t S = ((uint64_t)hp->num_items + hp->num_devices - 1) / hp->num_devices;
+    SBRCHK(shared->plan(hp->num_items, hp->embedding_dim, hp->optimizer == SBR_OPT_ADAM, (int)hp->num_devices, S, device));
+    std::vector<int> device_of_rank(hp->num_devices, device); /* only this rank's entry is used */
+    SBRCHK(shared->create_parts(device_of_rank));
+    return model_create_impl(hp, shared, TABLE_OWN_ROWS_DEFERRED, nullptr, out);
+}
+
+sbr_status sbr_partition_num_parts(const sbr_model* m, uint32_t* out) {
+    if (!m || !m->shared || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = (uint32_t)m->shared->parts.size();
+    return SBR_OK;
+}
+
+sbr_status sbr_partition_part_info(const sbr_model* m, uint32_t part, uint32_t* out_home_rank, uint64_t* out_bytes) {
+    if (!m || !m->shared || part >= m->shared->parts.size()) return SBR_ERR_INVALID_ARGUMENT;
+    if (out_home_rank) *out_home_rank = (uint32_t)m->shared->parts[part].home;
+    if (out_bytes) *out_bytes = m->shared->parts[part].bytes;
+    return SBR_OK;
+}
+
+sbr_status sbr_partition_export_part(sbr_model* m, uint32_t part, int32_t* out_fd) {
+    if (!m || !m->shared || !out_fd || part >= m->shared->parts.size()) return SBR_ERR_INVALID_ARGUMENT;
+    SharedTable::Part& pt = m->shared->parts[part];
+    if (!pt.have || pt.home != m->shared->local_rank) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    int fd = -1;
+    HIPCHK(hipMemExportToShareableHandle(&fd, pt.h, hipMemHandleTypePosixFileDescriptor, 0));
+    *out_fd = fd;
+    return SBR_OK;
+}
+
+sbr_status sbr_partition_import_part(sbr_model* m, uint32_t part, int32_t fd) {
+    if (!m || !m->shared || m->shared->local_rank < 0) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    return m->shared->import_part(part, fd);
+}
+
+sbr_status sbr_partition_finalize(sbr_model* m) {
+    if (!m || !m->shared || m->shared->local_rank < 0) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->partition_finalized) return SBR_OK;
+    SBRCHK(ensure_device(m));
+    SBRCHK(m->shared->set_access(std::vector<int>{m->device}));
+    const sbr::ModelView& v = m->mv;
+    const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, S = m->shared->slice;
+    const uint64_t r0 = std::min<uint64_t>(I, (uint64_t)m->hp.device_rank * S), r1 = std::min<uint64_t>(I, r0 + S), nr = r1 - r0;
+    if (nr) {
+        HIPCHK(hipMemcpy(v.E + r0 * d, m->pending_E.data(), nr * d * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(v.Eacc + r0 * d, 0, nr * d * 4));
+        HIPCHK(hipMemset(v.b + r0, 0, nr * 4));
+        HIPCHK(hipMemset(v.bacc + r0, 0, nr * 4));
+        if (m->hp.optimizer == SBR_OPT_ADAM) {
+            HIPCHK(hipMemset(v.Em + r0 * d, 0, nr * d * 4));
+            HIPCHK(hipMemset(v.bm + r0, 0, nr * 4));
+        }
+    }
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float>().swap(m->pending_E);
+    m->partition_finalized = true;
     return SBR_OK;
 }
 

@@ -89,6 +89,13 @@ class _HyperparametersBase:
         table is partitioned (the replicas must then be created together)."""
         hp = self._hparams(model_kind, device_rank)
         if getattr(self, "_partition", False):
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self._num_threads > 1:
+                # one process per GPU: this process owns the rows of its rank, the peers' rows are mapped
+                from .partitioned import create_partitioned_model
+
+                return create_partitioned_model(self._hparams(model_kind, dist.get_rank())), None
             from .engine import group_create
 
             group = group_create(hp, self._num_threads, partition_item_table=True)
@@ -162,8 +169,12 @@ class _ImplicitSequenceModel:
             return self.params.fit(interactions.user_pointers, interactions.item_ids)
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and not self.params.is_partitioned():
+        if dist.is_available() and dist.is_initialized() and getattr(self, "_peers", None) is None:
             # one process per GPU (torchrun): this process drives replica hp.device_rank
+            if self.params.is_partitioned():
+                from .partitioned import fit_partitioned
+
+                return fit_partitioned(self.params, interactions)
             from .distributed import fit_distributed
 
             return fit_distributed(self.params, interactions)

@@ -1,0 +1,178 @@
+"""Partitioned item table under one process per GPU (the launcher model of ``bench.py --gpus N``).
+
+Every rank holds the rows ``[r*S, (r+1)*S)`` of the item table on its own device; the whole table is one
+virtual address range in every process (HIP virtual memory management), the peers' parts being mapped
+from file descriptors that travel over Unix sockets (``SCM_RIGHTS``).  The unchanged gather kernels read
+remote rows through that mapping (xGMI); every row is updated by its owner from the ranks' gradient
+lists, which are shared the same way.  Results are bit-identical to the single-process partitioned group
+(``sbr_group_fit``) and to the replicated Synchronous exchange.
+
+torch.distributed supplies the control plane only (rendezvous, two small all-gathers and one barrier per
+step); the bulk data never goes through a collective.
+"""
+from __future__ import annotations
+
+import array
+import ctypes as C
+import json
+import os
+import socket
+import tempfile
+
+import numpy as np
+
+from . import _lib
+from .engine import FitPlan, Model, _check
+
+
+def _send_fds(path: str, payload: dict, fds) -> None:
+    with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as s:
+        s.connect(path)
+        socket.send_fds(s, [json.dumps(payload).encode()], list(fds))
+
+
+def _recv_fds(server: socket.socket, maxfds: int):
+    conn, _ = server.accept()
+    with conn:
+        msg, fds, _flags, _addr = socket.recv_fds(conn, 1 << 16, maxfds)
+        return json.loads(msg.decode()), list(fds)
+
+
+class _FdExchange:
+    """All-to-all of file descriptors between the ranks of one node."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        box = [tempfile.mkdtemp(prefix="sbr_fd_") if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.dir = box[0]
+        self.server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        self.server.bind(self._path(self.rank))
+        self.server.listen(self.world)
+        dist.barrier(group=group)
+
+    def _path(self, r: int) -> str:
+        return os.path.join(self.dir, f"r{r}.sock")
+
+    def all_to_all(self, payload: dict, fds):
+        """Sends (payload, fds) to every peer; returns {peer: (payload, fds)}."""
+        for peer in range(self.world):
+            if peer != self.rank:
+                _send_fds(self._path(peer), dict(payload, src=self.rank), fds)
+        out = {}
+        for _ in range(self.world - 1):
+            msg, got = _recv_fds(self.server, 64)
+            out[int(msg["src"])] = (msg, got)
+        self.dist.barrier(group=self.group)
+        return out
+
+    def close(self):
+        self.server.close()
+        self.dist.barrier(group=self.group)
+        if self.rank == 0:
+            for r in range(self.world):
+                try:
+                    os.unlink(self._path(r))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass
+
+
+def create_partitioned_model(hp, group=None) -> Model:
+    """This rank's model over the partitioned table (hp.num_devices = world size, hp.device_rank = rank; the
+    HIP device must already be selected)."""
+    import torch.distributed as dist
+
+    L = _lib.load()
+    if int(hp.num_devices) != dist.get_world_size(group) or int(hp.device_rank) != dist.get_rank(group):
+        raise RuntimeError("hp.num_devices / hp.device_rank must equal the process group's size / this rank")
+    h = C.c_void_p()
+    _check(L.sbr_model_create_partitioned(C.byref(hp), C.byref(h)))
+    model = Model._from_handle(hp, h)
+    nparts = C.c_uint32()
+    _check(L.sbr_partition_num_parts(h, C.byref(nparts)))
+    own, fds = [], []
+    for i in range(nparts.value):
+        home = C.c_uint32()
+        _check(L.sbr_partition_part_info(h, i, C.byref(home), None))
+        if home.value == int(hp.device_rank):
+            fd = C.c_int32()
+            _check(L.sbr_partition_export_part(h, i, C.byref(fd)))
+            own.append(i)
+            fds.append(fd.value)
+    ex = _FdExchange(group)
+    try:
+        for _peer, (msg, got) in ex.all_to_all({"parts": own}, fds).items():
+            for part, fd in zip(msg["parts"], got):
+                _check(L.sbr_partition_import_part(h, int(part), int(fd)))
+                os.close(fd)
+    finally:
+        ex.close()
+    for fd in fds:
+        os.close(fd)
+    _check(L.sbr_partition_finalize(h))
+    dist.barrier(group=group)  # every rank has written its rows before anybody reads the table
+    return model
+
+
+def fit_partitioned(model: Model, interactions, group=None) -> float:
+    """``fit`` over a partitioned table, one process per GPU (≙ fit with num_threads = world size)."""
+    import torch
+    import torch.distributed as dist
+
+    L = _lib.load()
+    world, rank = int(model.hp.num_devices), int(model.hp.device_rank)
+    up, it = (interactions.user_pointers, interactions.item_ids) if hasattr(interactions, "user_pointers") else interactions
+    model.set_stream(torch.cuda.current_stream().cuda_stream)
+    plan: FitPlan = model.fit_begin(up, it)
+    staged = dist.get_backend(group) == "gloo"  # gloo has no device collectives: stage the small blocks through the host
+    try:
+        fds4, bytes4 = (C.c_int32 * 4)(), (C.c_uint64 * 4)()
+        _check(L.sbr_fit_lists_export(plan._h, fds4, bytes4))
+        ex = _FdExchange(group)
+        try:
+            for peer, (msg, got) in ex.all_to_all({"bytes": [int(b) for b in bytes4]}, list(fds4)).items():
+                pf = (C.c_int32 * 4)(*got)
+                pb = (C.c_uint64 * 4)(*msg["bytes"])
+                _check(L.sbr_fit_lists_import(plan._h, peer, pf, pb))
+                for fd in got:
+                    os.close(fd)
+        finally:
+            ex.close()
+        for fd in fds4:
+            os.close(fd)
+        db = plan.dense_bytes()
+        dense = torch.zeros(db, dtype=torch.uint8, device="cuda")
+        dense_all = torch.zeros(world * db, dtype=torch.uint8, device="cuda")
+        bounds = np.zeros(world + 1, dtype=np.uint32)
+        for e in range(int(model.hp.num_epochs)):
+            nmb = plan.epoch_prepare()
+            if e + 1 < int(model.hp.num_epochs):
+                plan.epoch_prefetch()
+            for mb in range(nmb):
+                plan.step_local(mb)
+                _check(L.sbr_fit_step_reduce_own(plan._h, mb, bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(dense.data_ptr())))
+                # rendezvous: after these all-gathers every rank has finished READING the table
+                tb = torch.from_numpy(bounds.astype(np.int64)).to("cpu" if staged else "cuda")
+                gathered = [torch.zeros_like(tb) for _ in range(world)]
+                dist.all_gather(gathered, tb, group=group)
+                if staged:
+                    parts = [torch.empty(db, dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, dense.cpu(), group=group)
+                    dense_all.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(dense_all, dense, group=group)
+                all_bounds = np.ascontiguousarray(torch.stack([g.cpu() for g in gathered]).numpy().astype(np.uint32))
+                torch.cuda.current_stream().synchronize()
+                _check(L.sbr_fit_step_owner_apply(plan._h, all_bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(dense_all.data_ptr())))
+                dist.barrier(group=group)  # every owner has finished WRITING its rows
+        loss, _examples = plan.end()
+    finally:
+        plan.close()
+    return loss

@@ -18,7 +18,7 @@ PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, P
 CASE = dict(users=70, items=157, T=12, B=5, d=32, epochs=2, seed=9)
 
 
-def _worker(rank, world, port, kind, loss, par, out_dir):
+def _worker(rank, world, port, kind, loss, par, out_dir, partition=False):
     import torch
     import torch.distributed as dist
 
@@ -39,7 +39,8 @@ def _worker(rank, world, port, kind, loss, par, out_dir):
             h = sbr.lstm.Hyperparameters.new(c["items"], c["T"]).lstm_variant(sbr.LSTMVariant.Normal)
         model = (h.from_seed(bytes([42] * 16)).embedding_dim(c["d"]).learning_rate(0.16).l2_penalty(0.0004)
                  .loss(sbr.Loss(loss)).optimizer(sbr.Optimizer.Adagrad).num_epochs(c["epochs"]).num_threads(world)
-                 .parallelism(sbr.Parallelism(par)).batch_sequences(c["B"]).build(device_rank=rank))
+                 .parallelism(sbr.Parallelism(par)).batch_sequences(c["B"]).partition_item_table(partition).build(device_rank=rank))
+        assert model.params.is_partitioned() == partition
         loss_v = model.fit(comp)  # -> fit_distributed: a process group is initialised
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v,
                  **{p.name: model.params.get_param(p) for p in PARAMS[kind]})
@@ -66,6 +67,31 @@ def test_two_processes_share_one_gpu(tmp_path, oracle_lib, kind, loss, par):
     c = CASE
     ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
     ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world, par=par))
+    ref_loss = ref.fit(ptr, items)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for p in PARAMS[kind]:
+            assert np.array_equal(z[p.name].view(np.uint32), ref.get_param(p).view(np.uint32)), f"rank {r}: {p.name}"
+        assert float(z["loss"]) == pytest.approx(ref_loss, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,loss", [(int(ModelKind.EWMA), LOSS_HINGE), (int(ModelKind.LSTM_NORMAL), LOSS_WARP)])
+def test_partitioned_table_two_processes(tmp_path, oracle_lib, kind, loss):
+    """The item-partitioned table under one process per GPU: each process owns half of the rows, maps the
+    other half from a file descriptor its peer exported (HIP virtual memory management + SCM_RIGHTS), reads
+    remote rows with the unchanged kernels and updates only its own from the peers' shared gradient lists.
+    Both processes sit on cuda:0 here; get_param reads the WHOLE table through each process's mapping, so
+    both must return the oracle's num_devices = 2 table bit for bit."""
+    import torch.multiprocessing as mp
+
+    from oracle.oracle import OracleModel
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, 1, str(tmp_path), True), nprocs=world, join=True)
+    c = CASE
+    ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
+    ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world))
     ref_loss = ref.fit(ptr, items)
     for r in range(world):
         z = np.load(tmp_path / f"rank{r}.npz")

@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--no-mrr", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo (host-staged) lets several ranks share one GPU for testing the N > 1 path")
+    ap.add_argument("--partition-table", action="store_true",
+                    help="store the item table once across the ranks (BASELINE configs[4] layout) instead of replicating it")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
@@ -225,17 +227,25 @@ def main():
     total_users = args.users * world
     ptr, items = synthetic_csr(total_users, args.items, args.max_len, zipf=args.item_distribution == "zipf")
     hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
-    model = engine.Model(hp)
-    backend = HipBackend(model, (ptr, items), world if not args.force_exchange else max(world, 2))
-    plan = backend.plan
-    if args.force_exchange and world == 1:  # one rank owns the whole table: a single chunk
-        backend.send = backend.send[:backend.chunk]
-    # the production step sequencing (sbr_rs_amd/distributed.py); --force-exchange runs the collectives at world 1
-    loop = StepLoop(backend, world if not args.force_exchange else max(world, 2), asynchronous=args.parallelism == "async")
-    if args.force_exchange and world == 1:
-        loop.world = 2  # take the exchange branch; the process group itself has a single rank
-        c, db = backend.chunk, backend.dense_bytes
-        loop.bufs = tuple(torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (c, c, db))
+    if args.partition_table and world > 1:
+        # the item table stored once across the ranks; torch.distributed is the control plane only
+        from sbr_rs_amd.partitioned import PartitionedStepper, create_partitioned_model
+
+        model = create_partitioned_model(hp)
+        backend = loop = PartitionedStepper(model, (ptr, items))
+        plan = backend.plan
+    else:
+        model = engine.group_create(hp, 1, partition_item_table=True)[0] if args.partition_table else engine.Model(hp)
+        backend = HipBackend(model, (ptr, items), world if not args.force_exchange else max(world, 2))
+        plan = backend.plan
+        if args.force_exchange and world == 1:  # one rank owns the whole table: a single chunk
+            backend.send = backend.send[:backend.chunk]
+        # the production step sequencing (sbr_rs_amd/distributed.py); --force-exchange runs the collectives at world 1
+        loop = StepLoop(backend, world if not args.force_exchange else max(world, 2), asynchronous=args.parallelism == "async")
+        if args.force_exchange and world == 1:
+            loop.world = 2  # take the exchange branch; the process group itself has a single rank
+            c, db = backend.chunk, backend.dense_bytes
+            loop.bufs = tuple(torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (c, c, db))
 
     tp0 = time.perf_counter()
     state = {"nmb": loop.begin_epoch(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0}
@@ -361,14 +371,19 @@ def main():
                     tf = flops_per_row * rows_timed / (kernels[fam]["ms_total"] * 1e-3) / 1e12
                     mfma.append({"kernel": fam, "what": what, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
                                  "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF})
+        is_cfg2 = (args.model, args.loss, args.dim, args.items, args.users, args.max_len) == ("lstm", "warp", 128, 1_000_000, 100_000, 64)
+        is_cfg4 = (args.model, args.loss, args.dim) == ("ewma", "hinge", 256) and args.partition_table
+        workload_tag = ("BASELINE.json configs[2]" if is_cfg2 else
+                        "BASELINE.json configs[4] shape (EWMA + hinge, d 256, partitioned item table)" if is_cfg4 else "custom workload")
         out = {
             "metric": "train interactions/sec", "value": rows_total / elapsed, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[2]: synthetic {args.users} users/GPU x {args.items} items, "
+            "config": {"workload": f"{workload_tag}: synthetic {args.users} users/GPU x {args.items} items, "
                                    f"seq_len<={args.max_len}, dim {args.dim}, {args.model}+{args.loss}, Adagrad lr 0.16 l2 4e-4",
                        "users_per_gpu": args.users, "items": args.items, "max_len": args.max_len, "dim": args.dim,
                        "batch_sequences_per_gpu": args.batch_sequences, "item_distribution": args.item_distribution,
+                       "item_table": "partitioned across the ranks (one copy)" if args.partition_table else "replicated",
                        "parallelism": (f"user-sharded dp{world}, {'staleness-one pipelined (Asynchronous)' if args.parallelism == 'async' else 'synchronous'} "
                                        f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],

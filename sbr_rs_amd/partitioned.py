@@ -121,58 +121,81 @@ def create_partitioned_model(hp, group=None) -> Model:
     return model
 
 
-def fit_partitioned(model: Model, interactions, group=None) -> float:
-    """``fit`` over a partitioned table, one process per GPU (≙ fit with num_threads = world size)."""
-    import torch
-    import torch.distributed as dist
+class PartitionedStepper:
+    """The optimiser-step sequencing of one rank over a partitioned table (same surface as
+    distributed.StepLoop: begin_epoch / step), used by fit_partitioned and bench.py."""
 
-    L = _lib.load()
-    world, rank = int(model.hp.num_devices), int(model.hp.device_rank)
-    up, it = (interactions.user_pointers, interactions.item_ids) if hasattr(interactions, "user_pointers") else interactions
-    model.set_stream(torch.cuda.current_stream().cuda_stream)
-    plan: FitPlan = model.fit_begin(up, it)
-    staged = dist.get_backend(group) == "gloo"  # gloo has no device collectives: stage the small blocks through the host
-    try:
+    def __init__(self, model: Model, interactions, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.L = _lib.load()
+        self.model = model
+        self.world = int(model.hp.num_devices)
+        up, it = (interactions.user_pointers, interactions.item_ids) if hasattr(interactions, "user_pointers") else interactions
+        model.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.plan: FitPlan = model.fit_begin(up, it)
+        self.staged = dist.get_backend(group) == "gloo"  # gloo has no device collectives: small blocks go through the host
         fds4, bytes4 = (C.c_int32 * 4)(), (C.c_uint64 * 4)()
-        _check(L.sbr_fit_lists_export(plan._h, fds4, bytes4))
+        _check(self.L.sbr_fit_lists_export(self.plan._h, fds4, bytes4))
         ex = _FdExchange(group)
         try:
             for peer, (msg, got) in ex.all_to_all({"bytes": [int(b) for b in bytes4]}, list(fds4)).items():
-                pf = (C.c_int32 * 4)(*got)
-                pb = (C.c_uint64 * 4)(*msg["bytes"])
-                _check(L.sbr_fit_lists_import(plan._h, peer, pf, pb))
+                _check(self.L.sbr_fit_lists_import(self.plan._h, peer, (C.c_int32 * 4)(*got), (C.c_uint64 * 4)(*msg["bytes"])))
                 for fd in got:
                     os.close(fd)
         finally:
             ex.close()
         for fd in fds4:
             os.close(fd)
-        db = plan.dense_bytes()
-        dense = torch.zeros(db, dtype=torch.uint8, device="cuda")
-        dense_all = torch.zeros(world * db, dtype=torch.uint8, device="cuda")
-        bounds = np.zeros(world + 1, dtype=np.uint32)
-        for e in range(int(model.hp.num_epochs)):
-            nmb = plan.epoch_prepare()
-            if e + 1 < int(model.hp.num_epochs):
-                plan.epoch_prefetch()
-            for mb in range(nmb):
-                plan.step_local(mb)
-                _check(L.sbr_fit_step_reduce_own(plan._h, mb, bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(dense.data_ptr())))
-                # rendezvous: after these all-gathers every rank has finished READING the table
-                tb = torch.from_numpy(bounds.astype(np.int64)).to("cpu" if staged else "cuda")
-                gathered = [torch.zeros_like(tb) for _ in range(world)]
-                dist.all_gather(gathered, tb, group=group)
-                if staged:
-                    parts = [torch.empty(db, dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, dense.cpu(), group=group)
-                    dense_all.copy_(torch.cat(parts))
-                else:
-                    dist.all_gather_into_tensor(dense_all, dense, group=group)
-                all_bounds = np.ascontiguousarray(torch.stack([g.cpu() for g in gathered]).numpy().astype(np.uint32))
-                torch.cuda.current_stream().synchronize()
-                _check(L.sbr_fit_step_owner_apply(plan._h, all_bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(dense_all.data_ptr())))
-                dist.barrier(group=group)  # every owner has finished WRITING its rows
-        loss, _examples = plan.end()
+        self.db = self.plan.dense_bytes()
+        self.dense = torch.zeros(self.db, dtype=torch.uint8, device="cuda")
+        self.dense_all = torch.zeros(self.world * self.db, dtype=torch.uint8, device="cuda")
+        self.bounds = np.zeros(self.world + 1, dtype=np.uint32)
+        self.num_minibatches = 0
+
+    def begin_epoch(self, prefetch_next: bool = False) -> int:
+        self.num_minibatches = self.plan.epoch_prepare()
+        if prefetch_next:
+            self.plan.epoch_prefetch()
+        return self.num_minibatches
+
+    def step(self, mb: int) -> None:
+        torch, dist, L, plan, world = self.torch, self.dist, self.L, self.plan, self.world
+        plan.step_local(mb)
+        _check(L.sbr_fit_step_reduce_own(plan._h, mb, self.bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(self.dense.data_ptr())))
+        # rendezvous: after these all-gathers every rank has finished READING the table
+        tb = torch.from_numpy(self.bounds.astype(np.int64)).to("cpu" if self.staged else "cuda")
+        gathered = [torch.zeros_like(tb) for _ in range(world)]
+        dist.all_gather(gathered, tb, group=self.group)
+        if self.staged:
+            parts = [torch.empty(self.db, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, self.dense.cpu(), group=self.group)
+            self.dense_all.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.dense_all, self.dense, group=self.group)
+        all_bounds = np.ascontiguousarray(torch.stack([g.cpu() for g in gathered]).numpy().astype(np.uint32))
+        torch.cuda.current_stream().synchronize()
+        _check(L.sbr_fit_step_owner_apply(plan._h, all_bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(self.dense_all.data_ptr())))
+        dist.barrier(group=self.group)  # every owner has finished WRITING its rows
+
+    def end(self):
+        return self.plan.end()
+
+    def close(self):
+        self.plan.close()
+
+
+def fit_partitioned(model: Model, interactions, group=None) -> float:
+    """``fit`` over a partitioned table, one process per GPU (≙ fit with num_threads = world size)."""
+    stepper = PartitionedStepper(model, interactions, group)
+    try:
+        epochs = int(model.hp.num_epochs)
+        for e in range(epochs):
+            for mb in range(stepper.begin_epoch(prefetch_next=e + 1 < epochs)):
+                stepper.step(mb)
+        loss, _examples = stepper.end()
     finally:
-        plan.close()
+        stepper.close()
     return loss

@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--no-mrr", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo (host-staged) lets several ranks share one GPU for testing the N > 1 path")
+    ap.add_argument("--transport", choices=["collective", "peer"], default="collective",
+                    help="replicated multi-GPU exchange: collective = RCCL all-to-all + all-gather of the chunks; peer = the "
+                         "kernels read the peers' chunk buffers in place through peer mappings (xGMI), collectives only order the phases")
     ap.add_argument("--partition-table", action="store_true",
                     help="store the item table once across the ranks (BASELINE configs[4] layout) instead of replicating it")
     ap.add_argument("--force-exchange", action="store_true",
@@ -233,6 +236,12 @@ def main():
 
         model = create_partitioned_model(hp)
         backend = loop = PartitionedStepper(model, (ptr, items))
+        plan = backend.plan
+    elif args.transport == "peer" and world > 1:
+        from sbr_rs_amd.partitioned import PeerExchangeStepper
+
+        model = engine.Model(hp)
+        backend = loop = PeerExchangeStepper(model, (ptr, items))
         plan = backend.plan
     else:
         model = engine.group_create(hp, 1, partition_item_table=True)[0] if args.partition_table else engine.Model(hp)

@@ -200,6 +200,18 @@ sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out);
  *   drained) -> all-gather of the bounds and of the dense blocks -> sbr_fit_step_owner_apply (stream
  *   drained) -> barrier.
  * Same bits as sbr_group_fit over a partitioned group and as the replicated Synchronous exchange. */
+/* Peer transport of the REPLICATED exchange (one process per GPU): every rank exports its send buffer and
+ * its reduced own chunk once; the owner-reduce and table-update kernels then read the peers' buffers in
+ * place through peer mappings (xGMI), so no bulk collective is involved.  Host sequencing per step:
+ *   sbr_fit_step_local -> sbr_fit_step_scatter_shared -> barrier -> sbr_fit_step_owner_reduce_peers ->
+ *   sbr_fit_step_dense + all-gather of the dense blocks (a barrier as well) -> sbr_fit_step_apply_table_peers
+ *   -> barrier.  Every call returns with the stream drained.  Same bits as the collective transport. */
+sbr_status sbr_fit_exchange_export(sbr_fit_plan* p, int32_t out_fds[2], uint64_t out_bytes[2]);
+sbr_status sbr_fit_exchange_import(sbr_fit_plan* p, uint32_t peer_rank, const int32_t fds[2], const uint64_t bytes[2]);
+sbr_status sbr_fit_step_scatter_shared(sbr_fit_plan* p, uint64_t minibatch);
+sbr_status sbr_fit_step_owner_reduce_peers(sbr_fit_plan* p);
+sbr_status sbr_fit_step_apply_table_peers(sbr_fit_plan* p, const void* device_dense_all);
+
 sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out);
 sbr_status sbr_partition_num_parts(const sbr_model* m, uint32_t* out);
 sbr_status sbr_partition_part_info(const sbr_model* m, uint32_t part, uint32_t* out_home_rank, uint64_t* out_bytes);

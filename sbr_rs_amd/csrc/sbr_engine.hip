@@ -488,6 +488,10 @@ struct sbr_fit_plan {
     uint32_t *gfl = nullptr, *bounds_dev = nullptr;
     /* one process per GPU: the list (and the sorted keys) live in exportable allocations, the peers' lists
      * are mapped from the file descriptors they exported: [0] keys_sorted [1] glist [2] gblist [3] gfl */
+    /* peer transport of the replicated exchange: [0] this rank's send buffer (ndev chunks), [1] its reduced
+     * own chunk — exportable; the peers' pair is mapped here and read in place by the kernels */
+    VmmBuf xchg_own[2];
+    std::vector<std::array<VmmBuf, 2>> xchg_peer;
     bool exportable_lists = false;
     VmmBuf own_x[4];
     std::vector<std::array<VmmBuf, 4>> peer_x;
@@ -962,6 +966,8 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     }
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     p->wb.release();
+    for (auto& px : p->xchg_peer) for (auto& b : px) b.release();
+    for (auto& b : p->xchg_own) b.release();
     if (p->exportable_lists) { /* the sorted keys and the list are virtual-memory allocations, not hipMalloc'ed */
         for (auto& px : p->peer_x) for (auto& b : px) b.release();
         for (auto& b : p->own_x) b.release();
@@ -1283,13 +1289,20 @@ sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out) {
     return SBR_OK;
 }
 
+static sbr::ChunkPtrs contiguous_chunks(const sbr_fit_plan* p, const void* base) {
+    sbr::ChunkPtrs c;
+    const uint64_t chunk = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
+    for (int q = 0; q < 16; ++q) c.p[q] = q < p->ndev ? reinterpret_cast<const uint8_t*>(base) + (size_t)q * chunk : nullptr;
+    return c;
+}
+
 sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk) {
     if (!p || !device_recv || !device_own_chunk) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_owner_reduce(m->mv, device_recv, p->ndev, slice_rows(p), device_own_chunk, m->stream);
+        sbr::launch_owner_reduce(m->mv, contiguous_chunks(p, device_recv), p->ndev, slice_rows(p), device_own_chunk, m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1318,7 +1331,7 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
     SBRCHK(apply_dense_blocks(p, device_dense_all));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_table_apply(m->mv, device_table, slice_rows(p), m->stream);
+        sbr::launch_table_apply(m->mv, contiguous_chunks(p, device_table), slice_rows(p), m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1436,6 +1449,88 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
     sbr_fit_plan_destroy(p);
     return st;
+}
+
+/* ---- peer transport of the replicated owner-reduce exchange (one process per GPU) ----------------------
+ * Instead of moving the chunks with collectives, every rank exports its send buffer and its reduced own
+ * chunk once (file descriptors, like the partitioned table); the owner-reduce kernel then reads chunk q of
+ * every peer's send buffer IN PLACE and the table update reads every owner's reduced chunk in place — the
+ * bytes cross xGMI exactly once, inside the kernels that consume them, and no bulk collective is involved.
+ * The host supplies the ordering: [scatter] barrier [owner reduce] barrier + all-gather of the small dense
+ * blocks [apply]; the next step's scatter is safe because every rank passed the following barrier. */
+sbr_status sbr_fit_exchange_export(sbr_fit_plan* p, int32_t out_fds[2], uint64_t out_bytes[2]) {
+    if (!p || !out_fds || !out_bytes || p->ndev < 2 || p->m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    const uint64_t chunk = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
+    if (!p->xchg_own[0].ptr) {
+        SBRCHK(p->xchg_own[0].alloc((size_t)p->ndev * chunk, p->m->device));
+        SBRCHK(p->xchg_own[1].alloc((size_t)chunk, p->m->device));
+    }
+    for (int i = 0; i < 2; ++i) {
+        int fd = -1;
+        SBRCHK(p->xchg_own[i].export_fd(&fd));
+        out_fds[i] = fd;
+        out_bytes[i] = p->xchg_own[i].bytes;
+    }
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_exchange_import(sbr_fit_plan* p, uint32_t peer_rank, const int32_t fds[2], const uint64_t bytes[2]) {
+    if (!p || !fds || !bytes || (int)peer_rank >= p->ndev || (int)peer_rank == p->rank) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    if (p->xchg_peer.empty()) p->xchg_peer.resize(p->ndev);
+    for (int i = 0; i < 2; ++i) SBRCHK(p->xchg_peer[peer_rank][i].import_fd(fds[i], bytes[i], p->m->device));
+    return SBR_OK;
+}
+
+static sbr_status peer_chunks(const sbr_fit_plan* p, int which, sbr::ChunkPtrs* out) {
+    const uint64_t chunk = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
+    for (int r = 0; r < 16; ++r) out->p[r] = nullptr;
+    for (int r = 0; r < p->ndev; ++r) {
+        const VmmBuf* b = r == p->rank ? &p->xchg_own[which] : (p->xchg_peer.empty() ? nullptr : &p->xchg_peer[r][which]);
+        if (!b || !b->ptr) return SBR_ERR_INVALID_ARGUMENT; /* exchange buffers of rank r not mapped */
+        /* which 0: chunk `rank` of r's send buffer (what r contributes to my rows); which 1: r's reduced own chunk */
+        out->p[r] = reinterpret_cast<const uint8_t*>(b->ptr) + (which == 0 ? (size_t)p->rank * chunk : 0);
+    }
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_scatter_shared(sbr_fit_plan* p, uint64_t minibatch) {
+    if (!p || !p->xchg_own[0].ptr) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(sbr_fit_step_scatter(p, minibatch, p->xchg_own[0].ptr));
+    HIPCHK(hipStreamSynchronize(p->m->stream));
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_owner_reduce_peers(sbr_fit_plan* p) {
+    if (!p || !p->xchg_own[1].ptr) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    sbr::ChunkPtrs src;
+    SBRCHK(peer_chunks(p, 0, &src));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_owner_reduce(m->mv, src, p->ndev, slice_rows(p), p->xchg_own[1].ptr, m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_apply_table_peers(sbr_fit_plan* p, const void* device_dense_all) {
+    if (!p || !device_dense_all || !p->xchg_own[1].ptr) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    sbr::ChunkPtrs src;
+    SBRCHK(peer_chunks(p, 1, &src));
+    SBRCHK(apply_dense_blocks(p, device_dense_all));
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_table_apply(m->mv, src, slice_rows(p), m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return SBR_OK;
 }
 
 /* ---- one process per GPU over a partitioned table: the step halves the host sequences -----------------

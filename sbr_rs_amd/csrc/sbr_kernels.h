@@ -61,6 +61,12 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     unsigned int* part_tries;
 };
 
+/* one chunk pointer per device: slices of one gathered buffer (collective transport), or the peers' own
+ * buffers read in place through peer mappings (peer transport) */
+struct ChunkPtrs {
+    const void* p[16];
+};
+
 /* scratch of the long-segment path of the sparse reduction */
 struct SegScratch {
     uint32_t* counters;   /* [0] long segments, [1] chunk units */
@@ -116,8 +122,8 @@ void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_
 void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
                      const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, const SegScratch& sc,
                      hipStream_t s);
-void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
-void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s);
+void launch_owner_reduce(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
+void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t slice_rows, hipStream_t s);
 /* partitioned item table: the owner merges the peers' lists (read through peer mappings) in device order
  * and updates its rows */
 void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,

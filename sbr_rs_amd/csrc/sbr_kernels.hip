@@ -1473,7 +1473,7 @@ __global__ void clear_chunk_flags_kernel(void* buf, int nchunks, uint64_t S, int
 
 // owner: contributions of the devices added in device order (first toucher initialises)
 template <int D>
-__global__ __launch_bounds__(256) void owner_reduce_kernel(const void* recv, int ndev, uint64_t S, void* own) {
+__global__ __launch_bounds__(256) void owner_reduce_kernel(ChunkPtrs recv, int ndev, uint64_t S, void* own) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
@@ -1486,7 +1486,7 @@ __global__ __launch_bounds__(256) void owner_reduce_kernel(const void* recv, int
         float gb = 0.0f;
         uint32_t fl = 0;
         for (int q = 0; q < ndev; ++q) {
-            const float* c = chunk_ptr(recv, q, S, D);
+            const float* c = reinterpret_cast<const float*>(recv.p[q]); /* device q's contribution to this owner's rows */
             const uint32_t f = reinterpret_cast<const uint32_t*>(c + S * D + S)[i];
             if (f & 1u) {
                 const float4 v = ld4(c + i * D + 4 * lg);
@@ -1506,14 +1506,14 @@ __global__ __launch_bounds__(256) void owner_reduce_kernel(const void* recv, int
 
 // every device: Adagrad on every touched row from the gathered global sums
 template <int D>
-__global__ __launch_bounds__(256) void table_apply_kernel(ModelView m, const void* table, uint64_t S) {
+__global__ __launch_bounds__(256) void table_apply_kernel(ModelView m, ChunkPtrs table, uint64_t S) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t row = wave * GPW + grp; row < m.num_items; row += nwaves * GPW) {
-        const float* c = chunk_ptr(table, row / S, S, D);
+        const float* c = reinterpret_cast<const float*>(table.p[row / S]); /* the reduced chunk of the row's owner */
         const uint64_t lr = row % S;
         const uint32_t fl = reinterpret_cast<const uint32_t*>(c + S * D + S)[lr];
         if (fl & 1u) {
@@ -2034,14 +2034,14 @@ void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_
     launch_seg_reduce(m.d, blk, rows_host, keys_sorted, sc, EmitChunk{send, slice_rows}, s);
 }
 
-void launch_owner_reduce(const ModelView& m, const void* recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s) {
+void launch_owner_reduce(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s) {
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((owner_reduce_kernel<DD>), dim3(grid_for_groups((long long)slice_rows, gpb)), dim3(256), 0, s, recv, ndev, slice_rows, own);
     });
 }
 
-void launch_table_apply(const ModelView& m, const void* table, uint64_t slice_rows, hipStream_t s) {
+void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t slice_rows, hipStream_t s) {
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((table_apply_kernel<DD>), dim3(grid_for_groups((long long)m.num_items, gpb)), dim3(256), 0, s, m, table, slice_rows);

@@ -245,7 +245,7 @@ class HipBackend:
         self.plan.close()
 
 
-def fit_distributed(model, interactions, group=None) -> float:
+def fit_distributed(model, interactions, group=None, transport: str = None) -> float:
     """``fit`` for ``num_threads`` (= world size) > 1.  Requires an initialised process group whose
     size equals ``hp.num_devices`` and whose rank equals ``hp.device_rank``."""
     import torch.distributed as dist
@@ -255,6 +255,22 @@ def fit_distributed(model, interactions, group=None) -> float:
         raise RuntimeError(f"fit with num_threads={world} needs torch.distributed initialised with world size {world}")
     if dist.get_rank(group) != int(model.hp.device_rank):
         raise RuntimeError("process rank does not match hp.device_rank")
+    import os
+
+    transport = transport or os.environ.get("SBR_EXCHANGE_TRANSPORT", "collective")
+    if transport == "peer":  # chunks read in place through peer mappings; collectives only order the phases
+        from .partitioned import PeerExchangeStepper
+
+        stepper = PeerExchangeStepper(model, interactions, group)
+        try:
+            epochs = int(model.hp.num_epochs)
+            for e in range(epochs):
+                for mb in range(stepper.begin_epoch(prefetch_next=e + 1 < epochs)):
+                    stepper.step(mb)
+            loss, _examples = stepper.end()
+        finally:
+            stepper.close()
+        return loss
     backend = HipBackend(model, interactions, world)
     try:
         loss, _examples = run_fit(backend, int(model.hp.num_epochs), world, group,

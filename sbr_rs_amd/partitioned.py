@@ -199,3 +199,70 @@ def fit_partitioned(model: Model, interactions, group=None) -> float:
     finally:
         stepper.close()
     return loss
+
+
+class PeerExchangeStepper:
+    """The REPLICATED owner-reduce exchange with the peers' buffers read in place (peer transport): every rank
+    exports its send buffer and its reduced own chunk once, the owner-reduce and table-update kernels read the
+    peers' chunks through peer mappings (xGMI), and torch.distributed only orders the phases (two barriers and
+    the all-gather of the small dense blocks per step).  Same surface as distributed.StepLoop, same bits as the
+    collective transport."""
+
+    def __init__(self, model: Model, interactions, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group = torch, dist, group
+        self.L = _lib.load()
+        self.model = model
+        self.world = int(model.hp.num_devices)
+        up, it = (interactions.user_pointers, interactions.item_ids) if hasattr(interactions, "user_pointers") else interactions
+        model.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.plan: FitPlan = model.fit_begin(up, it)
+        self.staged = dist.get_backend(group) == "gloo"
+        fds2, bytes2 = (C.c_int32 * 2)(), (C.c_uint64 * 2)()
+        _check(self.L.sbr_fit_exchange_export(self.plan._h, fds2, bytes2))
+        ex = _FdExchange(group)
+        try:
+            for peer, (msg, got) in ex.all_to_all({"bytes": [int(b) for b in bytes2]}, list(fds2)).items():
+                _check(self.L.sbr_fit_exchange_import(self.plan._h, peer, (C.c_int32 * 2)(*got), (C.c_uint64 * 2)(*msg["bytes"])))
+                for fd in got:
+                    os.close(fd)
+        finally:
+            ex.close()
+        for fd in fds2:
+            os.close(fd)
+        self.db = self.plan.dense_bytes()
+        self.dense = torch.zeros(self.db, dtype=torch.uint8, device="cuda")
+        self.dense_all = torch.zeros(self.world * self.db, dtype=torch.uint8, device="cuda")
+        self.num_minibatches = 0
+
+    def begin_epoch(self, prefetch_next: bool = False) -> int:
+        self.num_minibatches = self.plan.epoch_prepare()
+        if prefetch_next:
+            self.plan.epoch_prefetch()
+        return self.num_minibatches
+
+    def step(self, mb: int) -> None:
+        torch, dist, L, plan = self.torch, self.dist, self.L, self.plan
+        plan.step_local(mb)
+        _check(L.sbr_fit_step_scatter_shared(plan._h, mb))       # this rank's send chunks are complete
+        dist.barrier(group=self.group)                           # ... and so are everybody's
+        _check(L.sbr_fit_step_owner_reduce_peers(plan._h))       # reads chunk `rank` of every peer's send buffer
+        plan.step_dense(self.dense.data_ptr())
+        self.model.synchronize()
+        if self.staged:                                          # the all-gather doubles as "all own chunks are complete"
+            parts = [torch.empty(self.db, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, self.dense.cpu(), group=self.group)
+            self.dense_all.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(self.dense_all, self.dense, group=self.group)
+        torch.cuda.current_stream().synchronize()
+        _check(L.sbr_fit_step_apply_table_peers(plan._h, C.c_void_p(self.dense_all.data_ptr())))
+        dist.barrier(group=self.group)                           # nobody is still reading this rank's buffers
+
+    def end(self):
+        return self.plan.end()
+
+    def close(self):
+        self.plan.close()

@@ -18,7 +18,8 @@ PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, P
 CASE = dict(users=70, items=157, T=12, B=5, d=32, epochs=2, seed=9)
 
 
-def _worker(rank, world, port, kind, loss, par, out_dir, partition=False):
+def _worker(rank, world, port, kind, loss, par, out_dir, partition=False, transport="collective"):
+    os.environ["SBR_EXCHANGE_TRANSPORT"] = transport
     import torch
     import torch.distributed as dist
 
@@ -89,6 +90,29 @@ def test_partitioned_table_two_processes(tmp_path, oracle_lib, kind, loss):
 
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), kind, loss, 1, str(tmp_path), True), nprocs=world, join=True)
+    c = CASE
+    ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
+    ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world))
+    ref_loss = ref.fit(ptr, items)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        for p in PARAMS[kind]:
+            assert np.array_equal(z[p.name].view(np.uint32), ref.get_param(p).view(np.uint32)), f"rank {r}: {p.name}"
+        assert float(z["loss"]) == pytest.approx(ref_loss, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,loss", [(int(ModelKind.LSTM_NORMAL), LOSS_WARP), (int(ModelKind.EWMA), LOSS_HINGE)])
+def test_peer_transport_two_processes(tmp_path, oracle_lib, kind, loss):
+    """The replicated exchange with the peers' chunk buffers read in place (exported once as file
+    descriptors, mapped by the peers, consumed by the owner-reduce / table-update kernels): no bulk
+    collective.  Must equal the oracle's num_devices = 2 run bit for bit on both ranks."""
+    import torch.multiprocessing as mp
+
+    from oracle.oracle import OracleModel
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, 1, str(tmp_path), False, "peer"), nprocs=world, join=True)
     c = CASE
     ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
     ref = OracleModel(hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"], ndev=world))

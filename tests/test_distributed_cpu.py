@@ -130,3 +130,42 @@ def test_partitioning_drops_remainder_and_shards_disjointly(oracle_lib):
     # in sequences, so total rows can only shrink when the remainder is dropped
     assert sum(rows[2]) <= rows[1][0] and sum(rows[3]) <= rows[1][0]
     assert all(r > 0 for r in rows[3])
+
+
+def _fd_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sbr_rs_amd.partitioned import _FdExchange
+
+        path = os.path.join(out_dir, f"payload{rank}.bin")
+        with open(path, "wb") as f:
+            f.write(bytes([rank + 1]) * 1000)
+        fd = os.open(path, os.O_RDONLY)
+        ex = _FdExchange()
+        try:
+            got = ex.all_to_all({"tag": f"from{rank}"}, [fd])
+        finally:
+            ex.close()
+        os.close(fd)
+        seen = {}
+        for peer, (msg, fds) in got.items():
+            assert msg["tag"] == f"from{peer}" and len(fds) == 1
+            seen[peer] = os.pread(fds[0], 1000, 0)
+            os.close(fds[0])
+        np.save(os.path.join(out_dir, f"fd{rank}.npy"), np.array([[p, data[0], len(data)] for p, data in sorted(seen.items())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_file_descriptor_exchange_between_ranks(tmp_path):
+    """The control plane of the partitioned table / peer transport: every rank hands every other rank a file
+    descriptor (SCM_RIGHTS over Unix sockets, rendezvous through torch.distributed).  Here the descriptors are
+    plain files, so the plumbing is covered without a GPU."""
+    world = 3
+    mp.spawn(_fd_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        rows = np.load(tmp_path / f"fd{r}.npy")
+        assert [int(x[0]) for x in rows] == [p for p in range(world) if p != r]
+        assert all(int(x[1]) == int(x[0]) + 1 and int(x[2]) == 1000 for x in rows)

@@ -1,8 +1,7 @@
 // The crate's README example (src/lib.rs:22-58) against the C++ host layer of the MI355X engine.
 //
 //   python -m sbr_rs_amd.build                      # builds sbr_rs_amd/libsbr_hip.so
-//   g++ -std=c++17 -O2 -Iinclude examples/movielens.cpp -o movielens -Lsbr_rs_amd -lsbr_hip \
-//       -Wl,-rpath,$PWD/sbr_rs_amd
+//   g++ -std=c++17 -O2 -Iinclude examples/movielens.cpp -o movielens -Lsbr_rs_amd -lsbr_hip -Wl,-rpath,$PWD/sbr_rs_amd
 //   ./movielens data.csv                             # user_id,item_id,rating,timestamp
 #include <chrono>
 #include <cstdio>

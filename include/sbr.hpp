@@ -90,10 +90,11 @@ class Result {
 };
 
 // ---- the index RNG --------------------------------------------------------------------------
-/// Marsaglia xorshift128 with the engine's integer/unit draws (sbr_numerics.h: sbr_xorshift,
-/// sbr_xs_below, sbr_xs_unit) — the object handed to `Hyperparameters::rng` / `from_seed`
-/// (lstm.rs:122-132).  rand 0.5's exact streams are pinned by no reference test; these are the
-/// engine's own and are identical in the library, the Python host layer and here.
+/// rand 0.5's `XorShiftRng` as recalled: Marsaglia xorshift128, next_u64 = low word
+/// first, gen_range / shuffle / Uniform with the crate's widening-multiply rejection zones — the
+/// object handed to `Hyperparameters::rng` / `from_seed` (lstm.rs:122-132).  Identical in the library
+/// (sbr_numerics.h: sbr_xorshift, sbr_rand_*), the Python host layer and here; the crate's source is not
+/// in this image and no reference test pins a stream.
 class XorShiftRng {
   public:
     static XorShiftRng from_seed(const std::array<std::uint8_t, 16>& seed) {
@@ -134,20 +135,36 @@ class XorShiftRng {
         const std::uint64_t hi = next_u32();
         return lo | (hi << 32);
     }
-    /// Uniform integer in [0, n): 64x64->128 multiply-high with rejection.
-    std::uint64_t below(std::uint64_t n) {
-        const std::uint64_t thresh = (0 - n) % n;
+    /// `Rng::gen_range(low, high)` (rand 0.5 `UniformInt::sample_single`): zone = range << leading_zeros(range),
+    /// accept when the low half of next_u64() * range is <= zone, result = low + high half.
+    std::uint64_t gen_range(std::uint64_t low, std::uint64_t high) {
+        const std::uint64_t range = high - low;
+        const std::uint64_t zone = range << __builtin_clzll(range);
         for (;;) {
-            const unsigned __int128 m = (unsigned __int128)next_u64() * n;
-            if ((std::uint64_t)m >= thresh) return (std::uint64_t)(m >> 64);
+            const unsigned __int128 m = (unsigned __int128)next_u64() * range;
+            if ((std::uint64_t)m <= zone) return low + (std::uint64_t)(m >> 64);
         }
     }
-    /// Uniform double in [0, 1) from the top 53 bits.
+    /// `Uniform::new(low, high).sample(rng)`: zone = MAX - (MAX - range + 1) % range (data.rs:77-78).
+    std::uint64_t uniform(std::uint64_t low, std::uint64_t high) {
+        const std::uint64_t range = high - low, max = std::numeric_limits<std::uint64_t>::max();
+        const std::uint64_t zone = max - (max - range + 1) % range;
+        for (;;) {
+            const unsigned __int128 m = (unsigned __int128)next_u64() * range;
+            if ((std::uint64_t)m <= zone) return low + (std::uint64_t)(m >> 64);
+        }
+    }
+    /// gen_range(0, n)
+    std::uint64_t below(std::uint64_t n) { return gen_range(0, n); }
+    /// `rng.gen::<f64>()` (rand 0.5 `Standard`): 53 random bits scaled to [0, 1).
     double unit() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
-    /// Fisher-Yates from the end: for i in (1..n).rev(): swap(i, below(i + 1)).
+    /// `Rng::shuffle`: i = len; while i >= 2 { i -= 1; swap(i, gen_range(0, i + 1)) }.
     template <class T>
     void shuffle(std::vector<T>& v) {
-        for (std::size_t i = v.size(); i > 1; --i) std::swap(v[i - 1], v[below(i)]);
+        for (std::size_t i = v.size(); i >= 2;) {
+            i -= 1;
+            std::swap(v[i], v[gen_range(0, i + 1)]);
+        }
     }
 
   private:
@@ -261,8 +278,8 @@ inline std::pair<Interactions, Interactions> user_based_split(Interactions& inte
                                                               float test_fraction) {
     const std::uint64_t denominator = 100000;
     const std::uint64_t train_cutoff = (std::uint64_t)(test_fraction * (float)denominator);
-    const std::uint64_t key_0 = rng.below(std::numeric_limits<std::uint64_t>::max());
-    const std::uint64_t key_1 = rng.below(std::numeric_limits<std::uint64_t>::max());
+    const std::uint64_t key_0 = rng.uniform(0, std::numeric_limits<std::uint64_t>::max());
+    const std::uint64_t key_1 = rng.uniform(0, std::numeric_limits<std::uint64_t>::max());
     return interactions.split_by([&](const Interaction& x) {
         return detail::siphash24_u64(key_0, key_1, (std::uint64_t)x.user_id()) % denominator > train_cutoff;
     });

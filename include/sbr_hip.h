@@ -282,7 +282,7 @@ sbr_status sbr_set_device(int32_t ordinal);
 /* Numerics-contract self-tests: run sbr_numerics.h primitives on the device so tests can compare
  * them bit for bit with the CPU oracle (no reference counterpart: wyrm's fast-math kernels are
  * replaced by the engine's own). */
-sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_exp, float* out_sig, float* out_tanh);
+sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_cell_h, float* out_sig, float* out_tanh);
 sbr_status sbr_selftest_dot_tree(const float* x, const float* y, uint32_t d, uint64_t nrows, float* out);
 sbr_status sbr_selftest_mfma(const float* a, const float* b, const float* c0, uint32_t k, float* out,
                              const float* a32, const float* b32, float* out32);

@@ -20,9 +20,10 @@ _lib = None
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "sbr_oracle.c")
-    hdr = os.path.join(_HERE, "..", "sbr_rs_amd", "csrc", "sbr_numerics.h")
+    hdrs = [os.path.join(_HERE, "orc_numerics.h"), os.path.join(_HERE, "orc_ziggurat_tables.h"),
+            os.path.join(_HERE, "..", "sbr_rs_amd", "csrc", "sbr_approx.h"), os.path.join(_HERE, "..", "include", "sbr_hip.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in [src] + hdrs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libsbr_oracle.so"])
     return _LIB_PATH
@@ -71,7 +72,13 @@ def lib():
         L.orc_user_representation.argtypes = [vp, vp, C.c_uint64, vp]
         L.orc_predict.argtypes = [vp, vp, vp, C.c_uint64, vp]
         L.orc_mrr_score.argtypes = [vp, vp, vp, C.c_uint64, fp, vp, u64p]
-        for name in ("orc_expf", "orc_sigmoidf", "orc_tanhf"):
+        L.orc_rand_stream.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, vp, C.c_int]
+        L.orc_rand_stream.restype = None
+        L.orc_rand_uniform_u64.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int]
+        L.orc_rand_uniform_u64.restype = C.c_uint64
+        L.orc_tanh_pq.argtypes = [C.c_float, fp, fp]
+        L.orc_tanh_pq.restype = None
+        for name in ("orc_sigmoidf", "orc_tanhf", "orc_selftest_cell_h"):
             getattr(L, name).argtypes = [C.c_float]
             getattr(L, name).restype = C.c_float
         for name in ("orc_dot_tree", "orc_dot_chain"):

@@ -18,9 +18,10 @@
  * the Rust path is UNPINNED ("parity unpinned" in DESIGN.md); parity of the HIP engine is
  * claimed against this oracle.
  *
- * Functions cite the reference lines they follow.  Scalar arithmetic (activations, dot orders,
- * losses, Adagrad, LSTM cell, negative-draw hash) comes from sbr_rs_amd/csrc/sbr_numerics.h, the
- * shared contract header, so that device and oracle are bit-comparable.
+ * Functions cite the reference lines they follow.  The scalar arithmetic (activations, dot orders,
+ * losses, Adagrad/Adam, LSTM cell, negative-draw hash, rand 0.5 generators) is the oracle's own
+ * statement in oracle/orc_numerics.h; from the product it shares nothing but the approximation
+ * polynomial of sbr_rs_amd/csrc/sbr_approx.h (tests/test_abi.py enforces this).
  */
 #include <math.h>
 #include <stdint.h>
@@ -29,9 +30,7 @@
 #include <string.h>
 
 #include "../include/sbr_hip.h"
-#include "../sbr_rs_amd/csrc/sbr_numerics.h"
-
-#define ORC_EWMA_CHUNK_SEQS 256
+#include "orc_numerics.h"
 
 typedef struct orc_model {
     sbr_hparams hp;
@@ -42,7 +41,7 @@ typedef struct orc_model {
     float *Em, *bm, *Wm, *bWm, *alpha_m; /* Adam first moments */
     float c1, c2;
     uint64_t opt_steps;
-    sbr_xorshift rng;
+    orc_rng rng;
     uint64_t global_epoch;
 } orc_model;
 
@@ -64,7 +63,7 @@ typedef struct orc_plan {
     uint64_t part_len;   /* subsequences per device partition */
     uint64_t* seq_start; /* [ndev][part_len] offsets into item_ids */
     uint32_t* seq_len;
-    sbr_xorshift* part_rng; /* [ndev] */
+    orc_rng* part_rng; /* [ndev] */
     uint64_t* fit_seed;     /* [ndev] */
     uint32_t* items;        /* copy of item_ids */
     uint64_t nnz;
@@ -77,27 +76,18 @@ typedef struct orc_plan {
 } orc_plan;
 
 /* ------------------------------------------------------------------------------------------ */
-static double orc_normal(sbr_xorshift* r, int* have, double* spare) {
-    /* Marsaglia polar; both variates used.  (Reference: rand 0.5 Normal = ziggurat, unpinned.) */
-    if (*have) { *have = 0; return *spare; }
-    for (;;) {
-        double u = 2.0 * sbr_xs_unit(r) - 1.0;
-        double v = 2.0 * sbr_xs_unit(r) - 1.0;
-        double s = u * u + v * v;
-        if (s >= 1.0 || s == 0.0) continue;
-        double f = sqrt(-2.0 * log(s) / s);
-        *spare = v * f;
-        *have = 1;
-        return u * f;
-    }
-}
-
 static int orc_dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
 /* ≙ Hyperparameters::build_params (lstm.rs:174-194, ewma.rs:167-198): E ~ N(0,(1/d)^2) drawn
- * row-major from the model RNG (embedding_init, lstm.rs:22-25), biases 0, alpha 0; then the LSTM
- * weights from the same RNG (wyrm nn::lstm::Parameters::new — distribution recalled as
- * xavier_normal with std 1/sqrt(rows) = 1/sqrt(2d)). */
+ * row-major from the model RNG (embedding_init, lstm.rs:22-25: rand 0.5 Normal, f64 -> f32), biases 0,
+ * alpha 0; then, from the same RNG,
+ *   LSTM: wyrm nn::lstm::Parameters::new — recalled as four [(hidden+input) x hidden] matrices drawn
+ *         one after the other in the order forget, update gate, update value, output gate, each
+ *         xavier_normal (std 1/sqrt(rows) = 1/sqrt(2d)), rows = hidden part first (the cell stacks
+ *         `hidden.stack(input)`); biases zero.  A coupled layer draws all four and ignores the update
+ *         gate's.  Stored here as W[2d][ng*d], rows [x ; h], column blocks i,f,g,o (coupled: f,g,o).
+ *   EWMA: the two unused d x d `dense_init` matrices fc1, fc2 (ewma.rs:179-188) — drawn and dropped so
+ *         that the RNG the driver shuffles with is where the reference's is. */
 int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     if (!orc_dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
@@ -116,11 +106,9 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     int adam = hp->optimizer == SBR_OPT_ADAM;
     m->c1 = m->c2 = 1.0f;
     if (adam) { m->Em = (float*)calloc(I * d, sizeof(float)); m->bm = (float*)calloc(I, sizeof(float)); }
-    sbr_xs_seed(&m->rng, hp->seed);
-    int have = 0;
-    double spare = 0.0;
+    orc_rng_from_seed(&m->rng, hp->seed);
     double std_e = 1.0 / (double)d;
-    for (size_t i = 0; i < I * (size_t)d; ++i) m->E[i] = (float)(orc_normal(&m->rng, &have, &spare) * std_e);
+    for (size_t i = 0; i < I * (size_t)d; ++i) m->E[i] = orc_rng_normal_f32(&m->rng, 0.0, std_e);
     if (m->ng) {
         size_t nw = (size_t)2 * d * m->ng * d;
         m->W = (float*)malloc(nw * sizeof(float));
@@ -128,13 +116,24 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
         m->bW = (float*)calloc((size_t)m->ng * d, sizeof(float));
         m->bWacc = (float*)calloc((size_t)m->ng * d, sizeof(float));
         if (adam) { m->Wm = (float*)calloc(nw, sizeof(float)); m->bWm = (float*)calloc((size_t)m->ng * d, sizeof(float)); }
-        double std_w = 1.0 / sqrt(2.0 * d);
-        have = 0;
-        for (size_t i = 0; i < nw; ++i) m->W[i] = (float)(orc_normal(&m->rng, &have, &spare) * std_w);
+        double std_w = 1.0 / sqrt((double)(2 * d));
+        int nz = m->ng * d;
+        for (int gate = 0; gate < 4; ++gate) { /* wyrm order: forget, update gate, update value, output gate */
+            int block = m->ng == 4 ? (gate == 0 ? 1 : gate == 1 ? 0 : gate) : (gate == 0 ? 0 : gate == 1 ? -1 : gate - 1);
+            for (int row = 0; row < 2 * d; ++row) {
+                int k = row < d ? d + row : row - d; /* wyrm rows: hidden first; here rows are [x ; h] */
+                for (int u = 0; u < d; ++u) {
+                    float v = orc_rng_normal_f32(&m->rng, 0.0, std_w);
+                    if (block >= 0) m->W[(size_t)k * nz + block * d + u] = v;
+                }
+            }
+        }
     } else {
         m->alpha = (float*)calloc(d, sizeof(float));
         m->alpha_acc = (float*)calloc(d, sizeof(float));
         if (adam) m->alpha_m = (float*)calloc(d, sizeof(float));
+        double std_fc = sqrt(2.0 / (double)(d + d)); /* dense_init, ewma.rs:38-41 */
+        for (int i = 0; i < 2 * d * d; ++i) (void)orc_rng_normal_f32(&m->rng, 0.0, std_fc);
     }
     *out = m;
     return SBR_OK;
@@ -194,12 +193,12 @@ uint64_t orc_model_get_opt_steps(orc_model* m) { return m->opt_steps; }
 
 /* optimiser element update (≙ wyrm optim::{Adagrad, Adam} as recalled) */
 static void orc_opt(orc_model* m, float* w, float* acc, float* mom, float g) {
-    if (m->hp.optimizer == SBR_OPT_ADAM) sbr_adam(w, mom, acc, g, m->hp.learning_rate, m->hp.l2_penalty, m->c1, m->c2);
-    else sbr_adagrad(w, acc, g, m->hp.learning_rate, m->hp.l2_penalty);
+    if (m->hp.optimizer == SBR_OPT_ADAM) orc_adam_step(w, mom, acc, g, m->hp.learning_rate, m->hp.l2_penalty, m->c1, m->c2);
+    else orc_adagrad_step(w, acc, g, m->hp.learning_rate, m->hp.l2_penalty);
 }
 static void orc_begin_optimizer_step(orc_model* m) {
     m->opt_steps += 1;
-    if (m->hp.optimizer == SBR_OPT_ADAM) sbr_adam_corrections(m->opt_steps, &m->c1, &m->c2);
+    if (m->hp.optimizer == SBR_OPT_ADAM) orc_adam_bias_corrections(m->opt_steps, &m->c1, &m->c2);
 }
 static void orc_dense_update(orc_model* m, const float* dg) {
     int d = m->d;
@@ -238,12 +237,15 @@ int orc_chunk_lengths(uint64_t user_len, uint64_t chunk_size, uint64_t* out, int
     return n;
 }
 
-/* Fisher-Yates from the end (rand 0.5 Rng::shuffle as recalled) on (start,len) */
-static void orc_shuffle(uint64_t* start, uint32_t* len, uint64_t n, sbr_xorshift* r) {
-    for (uint64_t i = n; i > 1; --i) {
-        uint64_t j = sbr_xs_below(r, i);
-        uint64_t ts = start[i - 1]; start[i - 1] = start[j]; start[j] = ts;
-        uint32_t tl = len[i - 1]; len[i - 1] = len[j]; len[j] = tl;
+/* rand 0.5 Rng::shuffle as recalled: `let mut i = len; while i >= 2 { i -= 1;
+ * values.swap(i, self.gen_range(0, i + 1)); }` — applied to the (start, len) pairs */
+static void orc_shuffle(uint64_t* start, uint32_t* len, uint64_t n, orc_rng* r) {
+    uint64_t i = n;
+    while (i >= 2) {
+        i -= 1;
+        uint64_t j = orc_rng_gen_range(r, i + 1);
+        uint64_t ts = start[i]; start[i] = start[j]; start[j] = ts;
+        uint32_t tl = len[i]; len[i] = len[j]; len[j] = tl;
     }
 }
 
@@ -306,16 +308,13 @@ int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
     orc_plan* p = (orc_plan*)calloc(1, sizeof(orc_plan));
     p->m = m; p->ndev = ndev; p->nseq_total = nseq; p->part_len = part;
     p->seq_start = start; p->seq_len = len;
-    p->part_rng = (sbr_xorshift*)calloc(ndev, sizeof(sbr_xorshift));
+    p->part_rng = (orc_rng*)calloc(ndev, sizeof(orc_rng));
     p->fit_seed = (uint64_t*)calloc(ndev, 8);
     for (int q = 0; q < ndev; ++q) {
         uint8_t seed[16];
-        for (int i = 0; i < 4; ++i) {
-            uint32_t v = sbr_xs_u32(&m->rng);
-            seed[4 * i] = v & 255; seed[4 * i + 1] = (v >> 8) & 255; seed[4 * i + 2] = (v >> 16) & 255; seed[4 * i + 3] = (v >> 24) & 255;
-        }
-        sbr_xs_seed(&p->part_rng[q], seed);
-        p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
+        orc_rng_gen_seed(&m->rng, seed);
+        orc_rng_from_seed(&p->part_rng[q], seed);
+        p->fit_seed[q] = orc_rng_u64(&p->part_rng[q]);
     }
     p->nnz = user_ptr[num_users];
     p->items = (uint32_t*)malloc((p->nnz ? p->nnz : 1) * 4);
@@ -420,12 +419,12 @@ static void orc_forward(orc_model* m, orc_local* L) {
                 for (int k = 0; k < d; ++k) {
                     float xv = x[k];
                     const float* w = m->W + (size_t)k * nz;
-                    for (int j = 0; j < nz; ++j) z[j] = sbr_fma(xv, w[j], z[j]);
+                    for (int j = 0; j < nz; ++j) z[j] = fmaf(xv, w[j], z[j]);
                 }
                 for (int k = 0; k < d; ++k) {
                     float hv = hp ? hp[k] : 0.0f;
                     const float* w = m->W + (size_t)(d + k) * nz;
-                    for (int j = 0; j < nz; ++j) z[j] = sbr_fma(hv, w[j], z[j]);
+                    for (int j = 0; j < nz; ++j) z[j] = fmaf(hv, w[j], z[j]);
                 }
                 float* g = L->G + (size_t)r * 4 * d;
                 for (int u = 0; u < d; ++u) {
@@ -433,8 +432,10 @@ static void orc_forward(orc_model* m, orc_local* L) {
                     float zf = coupled ? z[u] : z[d + u];
                     float zg = coupled ? z[d + u] : z[2 * d + u];
                     float zo = coupled ? z[2 * d + u] : z[3 * d + u];
-                    sbr_lstm_cell_fwd(zi, zf, zg, zo, cp ? cp[u] : 0.0f, coupled, &g[u], &g[d + u], &g[2 * d + u],
-                                      &g[3 * d + u], &L->C[(size_t)r * d + u], &L->H[(size_t)r * d + u]);
+                    orc_cell cell = orc_lstm_cell(zi, zf, zg, zo, cp ? cp[u] : 0.0f, coupled);
+                    g[u] = cell.i; g[d + u] = cell.f; g[2 * d + u] = cell.g; g[3 * d + u] = cell.o;
+                    L->C[(size_t)r * d + u] = cell.c;
+                    L->H[(size_t)r * d + u] = cell.h;
                 }
             }
         }
@@ -451,9 +452,9 @@ static void orc_forward(orc_model* m, orc_local* L) {
                 } else {
                     const float* sp = L->H + (size_t)(L->off[t - 1] + b) * d;
                     for (int k = 0; k < d; ++k) {
-                        float a = sbr_sigmoidf(m->alpha[k]);
+                        float a = orc_sigmoid(m->alpha[k]);
                         float oma = 1.0f - a;
-                        s[k] = sbr_fma(a, sp[k], oma * x[k]);
+                        s[k] = fmaf(a, sp[k], oma * x[k]);
                     }
                 }
             }
@@ -463,7 +464,7 @@ static void orc_forward(orc_model* m, orc_local* L) {
 
 /* ≙ predict_single in training (lstm.rs:338-350): bias + dot, "tree" order */
 static float orc_score_tree(const orc_model* m, const float* h, uint32_t item) {
-    return m->b[item] + sbr_dot_tree(h, m->E + (size_t)item * m->d, m->d);
+    return m->b[item] + orc_dot_training(h, m->E + (size_t)item * m->d, m->d);
 }
 
 /* Negative sampling + loss + dloss/dh for every packed row.
@@ -480,15 +481,15 @@ static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
         uint32_t nj = 0;
         float neg = 0.0f;
         uint32_t tries = 0;
-        int max_tries = m->hp.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+        int max_tries = m->hp.loss == SBR_LOSS_WARP ? ORC_WARP_TRIES : 1;
         for (int k = 0; k < max_tries; ++k) {
-            nj = sbr_neg_draw(epoch_key, L->ctr[r], (uint32_t)k, I);
+            nj = orc_negative_draw(epoch_key, L->ctr[r], (uint32_t)k, I);
             neg = orc_score_tree(m, h, nj);
             ++tries;
-            if (sbr_warp_violates(pos, neg)) break;
+            if (orc_warp_accepts(pos, neg)) break;
         }
         float g, l;
-        if (m->hp.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g); else l = sbr_loss_hinge(pos, neg, &g);
+        if (m->hp.loss == SBR_LOSS_BPR) l = orc_bpr(pos, neg, &g); else l = orc_hinge(pos, neg, &g);
         L->neg[r] = nj; L->tries[r] = tries; L->coef[r] = g; L->loss[r] = l;
         L->loss_sum += (double)l;
         const float* en = m->E + (size_t)nj * d;
@@ -500,7 +501,7 @@ static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
 }
 
 /* BPTT (≙ loss.backward(1.0), sequence_model.rs:161) + dense gradient of this device.
- * Dense reduction order: packed rows are cut into chunks of SBR_DW_CHUNK_ROWS; inside a chunk a
+ * Dense reduction order: packed rows are cut into chunks of ORC_DW_CHUNK_ROWS; inside a chunk a
  * row-ascending fma chain from 0; chunk partials added in chunk order. */
 static void orc_backward(orc_model* m, orc_local* L) {
     int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
@@ -523,20 +524,19 @@ static void orc_backward(orc_model* m, orc_local* L) {
                 float* dz = L->dZ + (size_t)r * nz;
                 for (int u = 0; u < d; ++u) {
                     float dh = L->dH[(size_t)r * d + u] + (last ? 0.0f : dh_rec[(size_t)b * d + u]);
-                    float dzi, dzf, dzg, dzo, dco;
-                    sbr_lstm_cell_bwd(dh, last ? 0.0f : dc_rec[(size_t)b * d + u], g[u], g[d + u], g[2 * d + u],
-                                      g[3 * d + u], L->C[(size_t)r * d + u], cp ? cp[u] : 0.0f, coupled, &dzi, &dzf,
-                                      &dzg, &dzo, &dco);
-                    dc_rec[(size_t)b * d + u] = dco;
-                    if (coupled) { dz[u] = dzf; dz[d + u] = dzg; dz[2 * d + u] = dzo; }
-                    else { dz[u] = dzi; dz[d + u] = dzf; dz[2 * d + u] = dzg; dz[3 * d + u] = dzo; }
+                    orc_cell_grad cg = orc_lstm_cell_backward(dh, last ? 0.0f : dc_rec[(size_t)b * d + u], g[u], g[d + u],
+                                                              g[2 * d + u], g[3 * d + u], L->C[(size_t)r * d + u],
+                                                              cp ? cp[u] : 0.0f, coupled);
+                    dc_rec[(size_t)b * d + u] = cg.dc_prev;
+                    if (coupled) { dz[u] = cg.dz_f; dz[d + u] = cg.dz_g; dz[2 * d + u] = cg.dz_o; }
+                    else { dz[u] = cg.dz_i; dz[d + u] = cg.dz_f; dz[2 * d + u] = cg.dz_g; dz[3 * d + u] = cg.dz_o; }
                 }
                 /* dxh[k] = chain_j fma(dz[j], W[k][j], acc), acc0 = 0 */
                 for (int k = 0; k < 2 * d; ++k) dxh[k] = 0.0f;
                 for (int j = 0; j < nz; ++j) {
                     float dv = dz[j];
                     const float* w = WT + (size_t)j * 2 * d;
-                    for (int k = 0; k < 2 * d; ++k) dxh[k] = sbr_fma(dv, w[k], dxh[k]);
+                    for (int k = 0; k < 2 * d; ++k) dxh[k] = fmaf(dv, w[k], dxh[k]);
                 }
                 for (int k = 0; k < d; ++k) L->dX[(size_t)r * d + k] = dxh[k];
                 for (int k = 0; k < d; ++k) dh_rec[(size_t)b * d + k] = dxh[d + k];
@@ -546,12 +546,12 @@ static void orc_backward(orc_model* m, orc_local* L) {
         size_t nd = (size_t)(2 * d + 1) * nz;
         float* part = (float*)malloc(sizeof(float) * nd);
         for (size_t i = 0; i < nd; ++i) L->dense[i] = 0.0f;
-        int nchunks = (L->R + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
+        int nchunks = (L->R + ORC_DW_CHUNK_ROWS - 1) / ORC_DW_CHUNK_ROWS;
         /* row -> (t, b) lookup */
         int* row_t = (int*)malloc(sizeof(int) * (L->R ? L->R : 1));
         for (int t = 0; t < L->Tm; ++t) for (int r = L->off[t]; r < L->off[t + 1]; ++r) row_t[r] = t;
         for (int c = 0; c < nchunks; ++c) {
-            int r0 = c * SBR_DW_CHUNK_ROWS, r1 = r0 + SBR_DW_CHUNK_ROWS;
+            int r0 = c * ORC_DW_CHUNK_ROWS, r1 = r0 + ORC_DW_CHUNK_ROWS;
             if (r1 > L->R) r1 = L->R;
             for (size_t i = 0; i < nd; ++i) part[i] = 0.0f;
             for (int r = r0; r < r1; ++r) {
@@ -562,12 +562,12 @@ static void orc_backward(orc_model* m, orc_local* L) {
                 for (int k = 0; k < d; ++k) {
                     float xv = x[k];
                     float* pr = part + (size_t)k * nz;
-                    for (int j = 0; j < nz; ++j) pr[j] = sbr_fma(xv, dz[j], pr[j]);
+                    for (int j = 0; j < nz; ++j) pr[j] = fmaf(xv, dz[j], pr[j]);
                 }
                 for (int k = 0; k < d; ++k) {
                     float hv = hp ? hp[k] : 0.0f;
                     float* pr = part + (size_t)(d + k) * nz;
-                    for (int j = 0; j < nz; ++j) pr[j] = sbr_fma(hv, dz[j], pr[j]);
+                    for (int j = 0; j < nz; ++j) pr[j] = fmaf(hv, dz[j], pr[j]);
                 }
                 float* pb = part + (size_t)2 * d * nz;
                 for (int j = 0; j < nz; ++j) pb[j] = pb[j] + dz[j];
@@ -583,7 +583,7 @@ static void orc_backward(orc_model* m, orc_local* L) {
         float* carry = (float*)calloc((size_t)L->B * d, 4);
         float* dab = (float*)calloc((size_t)L->B * d, 4);
         float* av = (float*)malloc(sizeof(float) * d);
-        for (int k = 0; k < d; ++k) av[k] = sbr_sigmoidf(m->alpha[k]);
+        for (int k = 0; k < d; ++k) av[k] = orc_sigmoid(m->alpha[k]);
         for (int t = L->Tm - 1; t >= 0; --t) {
             int bt = L->off[t + 1] - L->off[t];
             int bnext = t + 1 < L->Tm ? L->off[t + 2] - L->off[t + 1] : 0;
@@ -598,7 +598,7 @@ static void orc_backward(orc_model* m, orc_local* L) {
                         float a = av[k], oma = 1.0f - a;
                         L->dX[(size_t)r * d + k] = oma * ds;
                         carry[(size_t)b * d + k] = a * ds;
-                        dab[(size_t)b * d + k] = sbr_fma(ds, sp[k] - x[k], dab[(size_t)b * d + k]);
+                        dab[(size_t)b * d + k] = fmaf(ds, sp[k] - x[k], dab[(size_t)b * d + k]);
                     } else {
                         L->dX[(size_t)r * d + k] = ds;
                     }
@@ -626,7 +626,7 @@ int orc_fit_step_local(orc_plan* p, int q, uint64_t mb) {
     orc_local* L = &p->loc[q];
     orc_pack(p, q, mb, L);
     orc_forward(p->m, L);
-    orc_score(p->m, L, sbr_epoch_key(p->fit_seed[q], p->epoch_key_epoch));
+    orc_score(p->m, L, orc_epoch_key_of(p->fit_seed[q], p->epoch_key_epoch));
     orc_backward(p->m, L);
     return SBR_OK;
 }
@@ -673,15 +673,15 @@ static int orc_entry_cmp(const void* a, const void* b) {
 }
 
 /* One row's sparse gradient from its sorted entries ent[i..j): chunked in-order reduction, see
- * SBR_SEG_CHUNK in sbr_numerics.h.  Every entry is (source vector, scale, bias flag): input row -> dX,
+ * ORC_SEG_CHUNK in orc_numerics.h.  Every entry is (source vector, scale, bias flag): input row -> dX,
  * target row -> -g*h, negative row -> +g*h; target/negative entries also carry the bias gradient
  * (= scale).  `part` is scratch for one chunk partial [d]. */
 typedef struct { const float* H; const float* dX; const float* coef; } orc_entry_src;
 static void orc_reduce_row(const orc_entry* ent, uint64_t i, uint64_t j, int d, const orc_entry_src* s, uint32_t src_mod,
                            float* g, float* part, float* gb_out, int* has_b_out) {
     float gb = 0.0f; int has_b = 0, first_chunk = 1;
-    for (uint64_t c0 = i; c0 < j; c0 += SBR_SEG_CHUNK) {
-        uint64_t c1 = c0 + SBR_SEG_CHUNK < j ? c0 + SBR_SEG_CHUNK : j;
+    for (uint64_t c0 = i; c0 < j; c0 += ORC_SEG_CHUNK) {
+        uint64_t c1 = c0 + ORC_SEG_CHUNK < j ? c0 + ORC_SEG_CHUNK : j;
         float pb = 0.0f; int phb = 0, first = 1;
         for (uint64_t e = c0; e < c1; ++e) {
             uint32_t src = src_mod ? ent[e].src % src_mod : ent[e].src;
@@ -1007,16 +1007,15 @@ int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, 
         for (uint64_t t = 0; t < n; ++t) {
             const float* x = m->E + (size_t)item_ids[t] * d;
             for (int j = 0; j < nz; ++j) z[j] = m->bW[j];
-            for (int k = 0; k < d; ++k) { float xv = x[k]; const float* w = m->W + (size_t)k * nz; for (int j = 0; j < nz; ++j) z[j] = sbr_fma(xv, w[j], z[j]); }
-            for (int k = 0; k < d; ++k) { float hv = h[k]; const float* w = m->W + (size_t)(d + k) * nz; for (int j = 0; j < nz; ++j) z[j] = sbr_fma(hv, w[j], z[j]); }
+            for (int k = 0; k < d; ++k) { float xv = x[k]; const float* w = m->W + (size_t)k * nz; for (int j = 0; j < nz; ++j) z[j] = fmaf(xv, w[j], z[j]); }
+            for (int k = 0; k < d; ++k) { float hv = h[k]; const float* w = m->W + (size_t)(d + k) * nz; for (int j = 0; j < nz; ++j) z[j] = fmaf(hv, w[j], z[j]); }
             for (int u = 0; u < d; ++u) {
-                float gi, gf, gg, go, cc, hh;
                 float zi = coupled ? 0.0f : z[u];
                 float zf = coupled ? z[u] : z[d + u];
                 float zg = coupled ? z[d + u] : z[2 * d + u];
                 float zo = coupled ? z[2 * d + u] : z[3 * d + u];
-                sbr_lstm_cell_fwd(zi, zf, zg, zo, c[u], coupled, &gi, &gf, &gg, &go, &cc, &hh);
-                c[u] = cc; hn[u] = hh;
+                orc_cell cell = orc_lstm_cell(zi, zf, zg, zo, c[u], coupled);
+                c[u] = cell.c; hn[u] = cell.h;
             }
             memcpy(h, hn, sizeof(float) * d);
         }
@@ -1027,9 +1026,9 @@ int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, 
         for (uint64_t t = 1; t < n; ++t) {
             const float* x = m->E + (size_t)item_ids[t] * d;
             for (int k = 0; k < d; ++k) {
-                float a = sbr_sigmoidf(m->alpha[k]);
+                float a = orc_sigmoid(m->alpha[k]);
                 float oma = 1.0f - a;
-                out[k] = sbr_fma(a, out[k], oma * x[k]);
+                out[k] = fmaf(a, out[k], oma * x[k]);
             }
         }
     }
@@ -1040,7 +1039,7 @@ int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, 
 int orc_predict(orc_model* m, const float* user, const uint32_t* item_ids, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; ++i) {
         if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
-        float s = m->b[item_ids[i]] + sbr_dot_chain(user, m->E + (size_t)item_ids[i] * m->d, m->d);
+        float s = m->b[item_ids[i]] + orc_dot_prediction(user, m->E + (size_t)item_ids[i] * m->d, m->d);
         if (!isfinite(s)) return SBR_ERR_INVALID_PREDICTION;
         out[i] = s;
     }
@@ -1067,7 +1066,7 @@ int orc_mrr_score(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
         if (st != SBR_OK) break;
         st = orc_predict(m, rep, all, I, pred);
         if (st != SBR_OK) break;
-        for (uint64_t t = 0; t + 1 < n; ++t) pred[it[t]] = SBR_F32_MIN; /* :30-32, ALL history items */
+        for (uint64_t t = 0; t + 1 < n; ++t) pred[it[t]] = ORC_F32_MIN; /* :30-32, ALL history items */
         float ts = pred[test_item];
         uint32_t rank = 0;
         for (uint32_t i = 0; i < I; ++i) if (pred[i] >= ts) ++rank; /* :37-41 */
@@ -1083,20 +1082,19 @@ int orc_mrr_score(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
 }
 
 /* ---- scalar primitives exported for unit tests --------------------------------------------- */
-float orc_expf(float x) { return sbr_expf(x); }
-float orc_sigmoidf(float x) { return sbr_sigmoidf(x); }
-float orc_tanhf(float x) { return sbr_tanhf(x); }
-float orc_dot_tree(const float* x, const float* y, int d) { return sbr_dot_tree(x, y, d); }
-float orc_dot_chain(const float* x, const float* y, int d) { return sbr_dot_chain(x, y, d); }
+float orc_sigmoidf(float x) { return orc_sigmoid(x); }
+float orc_tanhf(float x) { return orc_tanh(x); }
+float orc_dot_tree(const float* x, const float* y, int d) { return orc_dot_training(x, y, d); }
+float orc_dot_chain(const float* x, const float* y, int d) { return orc_dot_prediction(x, y, d); }
 uint32_t orc_neg_draw(uint64_t epoch_key, uint32_t ctr, uint32_t try_idx, uint32_t num_items) {
-    return sbr_neg_draw(epoch_key, ctr, try_idx, num_items);
+    return orc_negative_draw(epoch_key, ctr, try_idx, num_items);
 }
-uint64_t orc_epoch_key(uint64_t fit_seed, uint64_t epoch) { return sbr_epoch_key(fit_seed, epoch); }
-void orc_adagrad(float* w, float* G, float g, float lr, float l2) { sbr_adagrad(w, G, g, lr, l2); }
+uint64_t orc_epoch_key(uint64_t fit_seed, uint64_t epoch) { return orc_epoch_key_of(fit_seed, epoch); }
+void orc_adagrad(float* w, float* G, float g, float lr, float l2) { orc_adagrad_step(w, G, g, lr, l2); }
 void orc_xorshift_stream(const uint8_t seed[16], uint32_t* out, int n) {
-    sbr_xorshift r;
-    sbr_xs_seed(&r, seed);
-    for (int i = 0; i < n; ++i) out[i] = sbr_xs_u32(&r);
+    orc_rng r;
+    orc_rng_from_seed(&r, seed);
+    for (int i = 0; i < n; ++i) out[i] = orc_rng_u32(&r);
 }
 /* out[M][N] = k-ascending fma chain seeded with c0 (NULL = 0): what an f32 MFMA accumulation
  * computes; used by tests/test_numerics_gpu.py to pin the "MFMA == fmaf chain" premise. */
@@ -1104,12 +1102,33 @@ void orc_fma_chain_gemm(const float* a, const float* b, const float* c0, int M, 
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < N; ++j) {
             float acc = c0 ? c0[i * N + j] : 0.0f;
-            for (int k = 0; k < K; ++k) acc = sbr_fma(a[i * K + k], b[k * N + j], acc);
+            for (int k = 0; k < K; ++k) acc = fmaf(a[i * K + k], b[k * N + j], acc);
             out[i * N + j] = acc;
         }
 }
 void orc_adam(float* w, float* m1, float* v2, float g, float lr, float l2, uint64_t t) {
     float c1, c2;
-    sbr_adam_corrections(t, &c1, &c2);
-    sbr_adam(w, m1, v2, g, lr, l2, c1, c2);
+    orc_adam_bias_corrections(t, &c1, &c2);
+    orc_adam_step(w, m1, v2, g, lr, l2, c1, c2);
 }
+/* rand 0.5 generators exported for unit tests (tests/test_rand05.py) */
+void orc_rand_stream(const uint8_t seed[16], int what, uint64_t arg, uint64_t arg2, double* out, int n) {
+    orc_rng r;
+    orc_rng_from_seed(&r, seed);
+    for (int i = 0; i < n; ++i) {
+        if (what == 0) out[i] = (double)orc_rng_gen_range(&r, arg);
+        else if (what == 1) out[i] = (double)orc_rng_uniform(&r, arg, arg2);
+        else if (what == 2) out[i] = orc_rng_standard_normal(&r);
+        else { uint8_t s[16]; orc_rng_gen_seed(&r, s); out[i] = (double)s[i % 16]; }
+    }
+}
+uint64_t orc_rand_uniform_u64(const uint8_t seed[16], uint64_t lo, uint64_t hi, int skip) {
+    orc_rng r;
+    orc_rng_from_seed(&r, seed);
+    uint64_t v = 0;
+    for (int i = 0; i <= skip; ++i) v = orc_rng_uniform(&r, lo, hi);
+    return v;
+}
+void orc_tanh_pq(float x, float* p, float* q) { sbr_tanh_pq(x, p, q); }
+/* h of one normal cell with (zi, zf, zg, zo) = (x, x/2, -x, x/4 + 1), c_prev = 1/2: twin of the engine's selftest */
+float orc_selftest_cell_h(float x) { return orc_lstm_cell(x, 0.5f * x, -x, fmaf(0.25f, x, 1.0f), 0.5f, 0).h; }

@@ -52,24 +52,25 @@ sbr_status dmalloc(T** p, size_t count) {
 
 int dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
-struct Normal { /* Marsaglia polar, both variates used (same generator as the oracle's) */
-    sbr_xorshift* r;
-    bool have = false;
-    double spare = 0.0;
-    double next() {
-        if (have) { have = false; return spare; }
-        for (;;) {
-            const double u = 2.0 * sbr_xs_unit(r) - 1.0;
-            const double v = 2.0 * sbr_xs_unit(r) - 1.0;
-            const double s = u * u + v * v;
-            if (s >= 1.0 || s == 0.0) continue;
-            const double f = std::sqrt(-2.0 * std::log(s) / s);
-            spare = v * f;
-            have = true;
-            return u * f;
+/* ≙ wyrm nn::lstm::Parameters::new as recalled: four [(hidden+input) x hidden]
+ * xavier_normal matrices (std 1/sqrt(rows)) drawn one after the other — forget, update gate, update
+ * value, output gate — rows = hidden part first; a coupled layer draws all four and ignores the update
+ * gate's.  Engine layout: W[2d][ng*d], rows [x ; h], column blocks i,f,g,o (coupled: f,g,o). */
+void draw_lstm_weights(sbr_xorshift* rng, int d, int ng, std::vector<float>* w) {
+    const double std_w = 1.0 / std::sqrt((double)(2 * d));
+    const int nz = ng * d;
+    w->assign((size_t)2 * d * nz, 0.0f);
+    for (int gate = 0; gate < 4; ++gate) {
+        const int block = ng == 4 ? (gate == 0 ? 1 : gate == 1 ? 0 : gate) : (gate == 0 ? 0 : gate == 1 ? -1 : gate - 1);
+        for (int row = 0; row < 2 * d; ++row) {
+            const int k = row < d ? d + row : row - d;
+            for (int u = 0; u < d; ++u) {
+                const float v = sbr_rand_normal_f32(rng, 0.0, std_w);
+                if (block >= 0) (*w)[(size_t)k * nz + block * d + u] = v;
+            }
         }
     }
-};
+}
 
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
@@ -521,10 +522,11 @@ sbr::MbView mb_view(const sbr_fit_plan* p, uint64_t i) {
 }
 
 void shuffle_pairs(uint64_t* start, uint32_t* len, uint64_t n, sbr_xorshift* r) {
-    for (uint64_t i = n; i > 1; --i) { /* Fisher-Yates from the end */
-        const uint64_t j = sbr_xs_below(r, i);
-        std::swap(start[i - 1], start[j]);
-        std::swap(len[i - 1], len[j]);
+    for (uint64_t i = n; i >= 2;) { /* rand 0.5 Rng::shuffle: Fisher-Yates from the end over gen_range(0, i + 1) */
+        i -= 1;
+        const uint64_t j = sbr_rand_gen_range(r, i + 1);
+        std::swap(start[i], start[j]);
+        std::swap(len[i], len[j]);
     }
 }
 
@@ -639,19 +641,17 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         hipMemsetAsync(v.b, 0, I * 4, m->stream);
         hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
         std::vector<float> host(I * d);
-        Normal nrm{&m->rng};
-        const double std_e = 1.0 / (double)d;
-        for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_e);
+        const double std_e = 1.0 / (double)d; /* embedding_init, lstm.rs:22-25 */
+        for (size_t i = 0; i < host.size(); ++i) host[i] = sbr_rand_normal_f32(&m->rng, 0.0, std_e);
         if (hipMemcpy(v.E, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
     } else if (table_init == TABLE_OWN_ROWS_DEFERRED) {
         /* every rank walks the whole initialisation stream (the RNG has no skip-ahead through the normal
          * sampler's rejections) and keeps the rows it owns; they are written once the peers' parts are mapped */
         const uint64_t S = shared->slice, r0 = std::min<uint64_t>(I, (uint64_t)hp->device_rank * S), r1 = std::min<uint64_t>(I, r0 + S);
         m->pending_E.resize((size_t)((r1 - r0) * d));
-        Normal nrm{&m->rng};
         const double std_e = 1.0 / (double)d;
         for (uint64_t i = 0; i < I * d; ++i) {
-            const float val = (float)(nrm.next() * std_e);
+            const float val = sbr_rand_normal_f32(&m->rng, 0.0, std_e);
             const uint64_t row = i / d;
             if (row >= r0 && row < r1) m->pending_E[(size_t)(i - r0 * d)] = val;
         }
@@ -677,10 +677,8 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         hipMemsetAsync(v.Wacc, 0, nw * 4, m->stream);
         hipMemsetAsync(v.bW, 0, nb * 4, m->stream);
         hipMemsetAsync(v.bWacc, 0, nb * 4, m->stream);
-        std::vector<float> host(nw);
-        Normal nrm{&m->rng};
-        const double std_w = 1.0 / std::sqrt(2.0 * (double)d);
-        for (size_t i = 0; i < host.size(); ++i) host[i] = (float)(nrm.next() * std_w);
+        std::vector<float> host;
+        draw_lstm_weights(&m->rng, m->d, m->ng, &host);
         if (hipMemcpy(v.W, host.data(), nw * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
         sbr::launch_repack_lstm(v, m->stream);
     } else {
@@ -692,6 +690,10 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         }
         hipMemsetAsync(v.alpha, 0, d * 4, m->stream);
         hipMemsetAsync(v.alpha_acc, 0, d * 4, m->stream);
+        /* the reference also draws the two unused d x d dense_init matrices fc1, fc2 from this RNG
+         * (ewma.rs:179-188): drawn and dropped, so the driver's shuffles start where the reference's do */
+        const double std_fc = std::sqrt(2.0 / (double)(d + d));
+        for (uint64_t i = 0; i < 2 * d * d; ++i) (void)sbr_rand_normal_f32(&m->rng, 0.0, std_fc);
     }
     if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(SBR_ERR_HIP);
     *out = m;
@@ -894,10 +896,7 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     p->fit_seed.resize(ndev);
     for (int q = 0; q < ndev; ++q) { /* :97 — XorShiftRng::from_seed(parameters.rng().gen()) */
         uint8_t seed[16];
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t v = sbr_xs_u32(&m->rng);
-            seed[4 * i] = v & 255; seed[4 * i + 1] = (v >> 8) & 255; seed[4 * i + 2] = (v >> 16) & 255; seed[4 * i + 3] = (v >> 24) & 255;
-        }
+        sbr_rand_gen_seed16(&m->rng, seed);
         sbr_xs_seed(&p->part_rng[q], seed);
         p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
     }
@@ -2146,7 +2145,7 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
 /* ---------------------------------------------------------------------------------------------
  * numerics self-tests (tests/test_numerics_gpu.py): run the contract's primitives on the device
  * ------------------------------------------------------------------------------------------- */
-sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_exp, float* out_sig, float* out_tanh) {
+sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_cell_h, float* out_sig, float* out_tanh) {
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
     float *dx, *de, *ds, *dt;
@@ -2154,7 +2153,7 @@ sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_exp, float* 
     HIPCHK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     sbr::launch_selftest_math(dx, de, ds, dt, n, nullptr);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out_exp, de, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_cell_h, de, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_sig, ds, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_tanh, dt, n * 4, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(de); hipFree(ds); hipFree(dt);

@@ -137,7 +137,7 @@ void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint
                  const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, float* ts_scratch,
                  uint32_t* ranks, uint32_t* nonfinite_flag, hipStream_t s);
 /* device self-tests of the numerics contract (tests/test_numerics_gpu.py) */
-void launch_selftest_math(const float* x, float* out_exp, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s);
+void launch_selftest_math(const float* x, float* out_cell_h, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s);
 void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s);
 void launch_selftest_mfma_chain(const float* a, const float* b, const float* c0, int k, float* out, hipStream_t s);
 void launch_selftest_mfma32_chain(const float* a, const float* b, int k, float* out, hipStream_t s);

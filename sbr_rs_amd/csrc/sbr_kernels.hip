@@ -1787,7 +1787,11 @@ __global__ __launch_bounds__(64) void rank_history_kernel(ModelView m, const flo
 __global__ void selftest_math_kernel(const float* x, float* e, float* s, float* t, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    e[i] = sbr_expf(x[i]);
+    {   /* one LSTM cell (shared-division gate activations): h of (zi, zf, zg, zo) = (x, x/2, -x, x/4 + 1), c_prev = 1/2 */
+        float gi, gf, gg, go, cc, hh;
+        sbr_lstm_cell_fwd(x[i], 0.5f * x[i], -x[i], sbr_fma(0.25f, x[i], 1.0f), 0.5f, 0, &gi, &gf, &gg, &go, &cc, &hh);
+        e[i] = hh;
+    }
     s[i] = sbr_sigmoidf(x[i]);
     t[i] = sbr_tanhf(x[i]);
 }
@@ -2091,8 +2095,8 @@ void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint
     });
 }
 
-void launch_selftest_math(const float* x, float* out_exp, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out_exp, out_sig, out_tanh, n);
+void launch_selftest_math(const float* x, float* out_cell_h, float* out_sig, float* out_tanh, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out_cell_h, out_sig, out_tanh, n);
 }
 void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s) {
     DISPATCH_D(d, {

@@ -1,15 +1,12 @@
-/* sbr_numerics.h — the scalar arithmetic contract of the MI355X sequence-recommender engine.
+/* sbr_numerics.h — the scalar arithmetic contract of the MI355X sequence-recommender engine
+ * (product side: gfx950 device code and the C++ host side of libsbr_hip.so).
  *
- * Everything that decides a *float bit* or an *index* on the hot path is defined here, once,
- * as plain scalar C that compiles unchanged for
- *   - the gfx950 device code (hipcc, -ffp-contract=off),
- *   - the C++ host side of libsbr_hip.so,
- *   - the C CPU oracle under oracle/ (gcc, -ffp-contract=off -mfma).
- * Only IEEE-754 correctly rounded operations are used (+, *, /, sqrt, fma), every fused
- * multiply-add is written explicitly as sbr_fma(), and no libm transcendental is called, so the
- * three builds produce bit-identical results.  The HIP kernels reproduce the *association
- * orders* documented next to each reduction below; that is what makes "bit-exact negatives,
- * ranks and parameters" a testable claim (tests/test_parity_gpu.py).
+ * Everything that decides a *float bit* or an *index* on the hot path is defined here as plain
+ * scalar code built from IEEE-754 correctly rounded operations only (+, *, /, sqrt, fma, min, max);
+ * every fused multiply-add is written explicitly as sbr_fma() and the build uses -ffp-contract=off,
+ * so host and device produce the same bits.  The CPU oracle does NOT include this header: it
+ * restates the same formulas independently (the numerics header under oracle/) and shares only the
+ * approximation polynomial of sbr_approx.h — tests/test_abi.py enforces that.
  *
  * Reference semantics being restated (sbr-rs, /root/reference):
  *   predict_single = bias + dot          src/models/lstm.rs:338-350, src/models/ewma.rs:353-365
@@ -17,14 +14,17 @@
  *   hinge / BPR losses                   src/models/lstm.rs:313-320, src/models/ewma.rs:328-335
  *   EWMA recurrence                      src/models/ewma.rs:302-313
  *   LSTM cell (wyrm::nn::lstm, source absent; classic cell as recalled in SURVEY.md App. B)
- *   Adagrad (wyrm::optim::Adagrad, source absent)
- * The sigmoid/tanh/exp below are this engine's own polynomial kernels (the reference uses
- * wyrm's "fast-math" approximations, which are not available here and not IEEE-exact either).
+ *   Adagrad / Adam (wyrm::optim, source absent)
+ *   rand 0.5 index generators (source absent): XorShiftRng, gen::<[u8; 16]>,
+ *   gen_range / shuffle, Uniform, Normal (ziggurat)
  */
 #ifndef SBR_NUMERICS_H
 #define SBR_NUMERICS_H
 
+#include <math.h>
 #include <stdint.h>
+
+#include "sbr_approx.h"
 
 #if defined(__HIPCC__)
 #define SBR_HD __host__ __device__ __forceinline__
@@ -35,75 +35,34 @@
 /* ---- fixed constants of the contract ------------------------------------------------------ */
 #define SBR_WARP_MAX_TRIES 5            /* sequence_model.rs:58 */
 #define SBR_ADAGRAD_EPS 1e-10f          /* wyrm Adagrad eps (recalled) */
-#define SBR_DW_CHUNK_ROWS 1024
+#define SBR_DW_CHUNK_ROWS 1024          /* split-K chunk (rows of the packed minibatch) for dense grads */
 /* Per-row reduction of sparse gradient entries: a row's entries (sorted by packed row, kind) are cut into
  * chunks of SBR_SEG_CHUNK counted from the row's first entry; a chunk partial is the in-order sum of its
  * entries (the first one initialises), the row total the in-order sum of the chunk partials.  A row with
  * at most SBR_SEG_CHUNK entries is therefore a plain in-order sum; the hot rows of a skewed catalogue get
  * chunk-level parallelism with the same bits everywhere. */
-#define SBR_SEG_CHUNK 256          /* split-K chunk (rows of the packed minibatch) for dense grads */
+#define SBR_SEG_CHUNK 256
 #define SBR_F32_MIN (-3.40282347e+38f)  /* Rust std::f32::MIN, evaluation.rs:31 */
 
 /* ---- primitive helpers ---------------------------------------------------------------------- */
 SBR_HD float sbr_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-SBR_HD float sbr_bits_to_float(uint32_t u) {
-    union { uint32_t u; float f; } v;
-    v.u = u;
-    return v.f;
-}
-SBR_HD uint32_t sbr_float_to_bits(float f) {
-    union { uint32_t u; float f; } v;
-    v.f = f;
-    return v.u;
-}
-
-/* exp(x), |rel err| ~ 1e-7 on [-87, 88]; input clamped to that range.  Cephes-style:
- * n = rne(x*log2 e); r = x - n*ln2 (two-term Cody-Waite); degree-5 minimax in r; scale by 2^n
- * through the exponent field.  The rne() is the 1.5*2^23 magic-number add (exact in fp32). */
-SBR_HD float sbr_expf(float x) {
-    if (x > 88.0f) x = 88.0f;
-    if (x < -87.0f) x = -87.0f;
-    float t = x * 1.44269504088896341f;
-    float n = (t + 12582912.0f) - 12582912.0f;
-    float r = sbr_fma(n, -0.693359375f, x);
-    r = sbr_fma(n, 2.12194440e-4f, r);
-    float p = 1.9875691500e-4f;
-    p = sbr_fma(p, r, 1.3981999507e-3f);
-    p = sbr_fma(p, r, 8.3334519073e-3f);
-    p = sbr_fma(p, r, 4.1665795894e-2f);
-    p = sbr_fma(p, r, 1.6666665459e-1f);
-    p = sbr_fma(p, r, 5.0000001201e-1f);
-    float y = sbr_fma(p, r * r, r);
-    y = y + 1.0f;
-    int32_t e = (int32_t)n + 127; /* in [1, 254] because of the clamp */
-    return y * sbr_bits_to_float((uint32_t)e << 23);
-}
-
-SBR_HD float sbr_sigmoidf(float x) { return 1.0f / (1.0f + sbr_expf(-x)); }
-
+/* ---- activations ------------------------------------------------------------------------------ */
+/* tanh = P/Q (sbr_approx.h), one IEEE division; sigmoid(x) = 1/2 + 1/2 tanh(x/2) */
 SBR_HD float sbr_tanhf(float x) {
-    float ax = x < 0.0f ? -x : x;
-    if (ax < 0.625f) {
-        float z = x * x;
-        float p = -5.70498872745e-3f;
-        p = sbr_fma(p, z, 2.06390887954e-2f);
-        p = sbr_fma(p, z, -5.37397155531e-2f);
-        p = sbr_fma(p, z, 1.33314422036e-1f);
-        p = sbr_fma(p, z, -3.33332819422e-1f);
-        return sbr_fma(p * z, x, x);
-    }
-    float e = sbr_expf(ax + ax);
-    float r = 1.0f - 2.0f / (e + 1.0f);
-    return x < 0.0f ? -r : r;
+    float p, q;
+    sbr_tanh_pq(x, &p, &q);
+    return p / q;
 }
+SBR_HD float sbr_sigmoidf(float x) { return sbr_fma(0.5f, sbr_tanhf(0.5f * x), 0.5f); }
 
 /* ---- dot products --------------------------------------------------------------------------- */
 /* Training-time score dot ("tree" order).  d = 4*L, L a power of two <= 64: lane l owns elements
  * 4l..4l+3 (one 16-byte load on the GPU), forms the partial  p_l = fma(x3,y3,fma(x2,y2,fma(x1,y1,
  * x0*y0))), then the L partials are combined by an xor-butterfly  p_l += p_{l^off}, off = L/2..1
- * (IEEE addition is commutative, so every lane ends with the same bits).  This is the order the
- * wave-level reduction of the gather/WARP-score kernel produces. */
+ * (IEEE addition is commutative, so every lane ends with the same bits).  Prediction-time dots
+ * (user_representation / predict / mrr_score) are k-ascending fma chains from 0 — the order an f32
+ * MFMA accumulation produces. */
 SBR_HD float sbr_dot4_partial(const float* x, const float* y) {
     float p = x[0] * y[0];
     p = sbr_fma(x[1], y[1], p);
@@ -111,26 +70,6 @@ SBR_HD float sbr_dot4_partial(const float* x, const float* y) {
     p = sbr_fma(x[3], y[3], p);
     return p;
 }
-#if !defined(__HIP_DEVICE_COMPILE__)
-static inline float sbr_dot_tree(const float* x, const float* y, int d) {
-    float p[64], q[64];
-    int L = d / 4;
-    for (int l = 0; l < L; ++l) p[l] = sbr_dot4_partial(x + 4 * l, y + 4 * l);
-    for (int off = L / 2; off >= 1; off /= 2) {
-        for (int l = 0; l < L; ++l) q[l] = p[l] + p[l ^ off];
-        for (int l = 0; l < L; ++l) p[l] = q[l];
-    }
-    return p[0];
-}
-/* Prediction-time dot ("chain" order): acc = 0; acc = fma(x_k, y_k, acc), k ascending — the
- * order an f32 MFMA accumulation over k produces (MI355X guide: v_mfma_f32_* is bit-for-bit a
- * k-ordered fmaf chain).  Used by user_representation/predict/mrr_score. */
-static inline float sbr_dot_chain(const float* x, const float* y, int d) {
-    float acc = 0.0f;
-    for (int k = 0; k < d; ++k) acc = sbr_fma(x[k], y[k], acc);
-    return acc;
-}
-#endif
 
 /* ---- counter-based negative sampling -------------------------------------------------------- */
 /* The reference draws negatives from a sequential per-thread xorshift stream with a
@@ -196,24 +135,35 @@ SBR_HD void sbr_adam(float* w, float* m1, float* v2, float g, float lr, float l2
     float step = lr / (__builtin_sqrtf(vhat) + SBR_ADAM_EPS);
     *w = sbr_fma(-step, mhat, *w);
 }
-#include <math.h>
-#if 1 /* host-side helper */
 static inline void sbr_adam_corrections(uint64_t t, float* c1, float* c2) {
     *c1 = (float)(1.0 - pow((double)SBR_ADAM_B1, (double)t));
     *c2 = (float)(1.0 - pow((double)SBR_ADAM_B2, (double)t));
 }
-#endif
 
 /* ---- LSTM cell, element level ----------------------------------------------------------------- */
 /* Forward for one hidden unit given the four pre-activations (i, f, g, o blocks of
- * z = [x_t ; h_{t-1}] W + b, each a k-ascending fma chain seeded with the bias). */
+ * z = [x_t ; h_{t-1}] W + b, each a k-ascending fma chain seeded with the bias):
+ *   i = sig(zi), f = sig(zf), g = tanh(zg), o = sig(zo)   (coupled: i = 1 - f)
+ *   c = f c_prev + i g,   h = o tanh(c)
+ * The four gate activations are rational (P/Q) and share ONE division: with the denominators
+ * qi, qf, qg, qo,  r = 1 / ((qi qf)(qg qo))  and  1/qi = (r (qg qo)) qf  etc. — on the GPU the
+ * cell epilogue is VALU time that f32 MFMAs cannot hide, and an IEEE division is ~10 instructions.
+ * Coupled cells have no input gate: qi = 1 exactly, and the same expressions apply. */
 SBR_HD void sbr_lstm_cell_fwd(float zi, float zf, float zg, float zo, float c_prev, int coupled,
                               float* gi, float* gf, float* gg, float* go, float* c, float* h) {
-    float f = sbr_sigmoidf(zf);
-    float i = coupled ? 1.0f - f : sbr_sigmoidf(zi);
-    float g = sbr_tanhf(zg);
-    float o = sbr_sigmoidf(zo);
-    float cc = sbr_fma(f, c_prev, i * g);
+    float pi = 0.0f, qi = 1.0f, pf, qf, pg, qg, po, qo;
+    if (!coupled) sbr_tanh_pq(0.5f * zi, &pi, &qi);
+    sbr_tanh_pq(0.5f * zf, &pf, &qf);
+    sbr_tanh_pq(zg, &pg, &qg);
+    sbr_tanh_pq(0.5f * zo, &po, &qo);
+    const float q_if = qi * qf, q_go = qg * qo;
+    const float r = 1.0f / (q_if * q_go);
+    const float r_if = r * q_go, r_go = r * q_if;
+    const float f = sbr_fma(0.5f, pf * (r_if * qi), 0.5f);
+    const float i = coupled ? 1.0f - f : sbr_fma(0.5f, pi * (r_if * qf), 0.5f);
+    const float g = pg * (r_go * qo);
+    const float o = sbr_fma(0.5f, po * (r_go * qg), 0.5f);
+    const float cc = sbr_fma(f, c_prev, i * g);
     *gi = i; *gf = f; *gg = g; *go = o; *c = cc;
     *h = o * sbr_tanhf(cc);
 }
@@ -240,11 +190,21 @@ SBR_HD void sbr_lstm_cell_bwd(float dh, float dc_in, float i, float f, float g, 
     *dzo = d_o * (o * (1.0f - o));
 }
 
-/* ---- host-side index generators (never run on the device) ----------------------------------- */
-#if 1
-/* Marsaglia xorshift128 — the algorithm of rand 0.5's XorShiftRng as recalled in SURVEY.md
- * App. C (seed = 16 bytes little endian, all-zero seed replaced).  The reference's exact
- * streams are unpinned (no rand source here), so this is the engine's own documented generator. */
+/* ---- host-side index generators: rand 0.5 as recalled ---------------------
+ * The reference draws every index stream from rand 0.5 (Cargo.toml:19), whose source is not in this
+ * image and which no reference test pins; the algorithms below are the crate's as recalled:
+ *   XorShiftRng           Marsaglia xorshift128; seed = 16 bytes little endian, all-zero replaced;
+ *                         next_u64 = low word first
+ *   gen::<[u8; 16]>()     sixteen next_u32() calls, each truncated to its low byte
+ *                         (XorShiftRng::from_seed(parameters.rng().gen()), sequence_model.rs:97)
+ *   gen_range / shuffle   UniformInt::sample_single: zone = range << leading_zeros(range), draw
+ *                         v = next_u64, accept when the low half of v*range is <= zone, result = high
+ *                         half; shuffle = Fisher-Yates from the end (sequence_model.rs:84,109)
+ *   Uniform::new(lo, hi)  zone = MAX - (MAX - range + 1) % range, same widening-multiply test
+ *                         (user_based_split keys, data.rs:77-78)
+ *   Normal                ziggurat, 256 layers (embedding_init lstm.rs:22-25; LSTM weights)
+ * Host functions: never run on the device. */
+#include "sbr_ziggurat_tables.h"
 typedef struct { uint32_t x, y, z, w; } sbr_xorshift;
 static inline void sbr_xs_seed(sbr_xorshift* r, const uint8_t seed[16]) {
     uint32_t s[4];
@@ -267,18 +227,62 @@ static inline uint64_t sbr_xs_u64(sbr_xorshift* r) {
     uint64_t hi = sbr_xs_u32(r);
     return lo | (hi << 32);
 }
-/* uniform integer in [0, n), n >= 1: 64x64->128 multiply-high with rejection (unbiased) */
-static inline uint64_t sbr_xs_below(sbr_xorshift* r, uint64_t n) {
-    uint64_t thresh = (0 - n) % n;
+static inline void sbr_rand_gen_seed16(sbr_xorshift* r, uint8_t out[16]) {
+    for (int i = 0; i < 16; ++i) out[i] = (uint8_t)sbr_xs_u32(r);
+}
+/* gen_range(0, n), n >= 1 */
+static inline uint64_t sbr_rand_gen_range(sbr_xorshift* r, uint64_t n) {
+    const uint64_t zone = n << __builtin_clzll(n);
     for (;;) {
-        uint64_t v = sbr_xs_u64(r);
-        __uint128_t m = (__uint128_t)v * (__uint128_t)n;
-        if ((uint64_t)m >= thresh) return (uint64_t)(m >> 64);
+        const __uint128_t m = (__uint128_t)sbr_xs_u64(r) * (__uint128_t)n;
+        if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
     }
 }
-static inline double sbr_xs_unit(sbr_xorshift* r) { /* [0,1) with 53 bits */
+/* Uniform::new(lo, hi).sample(), lo < hi */
+static inline uint64_t sbr_rand_uniform(sbr_xorshift* r, uint64_t lo, uint64_t hi) {
+    const uint64_t range = hi - lo; /* new_inclusive(lo, hi - 1): (hi - 1) - lo + 1 */
+    const uint64_t zone = UINT64_MAX - (UINT64_MAX - range + 1) % range;
+    for (;;) {
+        const __uint128_t m = (__uint128_t)sbr_xs_u64(r) * (__uint128_t)range;
+        if ((uint64_t)m <= zone) return lo + (uint64_t)(m >> 64);
+    }
+}
+static inline double sbr_rand_bits_to_f64(uint64_t fraction52, int exponent) {
+    union { uint64_t u; double f; } v;
+    v.u = ((uint64_t)(1023 + exponent) << 52) | fraction52;
+    return v.f;
+}
+static inline double sbr_rand_open01(sbr_xorshift* r) { /* Open01: (0, 1) */
+    return sbr_rand_bits_to_f64(sbr_xs_u64(r) >> 12, 0) - (1.0 - 2.220446049250313e-16 / 2.0);
+}
+static inline double sbr_rand_standard_f64(sbr_xorshift* r) { /* Standard: [0, 1), 53 bits */
     return (double)(sbr_xs_u64(r) >> 11) * (1.0 / 9007199254740992.0);
 }
-#endif
+/* StandardNormal */
+static inline double sbr_rand_standard_normal(sbr_xorshift* r) {
+    for (;;) {
+        const uint64_t bits = sbr_xs_u64(r);
+        const int i = (int)(bits & 0xff);
+        const double u = sbr_rand_bits_to_f64(bits >> 12, 1) - 3.0; /* [2, 4) - 3 = [-1, 1) */
+        const double x = u * SBR_ZIG_NORM_X[i];
+        if (fabs(x) < SBR_ZIG_NORM_X[i + 1]) return x;
+        if (i == 0) { /* tail */
+            double tx = 1.0, ty = 0.0;
+            while (-2.0 * ty < tx * tx) {
+                const double a = sbr_rand_open01(r);
+                const double b = sbr_rand_open01(r);
+                tx = log(a) / SBR_ZIG_NORM_R;
+                ty = log(b);
+            }
+            return u < 0.0 ? tx - SBR_ZIG_NORM_R : SBR_ZIG_NORM_R - tx;
+        }
+        if (SBR_ZIG_NORM_F[i + 1] + (SBR_ZIG_NORM_F[i] - SBR_ZIG_NORM_F[i + 1]) * sbr_rand_standard_f64(r) < exp(-x * x / 2.0))
+            return x;
+    }
+}
+/* Normal::new(mean, std).sample() as f32 */
+static inline float sbr_rand_normal_f32(sbr_xorshift* r, double mean, double std_dev) {
+    return (float)(mean + std_dev * sbr_rand_standard_normal(r));
+}
 
 #endif /* SBR_NUMERICS_H */

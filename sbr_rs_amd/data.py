@@ -188,8 +188,8 @@ def user_based_split(interactions: Interactions, rng: XorShiftRng, test_fraction
     SipHash-2-4 of the user id, train iff ``hash % 100000 > (test_fraction * 100000) as u64``."""
     denominator = 100_000
     train_cutoff = int(np.float32(test_fraction) * np.float32(denominator))
-    key_0 = rng.below(_M64)
-    key_1 = rng.below(_M64)
+    key_0 = rng.uniform(0, _M64)  # Uniform::new(0, std::u64::MAX).sample(rng), data.rs:77-78
+    key_1 = rng.uniform(0, _M64)
     users = interactions._users
     uniq, inverse = np.unique(users, return_inverse=True)
     hashes = _siphash24_u64(key_0, key_1, uniq)

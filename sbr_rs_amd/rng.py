@@ -1,11 +1,12 @@
 """Host-side index RNG — mirror of the reference's ``rand::XorShiftRng`` usage
 (``XorShiftRng::from_seed([42; 16])``, /root/reference/src/models/lstm.rs:428).
 
-The algorithm is Marsaglia xorshift128 as specified in sbr_rs_amd/csrc/sbr_numerics.h
-(``sbr_xorshift``); this class must stay bit-identical with it because a Python-side RNG is
-handed to the engine as a 16-byte seed (``Hyperparameters.rng(rng)``, lstm.rs:122-125).
-rand 0.5's exact streams are not pinned by any reference test (no rand source in this image), so
-the streams are this engine's own.
+rand 0.5 as recalled (the crate's source is not in this image and no reference test
+pins a stream): Marsaglia xorshift128, ``next_u64`` = low word first, ``gen_range`` / ``shuffle`` =
+``UniformInt::sample_single`` (zone = range << leading_zeros), ``Uniform::new`` = modulus zone,
+``gen::<[u8; 16]>`` = sixteen truncated ``next_u32``.  Must stay bit-identical with ``sbr_xorshift`` /
+``sbr_rand_*`` in sbr_rs_amd/csrc/sbr_numerics.h: a Python-side RNG is handed to the engine as a
+16-byte seed (``Hyperparameters.rng(rng)``, lstm.rs:122-125).
 """
 from __future__ import annotations
 
@@ -47,21 +48,44 @@ class XorShiftRng:
         hi = self.next_u32()
         return lo | (hi << 32)
 
-    def below(self, n: int) -> int:
-        """Uniform integer in [0, n): 64x64->128 multiply-high with rejection (sbr_xs_below)."""
-        thresh = ((1 << 64) - n) % n
+    def gen_range(self, low: int, high: int) -> int:
+        """``Rng::gen_range(low, high)`` = ``UniformInt::sample_single``: zone = range << leading_zeros(range);
+        draw v = next_u64, accept when the low half of v * range is <= zone; result = low + high half."""
+        rng = high - low
+        zone = (rng << (64 - rng.bit_length())) & _M64
         while True:
-            m = self.next_u64() * n
-            if (m & _M64) >= thresh:
-                return m >> 64
+            m = self.next_u64() * rng
+            if (m & _M64) <= zone:
+                return low + (m >> 64)
+
+    def uniform(self, low: int, high: int) -> int:
+        """``Uniform::new(low, high).sample(rng)``: zone = MAX - (MAX - range + 1) % range (data.rs:77-78)."""
+        rng = high - low
+        zone = _M64 - (_M64 - rng + 1) % rng
+        while True:
+            m = self.next_u64() * rng
+            if (m & _M64) <= zone:
+                return low + (m >> 64)
+
+    def below(self, n: int) -> int:
+        """``gen_range(0, n)``."""
+        return self.gen_range(0, n)
+
+    def gen_seed(self) -> bytes:
+        """``rng.gen::<[u8; 16]>()``: sixteen ``next_u32`` calls, each truncated to its low byte
+        (``XorShiftRng::from_seed(parameters.rng().gen())``, sequence_model.rs:97)."""
+        return bytes(self.next_u32() & 0xFF for _ in range(16))
 
     def unit(self) -> float:
+        """``rng.gen::<f64>()`` (rand 0.5 ``Standard``): 53 random bits scaled to [0, 1)."""
         return (self.next_u64() >> 11) * (1.0 / 9007199254740992.0)
 
     def permutation(self, n: int) -> np.ndarray:
-        """Fisher-Yates from the end: ``for i in (1..n).rev(): swap(i, below(i+1))``."""
+        """``Rng::shuffle`` applied to 0..n: ``i = n; while i >= 2: i -= 1; swap(i, gen_range(0, i + 1))``."""
         perm = np.arange(n, dtype=np.int64)
-        for i in range(n, 1, -1):
-            j = self.below(i)
-            perm[i - 1], perm[j] = perm[j], perm[i - 1]
+        i = n
+        while i >= 2:
+            i -= 1
+            j = self.gen_range(0, i + 1)
+            perm[i], perm[j] = perm[j], perm[i]
         return perm

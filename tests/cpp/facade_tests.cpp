@@ -200,24 +200,23 @@ static void mrr_test_single_thread(const std::string& csv) {
     const std::size_t num_items = datasets::download_movielens_100k(csv).num_items();
     const auto [test_mrr, train_mrr] = run_test(csv, lstm_test_hyper(num_items, Loss::Hinge, 1), true);
     (void)train_mrr;
-    // the reference's bound (0.081; 0.091 under MKL_CBWR=AVX, lstm.rs:467-470) is a lower bound seen on
-    // ITS RNG streams; this engine's seeds spread over 0.05-0.14.  The harness pins the
-    // value bit for bit against the Python host layer (itself bit-exact with the oracle).
-    CHECK(test_mrr > 0.05f);
+    // the reference's bound: 0.081, 0.091 under MKL_CBWR=AVX — the branch its CI runs (lstm.rs:466-471).
+    // The harness also pins the value bit for bit against the oracle.
+    CHECK(test_mrr > 0.091f);
 }
 
 static void mrr_test_two_threads(const std::string& csv) {
     const std::size_t num_items = datasets::download_movielens_100k(csv).num_items();
     const auto [test_mrr, train_mrr] = run_test(csv, lstm_test_hyper(num_items, Loss::Hinge, 2));
     (void)train_mrr;
-    CHECK(test_mrr > 0.05f); // reference: 0.074 / 0.078 (lstm.rs:492-495)
+    CHECK(test_mrr > 0.078f); // reference: 0.074 / 0.078 under MKL_CBWR=AVX (lstm.rs:490-495)
 }
 
 static void mrr_test_warp(const std::string& csv) {
     const std::size_t num_items = datasets::download_movielens_100k(csv).num_items();
     const auto [test_mrr, train_mrr] = run_test(csv, lstm_test_hyper(num_items, Loss::WARP, 1));
     (void)train_mrr;
-    CHECK(test_mrr > 0.05f); // reference: 0.10 / 0.089 (lstm.rs:517-520)
+    CHECK(test_mrr > 0.089f); // reference: 0.10 / 0.089 under MKL_CBWR=AVX (lstm.rs:514-519)
 }
 
 static void mrr_test_ewma(const std::string& csv) { // ewma.rs:455-487
@@ -233,7 +232,7 @@ static void mrr_test_ewma(const std::string& csv) { // ewma.rs:455-487
                      .batch_sequences(8);
     const auto [test_mrr, train_mrr] = run_test(csv, hyper);
     (void)train_mrr;
-    CHECK(test_mrr > 0.05f);
+    CHECK(test_mrr > 0.091f); // reference: 0.11 / 0.091 under MKL_CBWR=AVX (ewma.rs:478-483)
 }
 
 // ---- the crate's doctest (lib.rs:22-58): max_sequence_length 32, WARP, builder defaults otherwise ----

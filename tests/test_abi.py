@@ -119,3 +119,27 @@ def test_product_never_touches_the_oracle():
         code = re.sub(r'""".*?"""', "", open(os.path.join(ROOT, f)).read(), flags=re.S)
         code = re.sub(r"#.*", "", code)
         assert "/root/reference" not in code, f
+
+
+def test_oracle_shares_only_the_approximation_header():
+    """The oracle states the scalar formulas itself (oracle/orc_numerics.h); from the product it may include
+    nothing but the approximation polynomial (sbr_rs_amd/csrc/sbr_approx.h), and from include/ only the ABI
+    header (types and enum values)."""
+    odir = os.path.join(ROOT, "oracle")
+    for f in os.listdir(odir):
+        if not f.endswith((".c", ".h")):
+            continue
+        for inc in re.findall(r'#\s*include\s*"([^"]+)"', open(os.path.join(odir, f)).read()):
+            target = os.path.normpath(os.path.join(odir, inc))
+            rel = os.path.relpath(target, ROOT)
+            if rel.startswith("sbr_rs_amd"):
+                assert rel == os.path.join("sbr_rs_amd", "csrc", "sbr_approx.h"), (f, inc)
+            elif rel.startswith("include"):
+                assert rel == os.path.join("include", "sbr_hip.h"), (f, inc)
+            else:
+                assert rel.startswith("oracle"), (f, inc)
+    approx = open(os.path.join(ROOT, "sbr_rs_amd", "csrc", "sbr_approx.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", approx, flags=re.S)
+    # nothing but the polynomial lives there: no cell, loss, optimiser or generator
+    for word in ("adagrad", "adam", "lstm", "hinge", "bpr", "xorshift", "sigmoid"):
+        assert word not in code.lower(), word

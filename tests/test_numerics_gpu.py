@@ -32,12 +32,17 @@ def test_math_bitwise(L, oracle_lib):
     n = x.size
     e, s, t = (np.zeros(n, np.float32) for _ in range(3))
     assert L.sbr_selftest_math(_p(x), n, _p(e), _p(s), _p(t)) == 0
-    ce = np.array([oracle_lib.orc_expf(float(v)) for v in x], dtype=np.float32)
+    ce = np.array([oracle_lib.orc_selftest_cell_h(float(v)) for v in x], dtype=np.float32)
     cs = np.array([oracle_lib.orc_sigmoidf(float(v)) for v in x], dtype=np.float32)
     ct = np.array([oracle_lib.orc_tanhf(float(v)) for v in x], dtype=np.float32)
     assert np.array_equal(e.view(np.uint32), ce.view(np.uint32))
     assert np.array_equal(s.view(np.uint32), cs.view(np.uint32))
     assert np.array_equal(t.view(np.uint32), ct.view(np.uint32))
+    # and the device values themselves against float64 libm (the oracle shares the polynomial, so this
+    # is the check that the polynomial is a tanh): 3e-7 for tanh / sigmoid
+    x64 = x.astype(np.float64)
+    assert np.max(np.abs(t.astype(np.float64) - np.tanh(x64))) < 3e-7
+    assert np.max(np.abs(s.astype(np.float64) - 1 / (1 + np.exp(-x64)))) < 3e-7
 
 
 @pytest.mark.parametrize("d", [16, 32, 64, 128, 256])

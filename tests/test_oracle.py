@@ -2,7 +2,8 @@
 tests hold for the hot path: the chunking known-answer test, the split/CSR
 conservation property, FittingError::NoInteractions, and the MovieLens-100K MRR bounds.  Plus
 known-answer tests for the pieces the oracle restates from published algorithms (xorshift128,
-SipHash-2-4) and accuracy bounds for the contract's own exp/sigmoid/tanh kernels."""
+SipHash-2-4; rand 0.5's generators are in tests/test_rand05.py) and accuracy bounds for the contract's
+own sigmoid/tanh."""
 import ctypes as C
 import os
 
@@ -72,33 +73,32 @@ def test_empty_interactions_is_an_error(oracle_lib):
 
 
 # ---- reference tests: lstm.rs:450-520, ewma.rs:463-507 ------------------------------------------
-# (reference bound default / MKL_CBWR=AVX [the CI branch], bound asserted here)
+# (name, model, loss, threads, reference bound default / MKL_CBWR=AVX [the branch the reference's CI runs,
+#  .travis.yml:10]).  Asserted here: the CI-branch bound — the number the reference's own CI asserts.
 MRR_CASES = [
-    ("lstm hinge 1 thread", ModelKind.LSTM_NORMAL, LOSS_HINGE, 1, (0.081, 0.091), 0.070),
-    ("lstm hinge 2 threads", ModelKind.LSTM_NORMAL, LOSS_HINGE, 2, (0.074, 0.078), 0.078),
-    ("lstm warp", ModelKind.LSTM_NORMAL, LOSS_WARP, 1, (0.10, 0.089), 0.080),
-    ("ewma hinge", ModelKind.EWMA, LOSS_HINGE, 1, (0.11, 0.091), 0.091),
-    ("ewma warp", ModelKind.EWMA, LOSS_WARP, 1, (0.14, 0.089), 0.14),
+    ("lstm hinge 1 thread", ModelKind.LSTM_NORMAL, LOSS_HINGE, 1, (0.081, 0.091)),
+    ("lstm hinge 2 threads", ModelKind.LSTM_NORMAL, LOSS_HINGE, 2, (0.074, 0.078)),
+    ("lstm warp", ModelKind.LSTM_NORMAL, LOSS_WARP, 1, (0.10, 0.089)),
+    ("ewma hinge", ModelKind.EWMA, LOSS_HINGE, 1, (0.11, 0.091)),
+    ("ewma warp", ModelKind.EWMA, LOSS_WARP, 1, (0.14, 0.089)),
 ]
 
 
-@pytest.mark.parametrize("name,kind,loss,threads,ref_bounds,bound", MRR_CASES)
-def test_movielens_mrr_bounds(oracle_lib, name, kind, loss, threads, ref_bounds, bound):
-    """The reference's end-to-end tests: MovieLens-100K, seed [42;16], user_based_split 0.2,
-    max_len 128, dim 32, lr 0.16, l2 4e-4, Adagrad, 10 epochs; batch_sequences = 1 is the
-    reference's per-sequence SGD.  Its thresholds are lower bounds observed on ITS split and RNG
-    streams (which cannot be reproduced without rand 0.5); across six of this engine's seeds the
-    same configurations spread over 0.05-0.09 (LSTM) and 0.06-0.14 (EWMA), so three cases clear a
-    reference bound and the two single-thread LSTM cases are held to engine-level bounds
-    (DESIGN.md §3 lists measured values next to the reference's)."""
+@pytest.mark.parametrize("name,kind,loss,threads,ref_bounds", MRR_CASES)
+def test_movielens_mrr_bounds(oracle_lib, name, kind, loss, threads, ref_bounds):
+    """The reference's end-to-end tests, same protocol: MovieLens-100K, XorShiftRng::from_seed([42; 16]),
+    user_based_split 0.2, the SAME advanced RNG moved into the model, max_len 128, dim 32, lr 0.16,
+    l2 4e-4, Adagrad, 10 epochs; batch_sequences = 1 is the reference's per-sequence SGD.  The bound is
+    the reference's own (CI branch).  Test MRR over 188 users has a stream-to-stream standard deviation
+    of ~0.01 on this split (24 model streams per case, means 0.089 / 0.085 / 0.100 / 0.106 /
+    0.127), which is why the reference itself carries two thresholds per case."""
     data, train, test, rng = movielens_protocol()
     hp = hparams(data.num_items(), 128, 32, int(kind), loss, epochs=10, B=1, seed=rng.state_seed(), ndev=threads)
     m = OracleModel(hp)
     m.fit(train.user_pointers, train.item_ids)
     mrr, ranks = m.mrr_score(test.user_pointers, test.item_ids)
     assert len(ranks) == sum(1 for u in test.iter_users() if u.len() >= 2)
-    assert mrr > bound, (name, mrr, ref_bounds)
-    assert mrr > 0.02  # far above chance (1/1683 items)
+    assert mrr > ref_bounds[1], (name, mrr, ref_bounds)
 
 
 def test_movielens_fixture_shape():
@@ -157,16 +157,29 @@ def test_user_based_split_fraction_and_determinism():
     assert te.len() == 20000 and tr.len() == 80000
 
 
-def test_contract_math_accuracy(oracle_lib):
-    x = np.linspace(-87, 88, 20001).astype(np.float32)
-    e = np.array([oracle_lib.orc_expf(float(v)) for v in x], dtype=np.float64)
-    assert np.max(np.abs(e / np.exp(x.astype(np.float64)) - 1)) < 3e-7
-    x = np.linspace(-30, 30, 20001).astype(np.float32)
+def test_activation_accuracy(oracle_lib):
+    """The shared approximation (sbr_approx.h: tanh = P/Q) and what the oracle builds on it, against
+    float64 libm: tanh and sigmoid within 3e-7; a whole cell (four gate activations sharing one
+    division, then tanh(c)) within 1e-6 of the float64 cell."""
+    x = np.concatenate([np.linspace(-30, 30, 40001), np.linspace(-1, 1, 20001), np.linspace(-1e-2, 1e-2, 2001)]).astype(np.float32)
+    x64 = x.astype(np.float64)
     s = np.array([oracle_lib.orc_sigmoidf(float(v)) for v in x], dtype=np.float64)
     t = np.array([oracle_lib.orc_tanhf(float(v)) for v in x], dtype=np.float64)
-    assert np.max(np.abs(s - 1 / (1 + np.exp(-x.astype(np.float64))))) < 2e-7
-    assert np.max(np.abs(t - np.tanh(x.astype(np.float64)))) < 3e-7
+    assert np.max(np.abs(s - 1 / (1 + np.exp(-x64)))) < 3e-7
+    assert np.max(np.abs(t - np.tanh(x64))) < 3e-7
     assert oracle_lib.orc_tanhf(0.0) == 0.0 and oracle_lib.orc_sigmoidf(0.0) == 0.5
+    assert oracle_lib.orc_tanhf(100.0) <= 1.0 and oracle_lib.orc_tanhf(-100.0) >= -1.0
+    p, q = C.c_float(), C.c_float()
+    qs = []
+    for v in np.linspace(-12, 12, 4001):
+        oracle_lib.orc_tanh_pq(float(v), C.byref(p), C.byref(q))
+        qs.append(q.value)
+    assert 4.8e-3 < min(qs) and max(qs) < 0.91  # the range the shared division relies on
+    sig = lambda z: 1 / (1 + np.exp(-z))
+    h = np.array([oracle_lib.orc_selftest_cell_h(float(v)) for v in x], dtype=np.float64)
+    c64 = sig(0.5 * x64) * 0.5 + sig(x64) * np.tanh(-x64)
+    h64 = sig(0.25 * x64 + 1.0) * np.tanh(c64)
+    assert np.max(np.abs(h - h64)) < 1e-6
 
 
 def test_negative_draws_uniform_and_batch_independent(oracle_lib):

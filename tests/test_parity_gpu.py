@@ -559,13 +559,14 @@ def test_test_item_in_history_ranks_last():
 
 
 @pytest.mark.parametrize("kind,loss,B,bound", [
-    (ModelKind.LSTM_NORMAL, LOSS_WARP, 16, 0.07),   # BASELINE.json configs[1]
-    (ModelKind.EWMA, LOSS_HINGE, 16, 0.08),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 16, 0.089),   # BASELINE.json configs[1]; reference bound lstm.rs:514-519 (CI branch)
+    (ModelKind.EWMA, LOSS_HINGE, 16, 0.091),         # reference bound ewma.rs:478-483 (CI branch)
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 1, 0.091),   # the reference's per-sequence SGD, lstm.rs:466-471 (CI branch)
 ])
 def test_movielens_fit_bit_exact_and_mrr(kind, loss, B, bound):
     """MovieLens-100K under the reference's protocol (lstm.rs:427-448, 498-520): 10 epochs,
     dim 32, lr 0.16, l2 4e-4, Adagrad.  The GPU fit must equal the oracle's bit for bit, ranks and
-    MRR included, and clear the (engine-level) MRR sanity bound."""
+    MRR included, and clear the reference's own MRR lower bound (the MKL_CBWR=AVX branch its CI runs)."""
     data, train, test, rng = movielens_protocol()
     hp = hparams(data.num_items(), 128, 32, int(kind), loss, epochs=10, B=B, seed=rng.state_seed())
     g, o = make_pair(hp)

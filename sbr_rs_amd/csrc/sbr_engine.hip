@@ -413,7 +413,8 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
     sbr::WorkView& v = wb->v;
     if (m->ng) {
         SBRCHK(dmalloc(&v.C, rmax * d));
-        SBRCHK(dmalloc(&v.G, rmax * d * 4));
+        v.dump_row0 = (int)rmax;
+        SBRCHK(dmalloc(&v.G, (rmax + 64) * d * 4)); /* + 64 dump rows: where the sequence-resident kernels' lanes of finished sequences store (branch-free stores keep the in-order memory counter statically known) */
         SBRCHK(dmalloc(&v.X, rmax * d));
     }
     if (training) {

@@ -59,6 +59,7 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     uint32_t* tries;        /* [Rmax] */
     double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
     unsigned int* part_tries;
+    int dump_row0;          /* first of the 64 dump rows behind G (= Rmax) */
 };
 
 /* one chunk pointer per device: slices of one gathered buffer (collective transport), or the peers' own

@@ -18,6 +18,7 @@
 
 #include "sbr_kernels.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -37,6 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_FWD_WPE
 #define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
 #endif
+#define SBR_MAX_T 256 /* longest supported max_sequence_length of the sequence-resident kernels */
 #ifndef SBR_FWD_UPW
 #define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
 #endif
@@ -462,8 +464,19 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
 // workgroups drift out of phase over the steps, so one workgroup's gathers/epilogue overlap
 // another's MFMAs (per-step launches start every workgroup in lockstep and serialise the phases).
 // ------------------------------------------------------------------------------------------------
+// A kernel-argument pointer passed through an empty asm: the compiler can no longer hoist "pointer + per-lane
+// offset" out of the time loop as a 64-bit VGPR pair that lives across it (those pairs were being spilled to
+// scratch, and a scratch reload is a vector-memory operation that waits for EVERYTHING outstanding).
+template <class T>
+__device__ __forceinline__ T* launder(T* p) {
+    typedef T __attribute__((address_space(1))) * global_ptr;  // keep the address space: a generic pointer would
+    global_ptr g = (global_ptr)p;                              // turn every access into a flat_ operation
+    asm volatile("" : "+s"(g));
+    return (T*)g;
+}
+
 template <int D, int NG, int RT, int UPW>
-__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles) {
+__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles, int dump_row0) {
     constexpr int K2 = 2 * D;
     constexpr int LDA = K2 + 2;
     constexpr int NS = K2 / 16;
@@ -474,11 +487,17 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
     constexpr int NV = ROWS * (D / 4);
     constexpr int ITER = (NV + NT - 1) / NT;
     __shared__ float As[ROWS * LDA];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j16 = lane & 15;
-    const int kq = lane >> 4;
+    __shared__ int s_off[SBR_MAX_T + 2];
+    const int tid0 = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    // Per-lane values derived from the thread id are re-derived where they are used (the id passes through an
+    // empty asm), so that the compiler does not keep dozens of loop-invariant address pieces alive across the
+    // time loop and spill them
+    auto thread_id = [&]() { int t_ = tid0; asm volatile("" : "+v"(t_)); return t_; };
+    int tid = tid0;
+    int lane = tid & 63;
+    int j16 = lane & 15;
+    int kq = lane >> 4;
     // tiles are sorted by length; fold the list so that consecutive resident slots of a CU get
     // long/short/long/short ... and every CU ends up with about the same number of steps
     const int nslot = 256;
@@ -487,6 +506,9 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
     const int tile = (q & 1) ? q * nslot + (fold_w - 1 - c) : (int)blockIdx.x;
     const int b0 = tile * ROWS;
     const int nsteps = mb.steps[b0];
+    // the row offsets of the steps are read from LDS inside the time loop (a global read there would be a
+    // vector-memory operation queued behind the gathers and the stores)
+    for (int idx = tid; idx <= nsteps; idx += NT) s_off[idx] = mb.off[idx];
     float bias[UPW][NG];
 #pragma unroll
     for (int p = 0; p < UPW; ++p)
@@ -500,22 +522,74 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) cst[rt][p][reg] = 0.0f;
     for (int idx = tid; idx < ROWS * D; idx += NT) As[(idx / D) * LDA + D + (idx % D)] = 0.0f;  // h_{-1} = 0
+    __syncthreads();
+    auto step_rows = [&](int t, int* row_begin, int* nrows) {  // rows of this tile alive at step t
+        const int rb = __builtin_amdgcn_readfirstlane(s_off[t]);
+        int nr = __builtin_amdgcn_readfirstlane(s_off[t + 1]) - rb - b0;
+        *row_begin = rb;
+        *nrows = nr < ROWS ? nr : ROWS;
+    };
     float4 xn[ITER];
-    auto prefetch_x = [&](int row_begin, int nrows) {
+    uint32_t xidx[ITER];  // item ids of the NEXT gather, requested one step before the gather that needs them
+    // (the loaded ids are not touched until that gather is issued: any use right after the request would make
+    // the wave wait for them, and with them for every vector-memory operation issued before)
+    auto prefetch_idx = [&](int t) {  // step t's input item of this thread's rows (t < nsteps)
+        int rb, nr;
+        step_rows(t, &rb, &nr);
+        const uint32_t* in_idx = launder(mb.in_idx);
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * NT;
-            const int i = idx / (D / 4);
-            const int c4 = (idx % (D / 4)) * 4;
-            xn[it] = (idx < NV && i < nrows) ? ld4(m.E + (size_t)mb.in_idx[row_begin + b0 + i] * D + c4)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = 0; it < ITER; ++it) {  // branch-free: lanes of finished sequences read a valid position
+            const int i = (tid + it * NT) / (D / 4);
+            const bool live = tid + it * NT < NV && i < nr;
+            xidx[it] = in_idx[live ? rb + b0 + i : rb];
         }
     };
-    int row_begin = mb.off[0];
-    int nrows = mb.off[1] - row_begin - b0;
-    nrows = nrows < ROWS ? nrows : ROWS;
-    prefetch_x(row_begin, nrows);
-    for (int t = 0; t < nsteps; ++t) {
+    auto prefetch_x = [&]() {  // lanes of finished sequences gather a valid row too: their cells compute on, unobserved
+        const float* E = launder(m.E);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c4 = ((tid + it * NT) % (D / 4)) * 4;
+            xn[it] = ld4(E + ((size_t)xidx[it] * D + c4));
+        }
+    };
+    int row_begin, nrows;
+    step_rows(0, &row_begin, &nrows);
+    // Vector memory operations of a wave retire IN ORDER (loads and stores share one counter), so a weight
+    // fragment requested after an HBM gather or after the epilogue's stores cannot be consumed before those
+    // have completed.  The weights do not change between time steps: the fragment ring therefore runs across
+    // steps — the first PF k-blocks of step t+1 are requested at the end of step t's MFMA loop, AHEAD of the
+    // gather of x_{t+1} and of the epilogue's stores, and the gather is issued after the last fragment request
+    // of the step, with the cell epilogue and a barrier to land under.
+    constexpr int PF = NS < 4 ? NS : (RT >= 4 ? 4 : 2);
+    f32x4 ring[PF][UPW][NG];
+    auto load_b = [&](f32x4 (*dst)[NG], int S) {
+        const float* wbase = launder(m.Wp) + (size_t)(wv * UPW * NG) * NS * 256;
+        const uint32_t lane_off = (uint32_t)(thread_id() & 63) * 4u;
+#pragma unroll
+        for (int p = 0; p < UPW; ++p)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                dst[p][g] = *reinterpret_cast<const f32x4*>(wbase + (uint32_t)(((p * NG + g) * NS + S) * 256) + lane_off);
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_b(ring[j], j);
+    prefetch_idx(0);
+    prefetch_x();
+    if (nsteps > 1) prefetch_idx(1);
+#ifdef SBR_PROF_FWD
+    long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define PROF_MARK(k) { const long long now_ = clock64(); prof[k] += now_ - prof_t; prof_t = now_; }
+    long long prof_t = clock64();
+#else
+#define PROF_MARK(k)
+#endif
+    // x of the step (row_begin, nrows) describe goes from registers into LDS and into X (the copy of the
+    // gathered input rows that the dense-gradient GEMM streams instead of re-gathering E, which lets that GEMM
+    // run concurrently with the sparse update of E)
+    auto stage = [&]() {
+        tid = thread_id();
+        float* X = launder(w.X);
+        float* dump = launder(w.G) + (size_t)dump_row0 * 4 * D;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * NT;
@@ -525,19 +599,24 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
                 float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
                 dst[0] = make_float2(xn[it].x, xn[it].y);
                 dst[1] = make_float2(xn[it].z, xn[it].w);
-                // copy of the gathered input rows: the dense-gradient GEMM streams it instead of
-                // re-gathering E, which lets it run concurrently with the sparse update of E
-                if (i < nrows) st4(w.X + (size_t)(row_begin + b0 + i) * D + c4, xn[it]);
+                float* dst_x = i < nrows ? X + ((size_t)(row_begin + b0 + i) * D + c4) : dump + (i * 4 * D + c4);
+                st4(dst_x, xn[it]);
             }
         }
+    };
+    // One time step.  The body is instantiated twice — step 0 in straight-line code, steps >= 1 in the loop —
+    // and the first PF k-blocks of the MFMA loop are peeled the same way: the compiler derives every
+    // s_waitcnt from a static count of the memory operations issued since, and at a loop header it has to
+    // assume the shortest history of all incoming paths (after the prologue: almost none), which would make
+    // every iteration wait for the previous step's stores and gathers.
+    auto step = [&](int t) {
         __syncthreads();  // x_t staged, h_{t-1} written by the previous epilogue
-        int row_begin_next = 0, nrows_next = 0;
-        if (t + 1 < nsteps) {
-            row_begin_next = mb.off[t + 1];
-            nrows_next = mb.off[t + 2] - row_begin_next - b0;
-            nrows_next = nrows_next < ROWS ? nrows_next : ROWS;
-            prefetch_x(row_begin_next, nrows_next);  // in flight during the MFMAs below
-        }
+        PROF_MARK(1)
+        tid = thread_id();
+        lane = tid & 63;
+        j16 = lane & 15;
+        kq = lane >> 4;
+        const bool more = t + 1 < nsteps;
         f32x4 acc[RT][UPW][NG];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -545,15 +624,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
             for (int p = 0; p < UPW; ++p)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) acc[rt][p][g] = (f32x4){bias[p][g], bias[p][g], bias[p][g], bias[p][g]};
-        float4 bA[UPW][NG], bB[UPW][NG];
-        auto load_b = [&](float4 (*dst)[NG], int S) {
-#pragma unroll
-            for (int p = 0; p < UPW; ++p)
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    dst[p][g] = ld4(m.Wp + ((((size_t)((wv * UPW + p) * NG + g)) * NS + S) * 64 + lane) * 4);
-        };
-        auto mma_block = [&](int S, float4 (*bf)[NG]) {
+        auto mma_block = [&](int S, f32x4 (*bf)[NG]) {
             float av[RT][4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -567,29 +638,67 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
 #pragma unroll
                     for (int p = 0; p < UPW; ++p)
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) {
-                            const float bval = sub == 0 ? bf[p][g].x : sub == 1 ? bf[p][g].y : sub == 2 ? bf[p][g].z : bf[p][g].w;
-                            acc[rt][p][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], bval, acc[rt][p][g], 0, 0, 0);
-                        }
+                        for (int g = 0; g < NG; ++g)
+                            acc[rt][p][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], bf[p][g][sub], acc[rt][p][g], 0, 0, 0);
         };
-        load_b(bA, 0);
+        // sched_barrier: the request that refills a ring slot is issued as soon as the slot has been consumed
+        // (PF - 1 blocks of MFMAs ahead of its use), not sunk to the end of the loop body by the scheduler
+        if constexpr (NS > PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                mma_block(j, ring[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b(ring[j], j + PF);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll 1
-        for (int S = 0; S < NS; S += 2) {
-            load_b(bB, S + 1);
-            mma_block(S, bA);
-            if (S + 2 < NS) load_b(bA, S + 2);
-            mma_block(S + 1, bB);
+            for (int S0 = PF; S0 < NS - PF; S0 += PF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+                    mma_block(S0 + j, ring[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(ring[j], S0 + j + PF);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            mma_block(NS - PF + j, ring[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(ring[j], j);  // step t+1's first blocks, ahead of the gather and of the epilogue's stores (unconditional:
+                                 // a branch here would hide the request count from the wait-count analysis)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PROF_MARK(2)
+        int row_begin_next = 0, nrows_next = 0;
+        if (more) {
+            tid = thread_id();
+            step_rows(t + 1, &row_begin_next, &nrows_next);
+            prefetch_x();  // x_{t+1}: lands under the epilogue
+            if (t + 2 < nsteps) prefetch_idx(t + 2);
+        }
+        PROF_MARK(3)
         __syncthreads();  // every wave is done reading As
+        PROF_MARK(4)
+        tid = thread_id();
+        lane = tid & 63;
+        j16 = lane & 15;
+        kq = lane >> 4;
+        {
+            float* Gb = launder(w.G);
+            float* Cb = launder(w.C);
+            float* Hb = launder(H);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int p = 0; p < UPW; ++p) {
-                const int u = (wv * UPW + p) * 16 + j16;
+                for (int p = 0; p < UPW; ++p) {
+                    const int u = (wv * UPW + p) * 16 + j16;
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = rt * 16 + kq * 4 + reg;
-                    if (i < nrows) {
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = rt * 16 + kq * 4 + reg;
+                        // branch-free stores: the lanes of finished sequences write to the dump rows behind G
+                        const bool live = i < nrows;
                         const size_t r = (size_t)(row_begin + b0 + i);
                         float zi, zf, zg, zo;
                         if (NG == 4) { zi = acc[rt][p][0][reg]; zf = acc[rt][p][1][reg]; zg = acc[rt][p][2][reg]; zo = acc[rt][p][NG - 1][reg]; }
@@ -597,17 +706,30 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? 4 : SBR_FWD_WPE) vo
                         float gi, gf, gg, go, cc, hh;
                         sbr_lstm_cell_fwd(zi, zf, zg, zo, cst[rt][p][reg], NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
                         cst[rt][p][reg] = cc;
-                        float* G = w.G + r * 4 * D;
-                        G[u] = gi; G[D + u] = gf; G[2 * D + u] = gg; G[3 * D + u] = go;
-                        w.C[r * D + u] = cc;
-                        H[r * D + u] = hh;
+                        float* dumprow = Gb + ((size_t)(dump_row0 + i) * 4 * D + u);
+                        float* G = live ? Gb + (r * 4 * D + u) : dumprow;
+                        G[0] = gi; G[D] = gf; G[2 * D] = gg; G[3 * D] = go;
+                        *(live ? Cb + (r * D + u) : dumprow) = cc;
+                        *(live ? Hb + (r * D + u) : dumprow) = hh;
                         As[i * LDA + D + u] = hh;
                     }
                 }
-            }
+        }
+        PROF_MARK(5)
         row_begin = row_begin_next;
         nrows = nrows_next;
-    }
+        if (more) stage();  // the x region of As is free since the barrier above
+        PROF_MARK(0)
+    };
+    stage();
+    step(0);
+#pragma unroll 1
+    for (int t = 1; t < nsteps; ++t) step(t);
+#ifdef SBR_PROF_FWD
+    if ((tile == 40 || tile == 700 || tile == 1400) && lane == 0 && (wv == 0 || wv == 5))
+        printf("FWDPROF tile %d wave %d steps %d per-step cycles: stage(next) %lld bar1 %lld mfma %lld gather-issue %lld bar2 %lld epilogue %lld\n", tile, wv,
+               nsteps, prof[0] / nsteps, prof[1] / nsteps, prof[2] / nsteps, prof[3] / nsteps, prof[4] / nsteps, prof[5] / nsteps);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,8 +1100,16 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wj = wave & 1;
-    const int tk = blockIdx.x / TJ, tj = blockIdx.x % TJ;
-    const int c = blockIdx.y;
+    // XCD-aware tile order: workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has
+    // its own L2.  All tiles of one chunk therefore share an XCD (chunk = 8 * group + id % 8) and follow
+    // each other in that XCD's dispatch order (tile = (id / 8) % tiles), so the chunk's X / H / dZ rows are
+    // fetched from HBM once and re-read by the other tiles from that L2.
+    constexpr int NTILE = ((K2 + 127) / 128) * TJ;
+    const int wid = blockIdx.x;
+    const int tile = (wid >> 3) % NTILE;
+    const int c = (wid >> 3) / NTILE * 8 + (wid & 7);
+    if (c * SBR_DW_CHUNK_ROWS >= mb.R) return;
+    const int tk = tile / TJ, tj = tile % TJ;
     const int r0 = c * SBR_DW_CHUNK_ROWS;
     int r1 = r0 + SBR_DW_CHUNK_ROWS;
     if (r1 > mb.R) r1 = mb.R;
@@ -1862,16 +1992,26 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         });
         return;
     }
-    if (m.d <= 128) { /* sequence-resident kernel: one launch for all time steps */
+    if (m.d <= 128 && tm_host <= SBR_MAX_T) { /* sequence-resident kernel: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
-                constexpr int RT = SBR_FWD_RT;
-                constexpr int UPW = (DD / 16) % SBR_FWD_UPW == 0 ? SBR_FWD_UPW : 1;
-                const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
-                if (m.ng == 4)
-                    hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
-                else
-                    hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
+                constexpr int UPW = 1;
+                static const int rt_env = std::getenv("SBR_FWD_RT") ? std::atoi(std::getenv("SBR_FWD_RT")) : SBR_FWD_RT;
+                if (rt_env >= 4 && DD >= 64) { /* 64-sequence tiles, one workgroup per CU, 256 registers per wave */
+                    constexpr int RT = 4;
+                    const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
+                    if (m.ng == 4)
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                    else
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                } else {
+                    constexpr int RT = 2;
+                    const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
+                    if (m.ng == 4)
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                    else
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                }
             }
         });
         return;
@@ -1968,10 +2108,11 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
     DISPATCH_D(m.d, {
+        const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         if (m.ng == 4)
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(tiles, nch), dim3(256), 0, s, m, mb, blk, w);
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
         else
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(tiles, nch), dim3(256), 0, s, m, mb, blk, w);
+            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
     });
     const size_t n = (size_t)(K2 + 1) * NGD;
     hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);

@@ -424,7 +424,7 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         SBRCHK(dmalloc(&v.part_loss, 2048));
         SBRCHK(dmalloc(&v.part_tries, 2048));
         if (m->ng) {
-            SBRCHK(dmalloc(&v.dZ, rmax * d * (uint64_t)m->ng));
+            SBRCHK(dmalloc(&v.dZ, (rmax + 64) * d * (uint64_t)m->ng)); /* + 64 dump rows (BPTT kernel) */
             SBRCHK(dmalloc(&v.dHrec, bmax * d));
             SBRCHK(dmalloc(&v.dCrec, bmax * d));
             const uint64_t nch = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;

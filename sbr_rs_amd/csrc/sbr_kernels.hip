@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define EWMA_CHUNK_SEQS 256
 #ifndef SBR_FWD_RT
-#define SBR_FWD_RT 2   /* 16-row tiles per sequence-resident workgroup */
+#define SBR_FWD_RT 4   /* 16-row tiles per sequence-resident workgroup (d >= 64; smaller d: 2) */
 #endif
 #ifndef SBR_FWD_WPE
 #define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
@@ -905,141 +905,194 @@ __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5, sequence-resident form: one workgroup owns a tile of 32 sequences for ALL its time steps,
-// walking t downwards.  Per step: (a) cell backward for the tile — every thread owns two
-// (row, 4-unit) items, keeps their dc carry in registers, re-forms dloss/dh from (neg, coef) with
-// two row gathers, reads the recurrent dh from LDS — writes dz into LDS (GEMM operand) and HBM
-// (dense-gradient GEMM); (b) dxh = dz * W^T on v_mfma_f32_16x16x4_f32 (accumulators from 0,
-// j ascending), wave w producing column tiles w (dX of the row, stored) and UT+w (recurrent dh for
-// step t-1, kept in LDS).  The inputs of step t-1 (gates, cell states, embedding rows) are
-// requested before the GEMM of step t and arrive under its MFMAs.  One workgroup per CU; tiles are
-// dispatched longest first, so the tail is made of the shortest tiles.
+// K5, sequence-resident form: one workgroup owns a tile of 16*RT sequences for ALL its time steps, walking t
+// downwards.  Per step: (a) cell backward for the tile — every thread owns RT (row, 4-unit) items, keeps
+// their dc carry in registers, re-forms dloss/dh from (neg, coef) with two row gathers, reads the recurrent
+// dh from LDS — writes dz into LDS (GEMM operand) and HBM (dense-gradient GEMM); (b) dxh = dz * W^T on
+// v_mfma_f32_16x16x4_f32 (accumulators from 0, j ascending), wave w producing column tiles w (dX of the row,
+// stored) and UT+w (recurrent dh for step t-1, written into columns [0, D) of the dz tile once every wave
+// has finished reading it — the two never live at the same time, so they share LDS).
+// Memory operations of a wave retire in order, so the order of issue is part of the design (as in the
+// forward kernel): the weight-fragment ring runs across steps; the row gathers of step t-1 (item ids
+// requested one step earlier) are issued behind the first ring blocks of step t's GEMM and land under it;
+// the gate / cell-state rows of step t-1 are requested after the GEMM's last fragment request and land
+// under the epilogue; loaded values are not touched before the phase that needs them; stores are
+// branch-free (lanes of finished sequences write to dump rows) and step ts = nsteps-1 and the first ring
+// blocks are peeled, so that every wait count is static and exact.
 // ------------------------------------------------------------------------------------------------
-template <int D, int NG>
-__global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+template <int D, int NG, int RT>
+__global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
     constexpr int NGD = NG * D;
     constexpr int LDZ = NGD + 2;
     constexpr int NSZ = NGD / 16;
     constexpr int UT = D / 16;
-    constexpr int NW = UT;
-    constexpr int NT = NW * 64;
-    constexpr int ROWS = 32;
-    constexpr int RT = 2;
+    constexpr int NT = UT * 64;
+    constexpr int ROWS = 16 * RT;
     constexpr int Q = D / 4;
-    constexpr int CITER = (ROWS * Q) / NT;  // = 2 for every supported D
+    constexpr int CITER = (ROWS * Q) / NT;  // = RT
+    constexpr int PF = RT >= 4 ? 4 : (NSZ % 2 == 0 ? 2 : 1);  // ring depth (k-blocks in flight per column tile)
+    static_assert(NSZ >= 2 * PF && NSZ % PF == 0, "ring does not tile the GEMM");
     __shared__ float Zs[ROWS * LDZ];
-    __shared__ float Rs[ROWS * D];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c16 = lane & 15;
-    const int kq = lane >> 4;
+    __shared__ int s_off[SBR_MAX_T + 2];
+    const int tid0 = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    auto thread_id = [&]() { int t_ = tid0; asm volatile("" : "+v"(t_)); return t_; };
     const int b0 = blockIdx.x * ROWS;
     const int nsteps = mb.steps[b0];
-    for (int idx = tid; idx < ROWS * D; idx += NT) Rs[idx] = 0.0f;
+    for (int idx = tid0; idx <= nsteps; idx += NT) s_off[idx] = mb.off[idx];
+    for (int idx = tid0; idx < ROWS * D; idx += NT) Zs[(idx / D) * LDZ + (idx % D)] = 0.0f;  // no recurrent dh yet
+    __syncthreads();
+    auto step_rows = [&](int t, int* row_begin, int* nrows) {  // rows of this tile alive at step t
+        const int rb = __builtin_amdgcn_readfirstlane(s_off[t]);
+        int nr = __builtin_amdgcn_readfirstlane(s_off[t + 1]) - rb - b0;
+        *row_begin = rb;
+        *nrows = nr < ROWS ? nr : ROWS;
+    };
     float dc[CITER][4];
 #pragma unroll
     for (int k = 0; k < CITER; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dc[k][j] = 0.0f;
-    // prefetched cell inputs of the step about to be processed
+    // in flight between phases (raw: nothing below is touched before the cell phase that consumes it)
     float4 pg[CITER][4], pc[CITER], pcp[CITER], pen[CITER], pep[CITER];
     float pcoef[CITER];
-    int p_row_begin = 0, p_nrows = 0;
-    auto prefetch = [&](int t) {
-        p_row_begin = mb.off[t];
-        p_nrows = mb.off[t + 1] - p_row_begin - b0;
-        p_nrows = p_nrows < ROWS ? p_nrows : ROWS;
-        const int prev_begin = t > 0 ? mb.off[t - 1] : 0;
+    uint32_t nidx[CITER], oidx[CITER];
+    // packed row of item k at step t; lanes of finished sequences are sent to the tile's first row (valid memory)
+    auto item_row = [&](int tid, int k, int rb, int nr) {
+        const int i = (tid + k * NT) / Q;
+        return (size_t)(rb + b0 + (i < nr ? i : 0));
+    };
+    auto request_ids = [&](int t) {  // negatives / targets of step t
+        const int tid = thread_id();
+        int rb, nr;
+        step_rows(t, &rb, &nr);
+        const uint32_t* neg = launder(blk.neg);
+        const uint32_t* out = launder(blk.out_idx);
 #pragma unroll
         for (int k = 0; k < CITER; ++k) {
-            const int idx = tid + k * NT;
-            const int i = idx / Q;
-            const int u = (idx % Q) * 4;
-            if (i < p_nrows) {
-                const size_t r = (size_t)(p_row_begin + b0 + i);
-                const float* G = w.G + r * 4 * D;
-                pg[k][0] = ld4(G + u); pg[k][1] = ld4(G + D + u); pg[k][2] = ld4(G + 2 * D + u); pg[k][3] = ld4(G + 3 * D + u);
-                pc[k] = ld4(w.C + r * D + u);
-                pcp[k] = t > 0 ? ld4(w.C + (size_t)(prev_begin + b0 + i) * D + u) : make_float4(0.f, 0.f, 0.f, 0.f);
-                pcoef[k] = blk.coef[r];
-                pen[k] = ld4(m.E + (size_t)blk.neg[r] * D + u);
-                pep[k] = ld4(m.E + (size_t)blk.out_idx[r] * D + u);
-            }
+            const size_t r = item_row(tid, k, rb, nr);
+            nidx[k] = neg[r];
+            oidx[k] = out[r];
         }
     };
-    prefetch(nsteps - 1);
-    for (int t = nsteps - 1; t >= 0; --t) {
-        const int row_begin = p_row_begin;
-        const int nrows = p_nrows;
-        __syncthreads();  // Rs of the previous step is complete, Zs is free
-        // (a) cell backward
+    auto request_gathers = [&](int t) {  // E[neg], E[target], coef of step t (ids requested a step earlier)
+        const int tid = thread_id();
+        int rb, nr;
+        step_rows(t, &rb, &nr);
+        const float* E = launder(m.E);
+        const float* coef = launder(blk.coef);
 #pragma unroll
         for (int k = 0; k < CITER; ++k) {
-            const int idx = tid + k * NT;
-            const int i = idx / Q;
-            const int u = (idx % Q) * 4;
-            float dz[4][4];
+            const int u = ((tid + k * NT) % Q) * 4;
+            pen[k] = ld4(E + ((size_t)nidx[k] * D + u));
+            pep[k] = ld4(E + ((size_t)oidx[k] * D + u));
+            pcoef[k] = coef[item_row(tid, k, rb, nr)];
+        }
+    };
+    // cell state rows: the cell phase of step t needs c_t (pc) and c_{t-1} (pcp); c_{t-1} is step t-1's c_t, so one
+    // row per step is requested and the pair rotates
+    auto request_cstate = [&](float4* dst, int t) {  // c of every sequence of the tile alive at step t (t >= 0)
+        const int tid = thread_id();
+        int rb, nr_live;
+        step_rows(t, &rb, &nr_live);
+        const float* C = launder(w.C);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < CITER; ++k) {
+            const int u = ((tid + k * NT) % Q) * 4;
+            dst[k] = ld4(C + (item_row(tid, k, rb, nr_live) * D + u));
+        }
+    };
+    auto request_gates = [&](int t) {  // gate values of step t
+        const int tid = thread_id();
+        int rb, nr;
+        step_rows(t, &rb, &nr);
+        const float* G = launder(w.G);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dz[g][j] = 0.0f;
-            if (i < nrows) {
+        for (int k = 0; k < CITER; ++k) {
+            const int u = ((tid + k * NT) % Q) * 4;
+            const float* g = G + (item_row(tid, k, rb, nr) * 4 * D + u);
+            pg[k][0] = ld4(g); pg[k][1] = ld4(g + D); pg[k][2] = ld4(g + 2 * D); pg[k][3] = ld4(g + 3 * D);
+        }
+    };
+
+    f32x4 ring0[PF], ring1[PF];
+    auto load_ring = [&](int slot, int S) {
+        const float* wt = launder(m.WTp);
+        const uint32_t lane_off = (uint32_t)(thread_id() & 63) * 4u;
+        ring0[slot] = *reinterpret_cast<const f32x4*>(wt + (size_t)wv * NSZ * 256 + (uint32_t)(S * 256) + lane_off);
+        ring1[slot] = *reinterpret_cast<const f32x4*>(wt + (size_t)(UT + wv) * NSZ * 256 + (uint32_t)(S * 256) + lane_off);
+    };
+    // ---- prologue: everything step ts = nsteps-1 needs
+    const int ts = nsteps - 1;
+    request_ids(ts);
+    request_gates(ts);
+    request_cstate(pc, ts);
+    request_cstate(pcp, ts > 0 ? ts - 1 : 0);
+    request_gathers(ts);
+    if (ts > 0) request_ids(ts - 1);
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_ring(j, j);
+
+    auto step = [&](int t) {
+        int row_begin, nrows, nrows_above = 0;
+        step_rows(t, &row_begin, &nrows);
+        if (t + 1 < nsteps) { int rb_; step_rows(t + 1, &rb_, &nrows_above); }
+        __syncthreads();  // A: the recurrent dh of step t+1 is in Zs[:, 0:D)
+        // (a) cell backward
+        {
+            const int tid = thread_id();
+            float* dZ = launder(w.dZ);
+#pragma unroll
+            for (int k = 0; k < CITER; ++k) {
+                const int idx = tid + k * NT;
+                const int i = idx / Q;
+                const int u = (idx % Q) * 4;
+                const bool live = i < nrows;
+                const bool carried = i < nrows_above;  // the sequence has a step t+1: recurrent dh and dc exist
+                const float2 r01 = *reinterpret_cast<const float2*>(&Zs[i * LDZ + u]);
+                const float2 r23 = *reinterpret_cast<const float2*>(&Zs[i * LDZ + u + 2]);
+                const float recv[4] = {carried ? r01.x : 0.0f, carried ? r01.y : 0.0f, carried ? r23.x : 0.0f, carried ? r23.y : 0.0f};
                 const float g_ = pcoef[k];
-                const float4 rec = *reinterpret_cast<const float4*>(&Rs[i * D + u]);
                 const float dhl[4] = {g_ * pen[k].x - g_ * pep[k].x, g_ * pen[k].y - g_ * pep[k].y,
                                       g_ * pen[k].z - g_ * pep[k].z, g_ * pen[k].w - g_ * pep[k].w};
-                const float recv[4] = {rec.x, rec.y, rec.z, rec.w};
                 const float gi[4] = {pg[k][0].x, pg[k][0].y, pg[k][0].z, pg[k][0].w};
                 const float gf[4] = {pg[k][1].x, pg[k][1].y, pg[k][1].z, pg[k][1].w};
                 const float gg[4] = {pg[k][2].x, pg[k][2].y, pg[k][2].z, pg[k][2].w};
                 const float go[4] = {pg[k][3].x, pg[k][3].y, pg[k][3].z, pg[k][3].w};
                 const float cc[4] = {pc[k].x, pc[k].y, pc[k].z, pc[k].w};
                 const float cp[4] = {pcp[k].x, pcp[k].y, pcp[k].z, pcp[k].w};
+                float dz[4][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float dh = dhl[j] + recv[j];
                     float dco;
-                    sbr_lstm_cell_bwd(dh, dc[k][j], gi[j], gf[j], gg[j], go[j], cc[j], cp[j], NG == 3, &dz[0][j], &dz[1][j],
-                                      &dz[2][j], &dz[3][j], &dco);
+                    sbr_lstm_cell_bwd(dh, carried ? dc[k][j] : 0.0f, gi[j], gf[j], gg[j], go[j], cc[j], t > 0 ? cp[j] : 0.0f, NG == 3,
+                                      &dz[0][j], &dz[1][j], &dz[2][j], &dz[3][j], &dco);
                     dc[k][j] = dco;
                 }
-                float* dZ = w.dZ + (size_t)(row_begin + b0 + i) * NGD;
+                float* dzrow = live ? dZ + (size_t)(row_begin + b0 + i) * NGD : dZ + (size_t)(w.dump_row0 + i) * NGD;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int src = NG == 4 ? g : g + 1;
-                    st4(dZ + g * D + u, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3]));
+                    st4(dzrow + g * D + u, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3]));
+                    float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + g * D + u]);
+                    dst[0] = make_float2(dz[src][0], dz[src][1]);
+                    dst[1] = make_float2(dz[src][2], dz[src][3]);
                 }
             }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int src = NG == 4 ? g : g + 1;
-                float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + g * D + u]);
-                dst[0] = make_float2(dz[src][0], dz[src][1]);
-                dst[1] = make_float2(dz[src][2], dz[src][3]);
-            }
         }
-        __syncthreads();
-        // (b) GEMM.  Vector loads retire in order, so the weight-fragment loads of the first PFD
-        // k-blocks are issued BEFORE the (slow, HBM) prefetch of step t-1's cell inputs: the MFMAs
-        // of those blocks then run without waiting behind the gathers, which get PFD blocks of
-        // MFMA time to land.
-        constexpr int PFD = NSZ % 8 == 0 ? 8 : (NSZ % 6 == 0 ? 6 : (NSZ % 4 == 0 ? 4 : (NSZ % 3 == 0 ? 3 : (NSZ % 2 == 0 ? 2 : 1))));
+        __syncthreads();  // B: dz tile complete
+        // (b) GEMM
+        const int tid = thread_id();
+        const int lane = tid & 63;
+        const int c16 = lane & 15;
+        const int kq = lane >> 4;
         f32x4 acc[2][RT];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[cc][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* wp0 = m.WTp + ((size_t)wv * NSZ * 64 + lane) * 4;
-        const float* wp1 = m.WTp + ((size_t)(UT + wv) * NSZ * 64 + lane) * 4;
-        float4 ring0[PFD], ring1[PFD];
-#pragma unroll
-        for (int S = 0; S < PFD; ++S) {
-            ring0[S] = ld4(wp0 + (size_t)S * 256);
-            ring1[S] = ld4(wp1 + (size_t)S * 256);
-        }
-        if (t > 0) prefetch(t - 1);
-        auto mma_block = [&](int S, float4 b0v, float4 b1v) {
+        auto mma_block = [&](int S, int slot) {
             float av[RT][4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -1047,37 +1100,73 @@ __global__ __launch_bounds__((D / 16) * 64) void lstm_bwd_seq_kernel(ModelView m
                 av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
             }
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const float v0 = sub == 0 ? b0v.x : sub == 1 ? b0v.y : sub == 2 ? b0v.z : b0v.w;
-                const float v1 = sub == 0 ? b1v.x : sub == 1 ? b1v.y : sub == 2 ? b1v.z : b1v.w;
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], v0, acc[0][rt], 0, 0, 0);
-                    acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], v1, acc[1][rt], 0, 0, 0);
+                    acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], ring0[slot][sub], acc[0][rt], 0, 0, 0);
+                    acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], ring1[slot][sub], acc[1][rt], 0, 0, 0);
                 }
-            }
         };
-#pragma unroll 1
-        for (int S0 = 0; S0 < NSZ; S0 += PFD) {
 #pragma unroll
-            for (int j = 0; j < PFD; ++j) {
-                mma_block(S0 + j, ring0[j], ring1[j]);
-                if (S0 + j + PFD < NSZ) {
-                    ring0[j] = ld4(wp0 + (size_t)(S0 + j + PFD) * 256);
-                    ring1[j] = ld4(wp1 + (size_t)(S0 + j + PFD) * 256);
-                }
+        for (int j = 0; j < PF; ++j) {  // head (peeled)
+            mma_block(j, j);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ring(j, j + PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t > 0) {  // behind the head's fragment requests: gathers of step t-1, ids of step t-2
+            request_gathers(t - 1);
+            request_ids(t > 1 ? t - 2 : 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int S0 = PF; S0 < NSZ - PF; S0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                mma_block(S0 + j, j);
+                __builtin_amdgcn_sched_barrier(0);
+                load_ring(j, S0 + j + PF);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // epilogue: dX to HBM, recurrent dh to LDS (Rs was consumed before the second barrier above)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int j = 0; j < PF; ++j) {  // tail
+            mma_block(NSZ - PF + j, j);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // gate and cell-state rows of step t-1: requested now (the fragment ring is dead), they land under the
+        // epilogue and the barrier.  At t = 0 nothing follows; the requests are kept (valid rows, values unused)
+        // so that the operation counts stay static.
+        {
+            const int tn = t > 0 ? t - 1 : 0;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int i = rt * 16 + kq * 4 + reg;
-                if (i < nrows) blk.dX[(size_t)(row_begin + b0 + i) * D + wv * 16 + c16] = acc[0][rt][reg];
-                Rs[i * D + wv * 16 + c16] = acc[1][rt][reg];
-            }
-    }
+            for (int k = 0; k < CITER; ++k) pc[k] = pcp[k];
+            request_gates(tn);
+            request_cstate(pcp, tn > 0 ? tn - 1 : 0);
+        }
+        __syncthreads();  // C: every wave is done reading the dz tile
+        // epilogue: dX to HBM (branch-free), recurrent dh into columns [0, D) of the tile
+        {
+            float* dX = launder(blk.dX);
+            float* dump = launder(w.dZ) + (size_t)w.dump_row0 * NGD;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = rt * 16 + kq * 4 + reg;
+                    float* dst = i < nrows ? dX + ((size_t)(row_begin + b0 + i) * D + wv * 16 + c16) : dump + (i * NGD + wv * 16 + c16);
+                    *dst = acc[0][rt][reg];
+                    Zs[i * LDZ + wv * 16 + c16] = acc[1][rt][reg];
+                }
+        }
+        // first fragment blocks of the next step's GEMM (the weights do not change): requested behind the
+        // epilogue's stores, which have the whole cell phase to retire
+#pragma unroll
+        for (int j = 0; j < PF; ++j) load_ring(j, j);
+    };
+    step(ts);
+#pragma unroll 1
+    for (int t = ts - 1; t >= 0; --t) step(t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2071,14 +2160,22 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         return;
     }
     bool stepwise = true;
-    if (m.d <= 128) { /* sequence-resident BPTT: one launch for all time steps */
+    if (m.d <= 128 && tm_host <= SBR_MAX_T) { /* sequence-resident BPTT: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
-                const int ntiles = (b_host + 31) / 32;
-                if (m.ng == 4)
-                    hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
-                else
-                    hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                if constexpr (DD >= 64) { /* 64-sequence tiles, one workgroup per CU */
+                    const int ntiles = (b_host + 63) / 64;
+                    if (m.ng == 4)
+                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                    else
+                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                } else {
+                    const int ntiles = (b_host + 31) / 32;
+                    if (m.ng == 4)
+                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 2>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                    else
+                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3, 2>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                }
                 stepwise = false;
             }
         });

@@ -20,3 +20,17 @@ def oracle_lib():
 
     oracle.build()
     return oracle.lib()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """PyTorch bundles its own HIP runtime; it must initialise before libsbr_hip.so brings in the system one
+    (the other order leaves torch with "No HIP GPUs are available").  No-op on a machine without a GPU."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield

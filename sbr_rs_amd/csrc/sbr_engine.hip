@@ -938,6 +938,14 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         if (st == SBR_OK) st = dmalloc(&p->seg.P, units * (uint64_t)m->d);
         if (st == SBR_OK) st = dmalloc(&p->seg.Pb, units);
         if (st == SBR_OK) st = dmalloc(&p->seg.Pf, units);
+        if (st == SBR_OK) st = dmalloc(&p->seg.head_pos, max_entries + 1);
+        if (st == SBR_OK) st = dmalloc(&p->seg.nheads, 1);
+        if (st == SBR_OK) {
+            p->seg.select_temp_bytes = sbr::sparse_select_temp_bytes(max_entries);
+            uint8_t* tmp = nullptr;
+            st = dmalloc(&tmp, p->seg.select_temp_bytes);
+            p->seg.select_temp = tmp;
+        }
     }
     if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
@@ -977,6 +985,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     hipFree(p->loss_acc); hipFree(p->ex_acc);
     hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
     hipFree(p->seg.P); hipFree(p->seg.Pb); hipFree(p->seg.Pf);
+    hipFree(p->seg.head_pos); hipFree(p->seg.nheads); hipFree(p->seg.select_temp);
     hipFree(p->glist); hipFree(p->gblist); hipFree(p->gfl); hipFree(p->bounds_dev);
     hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
     delete p;
@@ -1190,7 +1199,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     HIPCHK(hipStreamWaitEvent(side, m->ev_scored, 0));
     {
         ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, side);
-        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, side);
+        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, side);
     }
     HIPCHK(hipEventRecord(m->ev_sorted, side));
     {

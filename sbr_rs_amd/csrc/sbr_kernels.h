@@ -78,6 +78,12 @@ struct SegScratch {
     float* Pb;
     uint32_t* Pf;         /* 1 = the chunk has a bias contribution */
     uint32_t cap;         /* capacity of the long-segment arrays */
+    /* segment heads of the sorted keys (positions whose row differs from the previous key's), ascending, plus
+     * the sentinel head_pos[*nheads] = number of keys; produced right after the sort, on its stream */
+    uint32_t* head_pos;
+    uint32_t* nheads;
+    void* select_temp;
+    size_t select_temp_bytes;
 };
 
 /* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
@@ -114,8 +120,9 @@ void launch_repack_lstm(const ModelView& m, hipStream_t s);
  * consumers: optimiser update (single device), the owners' dense send chunks (replicated multi-device),
  * the position-addressed list + owner bounds (partitioned table) */
 size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits);
+size_t sparse_select_temp_bytes(size_t max_entries);
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                     size_t sort_temp_bytes, int key_bits, hipStream_t s);
+                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s);
 void launch_seg_apply(const ModelView& m, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted,
                       const SegScratch& sc, hipStream_t s);
 void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,

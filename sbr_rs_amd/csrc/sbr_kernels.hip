@@ -22,6 +22,8 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "../../include/sbr_hip.h"
 #include "sbr_numerics.h"
@@ -1033,11 +1035,20 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
 #pragma unroll
     for (int j = 0; j < PF; ++j) load_ring(j, j);
 
+#ifdef SBR_PROF_BWD
+    long long bprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define BPROF(k_) { const long long now_ = clock64(); bprof[k_] += now_ - bprof_t; bprof_t = now_; }
+    long long bprof_t = clock64();
+#else
+#define BPROF(k_)
+#endif
     auto step = [&](int t) {
         int row_begin, nrows, nrows_above = 0;
         step_rows(t, &row_begin, &nrows);
         if (t + 1 < nsteps) { int rb_; step_rows(t + 1, &rb_, &nrows_above); }
+        BPROF(0)
         __syncthreads();  // A: the recurrent dh of step t+1 is in Zs[:, 0:D)
+        BPROF(1)
         // (a) cell backward
         {
             const int tid = thread_id();
@@ -1081,7 +1092,9 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
                 }
             }
         }
+        BPROF(2)
         __syncthreads();  // B: dz tile complete
+        BPROF(3)
         // (b) GEMM
         const int tid = thread_id();
         const int lane = tid & 63;
@@ -1144,7 +1157,9 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
             request_gates(tn);
             request_cstate(pcp, tn > 0 ? tn - 1 : 0);
         }
+        BPROF(4)
         __syncthreads();  // C: every wave is done reading the dz tile
+        BPROF(5)
         // epilogue: dX to HBM (branch-free), recurrent dh into columns [0, D) of the tile
         {
             float* dX = launder(blk.dX);
@@ -1167,6 +1182,11 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
     step(ts);
 #pragma unroll 1
     for (int t = ts - 1; t >= 0; --t) step(t);
+#ifdef SBR_PROF_BWD
+    if ((blockIdx.x == 20 || blockIdx.x == 350) && (tid0 & 63) == 0 && (wv == 0 || wv == 5))
+        printf("BWDPROF tile %d wave %d steps %d per-step cycles: epilogue+ringreq %lld barA %lld cell %lld barB %lld gemm+requests %lld barC %lld\n", (int)blockIdx.x, wv,
+               nsteps, bprof[0] / nsteps, bprof[1] / nsteps, bprof[2] / nsteps, bprof[3] / nsteps, bprof[4] / nsteps, bprof[5] / nsteps);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1407,19 +1427,39 @@ __device__ __forceinline__ void row_update(const ModelView& m, uint64_t row, int
 // finished row (Emit): optimiser update, write into the owner's send chunk, or entry of the list.
 // ------------------------------------------------------------------------------------------------
 
+struct RowPrefetch {  // the row's parameter / optimiser-state quads, requested as soon as the row id is known
+    float4 w, a, mo;
+};
 struct EmitApply {  // single device: one optimiser update per touched row
     ModelView m;
     template <int D>
-    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb) const {
-        row_update<D>(m, r, lg, g, has_b, gb);
+    __device__ __forceinline__ RowPrefetch pre(uint32_t r, int lg) const {
+        RowPrefetch q;
+        q.w = ld4(m.E + (size_t)r * D + 4 * lg);
+        q.a = ld4(m.Eacc + (size_t)r * D + 4 * lg);
+        q.mo = m.optimizer == SBR_OPT_ADAM ? ld4(m.Em + (size_t)r * D + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        return q;
     }
-    __device__ __forceinline__ void not_head(uint64_t, int) const {}
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb, RowPrefetch q) const {
+        const bool adam = m.optimizer == SBR_OPT_ADAM;
+        opt_update(m, &q.w.x, &q.a.x, &q.mo.x, g.x);
+        opt_update(m, &q.w.y, &q.a.y, &q.mo.y, g.y);
+        opt_update(m, &q.w.z, &q.a.z, &q.mo.z, g.z);
+        opt_update(m, &q.w.w, &q.a.w, &q.mo.w, g.w);
+        st4(m.E + (size_t)r * D + 4 * lg, q.w);
+        st4(m.Eacc + (size_t)r * D + 4 * lg, q.a);
+        if (adam) st4(m.Em + (size_t)r * D + 4 * lg, q.mo);
+        if (has_b) bias_update(m, r, lg, gb);
+    }
 };
 struct EmitChunk {  // replicated multi-device: the row's sum goes into the owner's dense send chunk
     void* send;
     uint64_t S;
     template <int D>
-    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb) const {
+    __device__ __forceinline__ RowPrefetch pre(uint32_t, int) const { return RowPrefetch{}; }
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb, RowPrefetch) const {
         float* c = reinterpret_cast<float*>(send) + (r / S) * S * ((uint64_t)D + 2);
         const uint64_t lr = r % S;
         st4(c + lr * D + 4 * lg, g);
@@ -1428,22 +1468,20 @@ struct EmitChunk {  // replicated multi-device: the row's sum goes into the owne
             reinterpret_cast<uint32_t*>(c + S * D + S)[lr] = 1u | (has_b ? 2u : 0u);
         }
     }
-    __device__ __forceinline__ void not_head(uint64_t, int) const {}
 };
-struct EmitList {  // partitioned table: list entry addressed by the position of the row's first key
-    float* G;
+struct EmitList {  // partitioned table: list entry addressed by the position of the row's first key (fl is
+    float* G;       // cleared beforehand: 0 at every position that is not a segment head)
     float* gbl;
     uint32_t* fl;
     template <int D>
-    __device__ __forceinline__ void row(uint32_t, uint64_t p, int lg, float4 g, bool has_b, float gb) const {
+    __device__ __forceinline__ RowPrefetch pre(uint32_t, int) const { return RowPrefetch{}; }
+    template <int D>
+    __device__ __forceinline__ void row(uint32_t, uint64_t p, int lg, float4 g, bool has_b, float gb, RowPrefetch) const {
         st4(G + p * D + 4 * lg, g);
         if (lg == 0) {
             gbl[p] = gb;
             fl[p] = 1u | (has_b ? 2u : 0u);
         }
-    }
-    __device__ __forceinline__ void not_head(uint64_t p, int lg) const {
-        if (lg == 0) fl[p] = 0u;
     }
 };
 
@@ -1501,41 +1539,57 @@ __device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, u
     return lo;
 }
 
+// One lane group per SEGMENT (the heads of the sorted keys were listed right after the sort): the group knows
+// the segment's first key position p and its length from two consecutive heads, fetches the key window with
+// one coalesced load, and then has every address it needs — the row's parameter / optimiser-state quads and
+// the gradient source rows are requested together, so a segment costs two dependent memory round trips (keys,
+// rows) instead of three, and no lane group spends a round trip finding out that its position is not a head.
+// The next segment's (p, length) is requested before the current one is processed.
 template <int D, class Emit>
 __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave = (uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6);
+    const uint32_t nwaves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
     const int gbase = grp * L;
-    for (uint64_t p = wave * GPW + grp; p < n; p += nwaves * GPW) {
-        // The kernel is bound by dependent memory round trips, so the keys are fetched cooperatively: lane
-        // lg of the group reads key p + lg (one coalesced load for the whole window of L keys), the group
-        // learns the segment length from a ballot, and the sources of the entries are then broadcast from
-        // the lanes that hold them.  Segments longer than the window fall back to bisection.
-        const bool inb = p + lg < n;
-        const uint64_t kmine = keys[inb ? p + lg : n - 1];
-        const uint64_t kprev = keys[p > 0 ? p - 1 : 0];
-        const uint32_t hi = (uint32_t)(kmine >> 32), lo = (uint32_t)kmine;
-        const uint32_t row = (uint32_t)__shfl((int)hi, gbase, 64);
-        const unsigned long long bal = __ballot(inb && hi == row);
-        if (p > 0 && (uint32_t)(kprev >> 32) == row) {
-            emit.not_head(p, lg);
+    const uint32_t nheads = *sc.nheads;
+    const uint32_t stride = nwaves * GPW;
+    uint32_t h = wave * GPW + grp;
+    uint32_t p_cur = sc.head_pos[h < nheads ? h : nheads], p_end = sc.head_pos[h < nheads ? h + 1 : nheads];
+    for (uint32_t h0 = wave * GPW; h0 < nheads; h0 += stride, h += stride) {  // wave-uniform trip count
+        const bool active = h < nheads;
+        const uint32_t hn = h + stride;
+        const uint32_t p_next = sc.head_pos[hn < nheads ? hn : nheads], p_next_end = sc.head_pos[hn < nheads ? hn + 1 : nheads];
+        const uint64_t p = p_cur;
+        const uint32_t len = active ? p_end - p_cur : 0u;
+        const uint32_t cnt = len < (uint32_t)L ? len : (uint32_t)L;  // entries of the segment inside the key window
+        const uint64_t kmine = keys[(uint32_t)lg < cnt ? p + lg : (p < n ? p : 0)];
+        const uint32_t lo = (uint32_t)kmine;
+        const uint32_t row = (uint32_t)__shfl((int)(uint32_t)(kmine >> 32), gbase, 64);
+        p_cur = p_next;
+        p_end = p_next_end;
+        if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
+            if (lg == 0) {
+                const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
+                if (slot < sc.cap) {
+                    sc.long_start[slot] = (uint32_t)p;
+                    sc.long_end[slot] = (uint32_t)p + len;
+                }
+            }
             continue;
         }
-        const unsigned long long full = L == 64 ? ~0ull : ((1ull << L) - 1ull);
-        const unsigned long long gm = L == 64 ? bal : ((bal >> gbase) & full);
-        const int cnt = gm == full ? L : __ffsll((long long)~gm) - 1; /* leading entries of the window in this row */
+        if (!active) continue;
+        const RowPrefetch pre = emit.template pre<D>(row, lg);
         float4 g;
         float gb;
         bool has_b;
-        if ((cnt < L || p + L >= n) && cnt <= SBR_SEG_CHUNK) { /* the whole segment is in the window */
+        if (len <= (uint32_t)L) { /* the whole segment is in the window */
             g = make_float4(0.f, 0.f, 0.f, 0.f);
             gb = 0.0f;
             has_b = false;
             bool first = true;
-            for (int e = 0; e < cnt; e += 4) {
+            for (int e = 0; e < (int)cnt; e += 4) {
                 float4 v[4];
                 float scl[4];
                 bool bias[4];
@@ -1544,7 +1598,7 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
                     v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                     scl[i] = 0.0f;
                     bias[i] = false;
-                    if (e + i < cnt) {
+                    if (e + i < (int)cnt) {
                         const uint32_t src = (uint32_t)__shfl((int)lo, gbase + e + i, 64);
                         const uint32_t r = src / 3, kind = src % 3;
                         v[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
@@ -1554,7 +1608,7 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (e + i < cnt) {
+                    if (e + i < (int)cnt) {
                         if (first) {
                             g = make_float4(scl[i] * v[i].x, scl[i] * v[i].y, scl[i] * v[i].z, scl[i] * v[i].w);
                             first = false;
@@ -1570,23 +1624,20 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
                 }
             }
         } else {
-            const uint64_t hi_pos = p + SBR_SEG_CHUNK + 1 < n ? p + SBR_SEG_CHUNK + 1 : n;
-            const uint64_t end = seg_end(keys, p + cnt, hi_pos, row);
-            if (end - p > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
-                if (lg == 0) {
-                    const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
-                    if (slot < sc.cap) {
-                        sc.long_start[slot] = (uint32_t)p;
-                        sc.long_end[slot] = (uint32_t)seg_end(keys, end, n, row);
-                    }
-                }
-                continue;
-            }
-            seg_accumulate<D>(blk, keys, p, end, lg, &g, &gb, &has_b);
+            seg_accumulate<D>(blk, keys, p, p + len, lg, &g, &gb, &has_b);
         }
-        emit.template row<D>(row, p, lg, g, has_b, gb);
+        emit.template row<D>(row, p, lg, g, has_b, gb, pre);
     }
 }
+
+// positions of the sorted keys that start a row segment
+struct HeadPredicate {
+    const uint64_t* keys;
+    __device__ bool operator()(const uint32_t& p) const {
+        return p == 0 || (uint32_t)(keys[p] >> 32) != (uint32_t)(keys[p - 1] >> 32);
+    }
+};
+__global__ void head_sentinel_kernel(uint32_t* head_pos, const uint32_t* nheads, uint32_t total) { head_pos[*nheads] = total; }
 
 // prefix of the long segments' chunk counts (a few thousand entries at most: one workgroup)
 __global__ void seg_units_kernel(SegScratch sc) {
@@ -1670,7 +1721,8 @@ __global__ __launch_bounds__(256) void seg_finish_kernel(const uint64_t* keys, S
             }
         }
         const uint64_t p = sc.long_start[sidx];
-        emit.template row<D>((uint32_t)(keys[p] >> 32), p, lg, g, has_b, gb);
+        const uint32_t row = (uint32_t)(keys[p] >> 32);
+        emit.template row<D>(row, p, lg, g, has_b, gb, emit.template pre<D>(row, lg));
     }
 }
 
@@ -2242,7 +2294,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
     (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
     DISPATCH_D(d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
+        hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(grid_for_groups((long long)total / 2 + 1, gpb)), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
         hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
         hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
         hipLaunchKernelGGL((seg_finish_kernel<DD, Emit>), dim3(64), dim3(256), 0, s, keys_sorted, sc, emit);
@@ -2261,12 +2313,23 @@ void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int
 
 /* keys of the device's own entries, sorted: needs only the index arrays and the sampled negatives, so
  * the engine runs it on the side stream underneath the backward pass */
+size_t sparse_select_temp_bytes(size_t max_entries) {
+    size_t bytes = 0;
+    (void)rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), (uint32_t*)nullptr, (uint32_t*)nullptr, max_entries,
+                          HeadPredicate{nullptr}, 0, false);
+    return bytes;
+}
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                     size_t sort_temp_bytes, int key_bits, hipStream_t s) {
+                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s) {
     if (rows_host == 0) return;
     const uint64_t total = 3ull * rows_host;
     hipLaunchKernelGGL(build_own_keys_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, blk, rows_host, keys);
     (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
+    /* segment heads (ascending) + sentinel: what the per-row reduction iterates over */
+    size_t tb = sc.select_temp_bytes;
+    (void)rocprim::select(sc.select_temp, tb, rocprim::counting_iterator<uint32_t>(0), sc.head_pos, sc.nheads, (size_t)total,
+                          HeadPredicate{keys_sorted}, s, false);
+    hipLaunchKernelGGL(head_sentinel_kernel, dim3(1), dim3(1), 0, s, sc.head_pos, sc.nheads, (uint32_t)total);
 }
 
 void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
@@ -2293,6 +2356,7 @@ void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t sli
 void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,
                      const uint64_t* keys_sorted, float* G, float* gbl, uint32_t* fl, uint32_t* bounds, const SegScratch& sc,
                      hipStream_t s) {
+    (void)hipMemsetAsync(fl, 0, (size_t)(3ull * rows_host) * sizeof(uint32_t), s); /* 0 at every position that is not a head */
     launch_seg_reduce(m.d, blk, rows_host, keys_sorted, sc, EmitList{G, gbl, fl}, s);
     hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys_sorted, (uint32_t)(3ull * rows_host), ndev, slice_rows, bounds);
 }

@@ -181,6 +181,11 @@ def main():
     ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
     ap.add_argument("--standalone-steps", type=int, default=6,
                     help="extra untimed steps with stream overlap disabled, for standalone per-kernel times (0 = skip)")
+    ap.add_argument("--cold-items", type=int, default=4_000_000,
+                    help="catalogue size of the untimed cache-cold pass of the gather + score kernel (table = 8x the 256 MiB "
+                         "Infinity Cache at dim 128); 0 = skip")
+    ap.add_argument("--batch-sweep", type=str, default="1024,4096,16384",
+                    help="extra batch sizes measured untimed after the main run (reported with the main one as batch_sweep); '' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -190,6 +195,8 @@ def main():
                          "kernels read the peers' chunk buffers in place through peer mappings (xGMI), collectives only order the phases")
     ap.add_argument("--partition-table", action="store_true",
                     help="store the item table once across the ranks (BASELINE configs[4] layout) instead of replicating it")
+    ap.add_argument("--param-crc", action="store_true",
+                    help="add CRC-32 checksums of the trained parameters to the JSON line (tests compare runs bit for bit)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
@@ -237,7 +244,7 @@ def main():
         model = create_partitioned_model(hp)
         backend = loop = PartitionedStepper(model, (ptr, items))
         plan = backend.plan
-    elif args.transport == "peer" and world > 1:
+    elif args.transport == "peer" and (world > 1 or args.force_exchange):
         from sbr_rs_amd.partitioned import PeerExchangeStepper
 
         model = engine.Model(hp)
@@ -305,6 +312,7 @@ def main():
         rows_total = rows_timed
     timing = model.timing_read()
     ex1, neg1 = plan.counters()
+    sparse_entries, sparse_unique = plan.sparse_stats() if hasattr(plan, "sparse_stats") else (0, 0)
     # Second, UNTIMED pass (single GPU): the same steps with the side-stream work queued on the main stream,
     # so that every kernel family runs alone — the times behind the per-kernel roofline figures below.  The
     # timed region above keeps the overlapped schedule and is what `value` reports.
@@ -318,6 +326,56 @@ def main():
         standalone = model.timing_read()
         model.set_overlap(True)
     model.timing_enable(False)
+
+    def short_run(hp_x, ptr_x, items_x, steps, warm):
+        """A few untimed-region steps of another configuration on a fresh model: (interactions/s, SCORE ms per launch,
+        rows per launch, negatives per interaction)."""
+        mdl = engine.Model(hp_x)
+        be = HipBackend(mdl, (ptr_x, items_x), 1)
+        lp = StepLoop(be, 1, asynchronous=False)
+        nmb = lp.begin_epoch(prefetch_next=False)
+        for i in range(warm):
+            lp.step(i % nmb)
+        mdl.synchronize()
+        mdl.timing_enable(True)
+        mdl.timing_read()
+        e0, n0 = be.plan.counters()
+        rows = 0
+        t_a = time.perf_counter()
+        for i in range(steps):
+            mbi = (warm + i) % nmb
+            rows += be.plan.minibatch_rows(mbi)
+            lp.step(mbi)
+        mdl.synchronize()
+        dt = time.perf_counter() - t_a
+        tm = mdl.timing_read()
+        e1, n1 = be.plan.counters()
+        be.close()
+        sc_ms = tm["SCORE"][0] / max(tm["SCORE"][1], 1) if "SCORE" in tm else None
+        return rows / dt, sc_ms, rows / max(steps, 1), (n1 - n0) / max(e1 - e0, 1), 1e3 * dt / max(steps, 1)
+
+    cold, sweep = None, None
+    if world == 1 and not args.force_exchange and not args.partition_table and rank == 0:
+        if args.cold_items > 0 and model_kind != 2:
+            try:  # the same kernel against a table far larger than the Infinity Cache: no row is re-read from cache
+                cptr, citems = synthetic_csr(args.users, args.cold_items, args.max_len)
+                _, sc_ms, rpl, kc, _ = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.cold_items), cptr, citems, 3, 1)
+                cb = ((2 + kc) * 4 * args.dim + (1 + kc) * 4) * rpl
+                cold = {"items": args.cold_items, "table_bytes": args.cold_items * args.dim * 4, "avg_launch_ms": sc_ms,
+                        "mean_negatives_scored": kc, "algorithmic_bytes_per_launch": cb,
+                        "achieved": cb / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": cb / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del cptr, citems
+            except Exception as e:
+                cold = {"error": repr(e)}
+        if args.batch_sweep:
+            sweep = []
+            try:
+                for bsz in [int(x) for x in args.batch_sweep.split(",") if x]:
+                    v, _, rpl, _, ms = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.items, batch=bsz), ptr, items, 8, 3)
+                    sweep.append({"batch_sequences": bsz, "interactions_per_s": v, "ms_per_step": ms, "interactions_per_step": rpl})
+            except Exception as e:
+                sweep.append({"error": repr(e)})
 
     if rank == 0:
         d, ng = args.dim, {0: 4, 1: 3, 2: 0}[model_kind]
@@ -361,10 +419,23 @@ def main():
             kernels_sa = {"steps": args.standalone_steps, "interactions": rows_standalone,
                           "ms_per_step": {n: ms / args.standalone_steps for n, (ms, c) in standalone.items() if c}}
             if "SPARSE_UPDATE" in per_row:
+                # (a) BASELINE.md §4's per-interaction formula: 3 rows x (gradient source 4d, w and G read, w and G written)
+                #     + biases = 36d + 24 B — what a per-entry update would move;
+                # (b) the bytes this update really moves: it reduces the entries per table row first, so every DISTINCT row
+                #     is read-modified-written once (w, G in and out: 16d B, + 16 B of bias state for rows that have one)
+                #     and every entry reads its 4d-byte gradient source row (+ 4 B coefficient, 8 B sorted key)
+                sa_step_ms = kernels_sa["ms_per_step"]["SPARSE_UPDATE"]
                 gbs = (36 * d + 24) / (per_row["SPARSE_UPDATE"] * 1e-3) / 1e9
-                kernels_sa["sparse_update_hbm"] = {"kernel": "seg_short_kernel (+ hot-row path): per-row reduction + Adagrad read-modify-write",
-                                                   "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                                   "algorithmic_bytes_per_interaction": 36 * d + 24}
+                real_bytes = sparse_unique * (16 * d + 16) + sparse_entries * (4 * d + 12)
+                real_gbs = real_bytes / (sa_step_ms * 1e-3) / 1e9 if sparse_entries else None
+                kernels_sa["sparse_update_hbm"] = {
+                    "kernel": "seg_short_kernel (+ hot-row path): per-row reduction of the sorted entries + one Adagrad read-modify-write per distinct row",
+                    "bound": "hbm", "achieved": real_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": real_gbs / HBM_PEAK_GBS if real_gbs else None,
+                    "bytes_per_launch": real_bytes, "entries_per_launch": sparse_entries, "distinct_rows_per_launch": sparse_unique,
+                    "pricing": "distinct rows x (16d + 16) + entries x (4d + 12) bytes (de-duplicated, what the kernel moves)",
+                    "per_entry_formula": {"bytes_per_interaction": 36 * d + 24, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                          "note": "BASELINE.md section 4 formula (no de-duplication): an upper bound on the traffic, not what moves"}}
             if ng:
                 gemm_sa = 2 * 2 * d * ng * d
                 kernels_sa["mfma"] = {fam: {"achieved": gemm_sa / (per_row[fam] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -397,8 +468,19 @@ def main():
                                        f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
-            "roofline": roofline, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
+            "roofline": roofline, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
         }
+        if sweep is not None:
+            sweep.append({"batch_sequences": args.batch_sequences, "interactions_per_s": rows_total / elapsed,
+                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "interactions_per_step": rows_per_launch, "note": "the timed run"})
+            out["batch_sweep"] = sorted((x for x in sweep if "batch_sequences" in x), key=lambda x: x["batch_sequences"]) + [x for x in sweep if "error" in x]
+        if args.param_crc:
+            import zlib
+
+            from sbr_rs_amd._abi import Param
+
+            names = ["ITEM_EMBEDDING", "ITEM_EMBEDDING_ACC", "ITEM_BIAS", "ITEM_BIAS_ACC"] + (["LSTM_W", "LSTM_W_ACC", "LSTM_B"] if ng else ["EWMA_ALPHA"])
+            out["param_crc"] = {n: zlib.crc32(model.get_param(getattr(Param, n)).tobytes()) for n in names}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -139,6 +139,10 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
 /* Running totals of the plan, all devices: loss terms processed and negatives scored by the WARP
  * search (the k of BASELINE.md §4's bytes-per-interaction formula). */
 sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored);
+/* The last step's sparse update on this device: gradient entries (3 per loss term: input, target and
+ * negative row) and the distinct item-table rows they touch (each is read-modified-written once,
+ * sequence_model.rs:163-169) — what the real HBM traffic of the update is priced from. */
+sbr_status sbr_fit_sparse_stats(sbr_fit_plan* p, uint64_t* out_entries, uint64_t* out_unique_rows);
 void sbr_fit_plan_destroy(sbr_fit_plan* p);
 
 /* The two halves of a single-device step (sbr_fit_step = local + apply). */
@@ -163,6 +167,11 @@ sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
 sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send);
 sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out);
 sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk);
+/* The same kernel launched on `hip_stream` instead of the model's stream, without synchronising either: the
+ * caller orders the two streams itself (events / wait_stream).  What the staleness-one pipeline
+ * (Parallelism::Asynchronous) uses to keep the exchange of step k on a side stream underneath the computation
+ * of step k+1. */
+sbr_status sbr_fit_step_owner_reduce_on(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk, void* hip_stream);
 sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all);
 
 /* The same multi-device fit driven from ONE process (≙ fit with num_threads(n) on one host,
@@ -249,6 +258,11 @@ sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch);
 /* Optimiser steps taken so far (Adam's bias-correction counter) and the epoch counter that keys the
  * negative draws: together with the parameter blocks this is the complete resumable state. */
 sbr_status sbr_model_get_counters(const sbr_model* m, uint64_t* out_global_epoch, uint64_t* out_optimizer_steps);
+/* State of the model RNG (the Hyperparameters' rng, which the reference serialises with the model,
+ * lstm.rs:38-51): 16 bytes that re-create it through XorShiftRng::from_seed.  A restored model continues
+ * the shuffle / partition-seed stream of the saved one. */
+sbr_status sbr_model_get_rng(const sbr_model* m, uint8_t out_state[16]);
+sbr_status sbr_model_set_rng(sbr_model* m, const uint8_t state[16]);
 sbr_status sbr_model_set_counters(sbr_model* m, uint64_t global_epoch, uint64_t optimizer_steps);
 
 /* Library / device identification ("gfx950", CU count, HBM bytes); device_name may be NULL. */

@@ -71,6 +71,8 @@ typedef struct orc_plan {
     orc_local* loc; /* [ndev] */
     double loss_sum;
     uint64_t examples;
+    double loss_dev[16];    /* per partition (sequence_model.rs:173-177 sums the partitions' ratios) */
+    uint64_t examples_dev[16];
     uint64_t epochs_prepared;
     uint64_t epoch_key_epoch;
 } orc_plan;
@@ -91,7 +93,7 @@ static int orc_dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d ==
 int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     if (!orc_dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
-        hp->num_devices == 0 || hp->batch_sequences == 0)
+        hp->num_devices == 0 || hp->num_devices > 16 || hp->batch_sequences == 0)
         return SBR_ERR_INVALID_ARGUMENT;
     if (hp->optimizer != SBR_OPT_ADAGRAD && hp->optimizer != SBR_OPT_ADAM) return SBR_ERR_INVALID_ARGUMENT;
     orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
@@ -723,6 +725,7 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
         double ls; uint64_t ex;
         memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
         p->loss_sum += ls; p->examples += ex;
+        p->loss_dev[q] += ls; p->examples_dev[q] += ex;
     }
     orc_dense_update(m, dg);
     free(dg);
@@ -866,6 +869,7 @@ int orc_fit_apply_table(orc_plan* p, const void* all_chunks, const void* dense_a
         double ls; uint64_t ex;
         memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
         p->loss_sum += ls; p->examples += ex;
+        p->loss_dev[q] += ls; p->examples_dev[q] += ex;
     }
     orc_dense_update(m, dg);
     free(dg);
@@ -943,9 +947,12 @@ int orc_fit_epoch_async(orc_plan* p, uint64_t nmb) {
 }
 
 int orc_fit_end(orc_plan* p, float* out_loss, uint64_t* out_examples) {
-    /* ≙ loss_value / (1.0 + examples) (sequence_model.rs:173).  The reference reads a stale node
-     * value (:157 before :160); the engine reports the true summed loss. */
-    if (out_loss) *out_loss = (float)(p->loss_sum / (1.0 + (double)p->examples));
+    /* ≙ the sum over the workers of loss_value / (1.0 + examples) (sequence_model.rs:173-177).  The
+     * reference reads a stale node value (:157 before :160); reported here: the true
+     * loss sums. */
+    double total = 0.0;
+    for (int q = 0; q < p->ndev; ++q) total += p->loss_dev[q] / (1.0 + (double)p->examples_dev[q]);
+    if (out_loss) *out_loss = (float)total;
     if (out_examples) *out_examples = p->examples;
     return SBR_OK;
 }

@@ -546,7 +546,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 3; }
+uint32_t sbr_abi_version(void) { return 4; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -817,6 +817,20 @@ sbr_status sbr_model_set_counters(sbr_model* m, uint64_t global_epoch, uint64_t 
     return SBR_OK;
 }
 
+sbr_status sbr_model_get_rng(const sbr_model* m, uint8_t out_state[16]) {
+    if (!m || !out_state) return SBR_ERR_INVALID_ARGUMENT;
+    const uint32_t w[4] = {m->rng.x, m->rng.y, m->rng.z, m->rng.w};
+    for (int i = 0; i < 4; ++i)
+        for (int b = 0; b < 4; ++b) out_state[4 * i + b] = (uint8_t)(w[i] >> (8 * b));
+    return SBR_OK;
+}
+
+sbr_status sbr_model_set_rng(sbr_model* m, const uint8_t state[16]) {
+    if (!m || !state) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_xs_seed(&m->rng, state);
+    return SBR_OK;
+}
+
 sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(m));
@@ -864,7 +878,10 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     *out = nullptr;
     SBRCHK(ensure_device(m));
     const uint64_t T = m->hp.max_sequence_length;
+    for (uint64_t u = 0; u < num_users; ++u)
+        if (user_ptr[u + 1] < user_ptr[u]) return SBR_ERR_INVALID_ARGUMENT; /* pointers must be non-decreasing */
     const uint64_t nnz = user_ptr[num_users];
+    if (nnz && !item_ids) return SBR_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < nnz; ++i)
         if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
     /* subsequences = chunks (first chunk short, data.rs:406-431) with len > 2 (sequence_model.rs:76-83) */
@@ -950,11 +967,11 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
-    if (st == SBR_OK) st = dmalloc(&p->loss_acc, 1);
-    if (st == SBR_OK) st = dmalloc(&p->ex_acc, 2); /* [0] examples, [1] negatives scored */
+    if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
+    if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
-    hipMemsetAsync(p->loss_acc, 0, sizeof(double), m->stream);
-    hipMemsetAsync(p->ex_acc, 0, 2 * sizeof(unsigned long long), m->stream);
+    hipMemsetAsync(p->loss_acc, 0, 17 * sizeof(double), m->stream);
+    hipMemsetAsync(p->ex_acc, 0, 18 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
     *out = p;
     return SBR_OK;
@@ -1317,6 +1334,19 @@ sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, v
     return SBR_OK;
 }
 
+sbr_status sbr_fit_step_owner_reduce_on(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk, void* hip_stream) {
+    if (!p || !device_recv || !device_own_chunk) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1, st);
+        sbr::launch_owner_reduce(m->mv, contiguous_chunks(p, device_recv), p->ndev, slice_rows(p), device_own_chunk, st);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
 /* the part of an exchanged step that every device applies identically: step counter, loss header,
  * dense parameters (device-order sum of the gathered dense blocks) */
 static sbr_status apply_dense_blocks(sbr_fit_plan* p, const void* device_dense_all) {
@@ -1421,13 +1451,16 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
-    double loss = 0.0;
-    unsigned long long ex = 0;
-    HIPCHK(hipMemcpy(&loss, p->loss_acc, sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&ex, p->ex_acc, sizeof(ex), hipMemcpyDeviceToHost));
-    /* ≙ loss_value / (1.0 + examples) (sequence_model.rs:173); true loss, not the stale node value */
-    if (out_loss) *out_loss = (float)(loss / (1.0 + (double)ex));
-    if (out_examples) *out_examples = (uint64_t)ex;
+    double loss[17];
+    unsigned long long ex[18];
+    HIPCHK(hipMemcpy(loss, p->loss_acc, sizeof(loss), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ex, p->ex_acc, sizeof(ex), hipMemcpyDeviceToHost));
+    /* ≙ the sum over the partitions' workers of loss_value / (1.0 + examples) (sequence_model.rs:173-177); the
+     * true loss sums, not the stale node values the reference reads */
+    double total = 0.0;
+    for (int q = 0; q < p->ndev; ++q) total += loss[1 + q] / (1.0 + (double)ex[2 + q]);
+    if (out_loss) *out_loss = (float)total;
+    if (out_examples) *out_examples = (uint64_t)ex[0];
     return SBR_OK;
 }
 
@@ -1439,6 +1472,18 @@ sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* o
     HIPCHK(hipMemcpy(v, p->ex_acc, sizeof(v), hipMemcpyDeviceToHost));
     if (out_examples) *out_examples = v[0];
     if (out_negatives_scored) *out_negatives_scored = v[1];
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_sparse_stats(sbr_fit_plan* p, uint64_t* out_entries, uint64_t* out_unique_rows) {
+    if (!p) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    HIPCHK(hipStreamSynchronize(p->m->side));
+    HIPCHK(hipStreamSynchronize(p->m->stream));
+    uint32_t nheads = 0;
+    HIPCHK(hipMemcpy(&nheads, p->seg.nheads, sizeof(nheads), hipMemcpyDeviceToHost));
+    if (out_entries) *out_entries = 3ull * (uint64_t)p->last_R;
+    if (out_unique_rows) *out_unique_rows = nheads;
     return SBR_OK;
 }
 
@@ -1468,7 +1513,9 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
  * The host supplies the ordering: [scatter] barrier [owner reduce] barrier + all-gather of the small dense
  * blocks [apply]; the next step's scatter is safe because every rank passed the following barrier. */
 sbr_status sbr_fit_exchange_export(sbr_fit_plan* p, int32_t out_fds[2], uint64_t out_bytes[2]) {
-    if (!p || !out_fds || !out_bytes || p->ndev < 2 || p->m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    if (!p || !out_fds || !out_bytes || p->ndev < 1 || p->m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    /* the peer transport runs the synchronous step only (Asynchronous = the collective transport's pipeline) */
+    if (p->ndev > 1 && p->m->hp.parallelism == SBR_PAR_ASYNCHRONOUS) return SBR_ERR_UNSUPPORTED;
     SBRCHK(ensure_device(p->m));
     const uint64_t chunk = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
     if (!p->xchg_own[0].ptr) {
@@ -1878,6 +1925,8 @@ sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out) 
     if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->num_devices == 0 || hp->num_devices > 16 ||
         hp->device_rank >= hp->num_devices)
         return SBR_ERR_INVALID_ARGUMENT;
+    /* a partitioned table is updated in place by its owners after a rendezvous: no staleness-one pipeline */
+    if (hp->num_devices > 1 && hp->parallelism == SBR_PAR_ASYNCHRONOUS) return SBR_ERR_UNSUPPORTED;
     int ndevices = 0, device = 0;
     if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
     HIPCHK(hipGetDevice(&device));
@@ -2081,7 +2130,10 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     std::lock_guard<std::mutex> lock(m->mu);
     SBRCHK(ensure_device(m));
     const uint64_t T = m->hp.max_sequence_length;
+    for (uint64_t u = 0; u < num_users; ++u)
+        if (user_ptr[u + 1] < user_ptr[u]) return SBR_ERR_INVALID_ARGUMENT; /* pointers must be non-decreasing */
     const uint64_t nnz = user_ptr[num_users];
+    if (nnz && !item_ids) return SBR_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < nnz; ++i)
         if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
     std::vector<uint64_t> users; /* users with >= 2 interactions (evaluation.rs:20) */

@@ -1544,7 +1544,8 @@ __device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, u
 // one coalesced load, and then has every address it needs — the row's parameter / optimiser-state quads and
 // the gradient source rows are requested together, so a segment costs two dependent memory round trips (keys,
 // rows) instead of three, and no lane group spends a round trip finding out that its position is not a head.
-// The next segment's (p, length) is requested before the current one is processed.
+// Positions are requested two segments ahead and key windows one segment ahead, so that in steady state only
+// the row round trip is exposed.
 template <int D, class Emit>
 __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
     constexpr int L = D / 4;
@@ -1556,19 +1557,30 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
     const uint32_t nheads = *sc.nheads;
     const uint32_t stride = nwaves * GPW;
     uint32_t h = wave * GPW + grp;
-    uint32_t p_cur = sc.head_pos[h < nheads ? h : nheads], p_end = sc.head_pos[h < nheads ? h + 1 : nheads];
+    auto head_at = [&](uint32_t hh) { return sc.head_pos[hh < nheads ? hh : nheads]; };
+    auto window_key = [&](uint32_t p0, uint32_t p1) {  // this lane's key of the segment [p0, p1) (clamped to valid memory)
+        const uint32_t c = p1 - p0 < (uint32_t)L ? p1 - p0 : (uint32_t)L;
+        return keys[(uint32_t)lg < c ? (uint64_t)p0 + lg : ((uint64_t)p0 < n ? (uint64_t)p0 : 0)];
+    };
+    // two segments ahead: (first key position, end); one segment ahead: its key window
+    uint32_t p_cur = head_at(h), p_end = head_at(h + 1);
+    uint32_t p_next = head_at(h + stride), p_next_end = head_at(h + stride + 1);
+    uint64_t kmine = window_key(p_cur, p_end);
     for (uint32_t h0 = wave * GPW; h0 < nheads; h0 += stride, h += stride) {  // wave-uniform trip count
         const bool active = h < nheads;
-        const uint32_t hn = h + stride;
-        const uint32_t p_next = sc.head_pos[hn < nheads ? hn : nheads], p_next_end = sc.head_pos[hn < nheads ? hn + 1 : nheads];
+        const uint32_t p_nn = head_at(h + 2 * stride), p_nn_end = head_at(h + 2 * stride + 1);
         const uint64_t p = p_cur;
         const uint32_t len = active ? p_end - p_cur : 0u;
         const uint32_t cnt = len < (uint32_t)L ? len : (uint32_t)L;  // entries of the segment inside the key window
-        const uint64_t kmine = keys[(uint32_t)lg < cnt ? p + lg : (p < n ? p : 0)];
         const uint32_t lo = (uint32_t)kmine;
         const uint32_t row = (uint32_t)__shfl((int)(uint32_t)(kmine >> 32), gbase, 64);
+        // the next segment's key window (its position arrived an iteration ago) is requested here and consumed
+        // in the next iteration
+        kmine = window_key(p_next, p_next_end);
         p_cur = p_next;
         p_end = p_next_end;
+        p_next = p_nn;
+        p_next_end = p_nn_end;
         if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
             if (lg == 0) {
                 const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
@@ -1867,15 +1879,20 @@ __global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, Peer
 __global__ void accumulate_loss_kernel(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                                        unsigned long long* ex_acc) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double l = *loss_acc;
+    /* loss_acc: [0] all devices, [1 + q] device q;  ex_acc: [0] examples, [1] negatives scored, [2 + q] examples of device q */
+    double l = loss_acc[0];
     unsigned long long e = ex_acc[0], tr = ex_acc[1];
     for (int q = 0; q < ndev; ++q) {
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(all_blocks + (size_t)q * block_bytes);
-        l += *reinterpret_cast<const double*>(hdr + 4);
-        e += *reinterpret_cast<const unsigned long long*>(hdr + 6);
+        const double lq = *reinterpret_cast<const double*>(hdr + 4);
+        const unsigned long long eq = *reinterpret_cast<const unsigned long long*>(hdr + 6);
+        l += lq;
+        e += eq;
         tr += hdr[1];
+        loss_acc[1 + q] += lq;
+        ex_acc[2 + q] += eq;
     }
-    *loss_acc = l;
+    loss_acc[0] = l;
     ex_acc[0] = e;
     ex_acc[1] = tr;
 }

@@ -211,13 +211,9 @@ class HipBackend:
         return self._dense
 
     def owner_reduce(self, recv, stream=None):
-        if stream is not None:  # launch on the exchange stream (Asynchronous)
-            self.model.set_stream(stream.cuda_stream)
-        try:
-            self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr())
-        finally:
-            if stream is not None:
-                self.model.set_stream(self._compute.cuda_stream)
+        # stream != None: launched on the exchange stream (Asynchronous) with no host-side synchronisation of either
+        # stream, so that compute_local(k+1) is enqueued while the exchange of step k is still in flight
+        self.plan.step_owner_reduce(recv.data_ptr(), self.own.data_ptr(), None if stream is None else stream.cuda_stream)
         return self.own
 
     def exchange_streams(self):
@@ -260,6 +256,10 @@ def fit_distributed(model, interactions, group=None, transport: str = None) -> f
     transport = transport or os.environ.get("SBR_EXCHANGE_TRANSPORT", "collective")
     if transport == "peer":  # chunks read in place through peer mappings; collectives only order the phases
         from .partitioned import PeerExchangeStepper
+
+        if int(model.hp.parallelism) == 0:  # Parallelism::Asynchronous: only the collective transport has the pipelined order
+            raise ValueError("Parallelism.Asynchronous is implemented for the collective transport only; the peer transport "
+                             "runs the synchronous step (set parallelism(Synchronous) or SBR_EXCHANGE_TRANSPORT=collective)")
 
         stepper = PeerExchangeStepper(model, interactions, group)
         try:

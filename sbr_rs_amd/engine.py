@@ -128,8 +128,13 @@ class FitPlan:
     def step_dense(self, dense_ptr: int):
         _check(self._L.sbr_fit_step_dense(self._h, C.c_void_p(dense_ptr)))
 
-    def step_owner_reduce(self, recv_ptr: int, own_ptr: int):
-        _check(self._L.sbr_fit_step_owner_reduce(self._h, C.c_void_p(recv_ptr), C.c_void_p(own_ptr)))
+    def step_owner_reduce(self, recv_ptr: int, own_ptr: int, stream_ptr: int = None):
+        """``stream_ptr``: launch on that HIP stream without synchronising it or the model's stream (the caller
+        orders them) — the exchange stream of the staleness-one pipeline."""
+        if stream_ptr is None:
+            _check(self._L.sbr_fit_step_owner_reduce(self._h, C.c_void_p(recv_ptr), C.c_void_p(own_ptr)))
+        else:
+            _check(self._L.sbr_fit_step_owner_reduce_on(self._h, C.c_void_p(recv_ptr), C.c_void_p(own_ptr), C.c_void_p(stream_ptr)))
 
     def step_apply_table(self, table_ptr: int, dense_all_ptr: int):
         _check(self._L.sbr_fit_step_apply_table(self._h, C.c_void_p(table_ptr), C.c_void_p(dense_all_ptr)))
@@ -143,6 +148,12 @@ class FitPlan:
         ex, neg = C.c_uint64(), C.c_uint64()
         _check(self._L.sbr_fit_counters(self._h, C.byref(ex), C.byref(neg)))
         return ex.value, neg.value
+
+    def sparse_stats(self):
+        """(gradient entries, distinct table rows) of the last step's sparse update on this device."""
+        ent, uniq = C.c_uint64(), C.c_uint64()
+        _check(self._L.sbr_fit_sparse_stats(self._h, C.byref(ent), C.byref(uniq)))
+        return ent.value, uniq.value
 
     def debug_fetch(self, which: int, rows: int) -> np.ndarray:
         d = self.model.dim
@@ -225,6 +236,18 @@ class Model:
 
     def set_counters(self, global_epoch: int, optimizer_steps: int):
         _check(self._L.sbr_model_set_counters(self._h, global_epoch, optimizer_steps))
+
+    def get_rng(self) -> bytes:
+        """The model RNG's state as the 16 bytes that re-create it through ``XorShiftRng.from_seed``."""
+        buf = (C.c_uint8 * 16)()
+        _check(self._L.sbr_model_get_rng(self._h, buf))
+        return bytes(buf)
+
+    def set_rng(self, state: bytes):
+        state = bytes(state)
+        if len(state) != 16:
+            raise ValueError("RNG state is 16 bytes")
+        _check(self._L.sbr_model_set_rng(self._h, (C.c_uint8 * 16)(*state)))
 
     def set_stream(self, hip_stream_ptr: int):
         _check(self._L.sbr_model_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

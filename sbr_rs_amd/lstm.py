@@ -167,9 +167,13 @@ class _ImplicitSequenceModel:
         world = int(self.params.hp.num_devices)
         if world == 1:
             return self.params.fit(interactions.user_pointers, interactions.item_ids)
-        import torch.distributed as dist
+        try:  # torch is needed only for the one-process-per-GPU driver
+            import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and getattr(self, "_peers", None) is None:
+            launched = dist.is_available() and dist.is_initialized()
+        except ImportError:
+            launched = False
+        if launched and getattr(self, "_peers", None) is None:
             # one process per GPU (torchrun): this process drives replica hp.device_rank
             if self.params.is_partitioned():
                 from .partitioned import fit_partitioned

@@ -189,6 +189,9 @@ class PartitionedStepper:
 
 def fit_partitioned(model: Model, interactions, group=None) -> float:
     """``fit`` over a partitioned table, one process per GPU (≙ fit with num_threads = world size)."""
+    if int(model.hp.parallelism) == 0:
+        raise ValueError("Parallelism.Asynchronous is not implemented for a partitioned item table (its owners update in "
+                         "place after a rendezvous); use Parallelism.Synchronous")
     stepper = PartitionedStepper(model, interactions, group)
     try:
         epochs = int(model.hp.num_epochs)

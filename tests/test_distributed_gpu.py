@@ -122,3 +122,33 @@ def test_peer_transport_two_processes(tmp_path, oracle_lib, kind, loss):
         for p in PARAMS[kind]:
             assert np.array_equal(z[p.name].view(np.uint32), ref.get_param(p).view(np.uint32)), f"rank {r}: {p.name}"
         assert float(z["loss"]) == pytest.approx(ref_loss, rel=1e-6)
+
+
+# ---- RCCL itself (backend "nccl"), world size 1 ------------------------------------------------------------
+def _bench(extra):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-mrr",
+           "--standalone-steps", "0", "--cold-items", "0", "--batch-sweep", "", "--param-crc", "--users", "3000", "--items", "20000",
+           "--max-len", "32", "--dim", "64", "--batch-sequences", "1000"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["collective", "peer"])
+def test_rccl_exchange_world_one_equals_single_device(transport):
+    """The multi-GPU step through RCCL (backend nccl): `bench.py --force-exchange` runs the production step
+    sequence — scatter into owner chunks, all_to_all_single / all_gather_into_tensor (collective transport) or
+    the peers' buffers read in place with RCCL barriers and the dense all-gather (peer transport), owner reduce,
+    table apply — on a process group of one rank.  The trained parameters must equal the plain single-device
+    run's bit for bit (CRC-32 of every parameter array)."""
+    plain = _bench([])
+    exch = _bench(["--force-exchange", "--backend", "nccl", "--transport", transport])
+    assert exch["param_crc"] == plain["param_crc"]
+    assert exch["interactions_timed"] == plain["interactions_timed"]

@@ -440,16 +440,39 @@ def test_save_load_resumes_training_bit_exactly(tmp_path):
             assert_same_bits(a.get_param(p), b.get_param(p), f"reload {p.name}")
         u = np.array([3, 1, 4, 1, 5], dtype=np.uint32)
         assert_same_bits(a.user_representation(u), b.user_representation(u), "reload user_representation")
-        # a model restored from disk restarts its shuffle RNG from the saved seed: compare against a
-        # fresh model brought to the same state through set_param/set_counters
-        c = Model(hp)
+        # the model RNG travels with the model (as the reference's serialised Hyperparameters.rng does): the
+        # restored model's next fit is the one the original runs — same shuffles, same partition seeds
+        assert b.get_rng() == a.get_rng() != bytes(hp.seed)
+        assert sbr.persistence.load_engine(str(tmp_path / f"m{opt}")).counters() == a.counters()  # suffix optional
+        a.fit(ptr, it), b.fit(ptr, it)
         for p in Param:
-            if a.param_count(p):
-                c.set_param(p, a.get_param(p))
-        c.set_counters(*a.counters())
-        b.fit(ptr, it), c.fit(ptr, it)
-        for p in Param:
-            assert_same_bits(b.get_param(p), c.get_param(p), f"resumed {p.name}")
+            assert_same_bits(a.get_param(p), b.get_param(p), f"resumed {p.name}")
+        assert b.get_rng() == a.get_rng()
+
+
+def test_save_load_multi_replica_model_continues(tmp_path):
+    """A model built with num_threads(2) (two replicas in one process, sbr_group_fit) is saved, restored as two
+    replicas and continues training exactly like the original."""
+    import sbr_rs_amd as sbr
+
+    ptr, it = synthetic_interactions(60, 120, 14, seed=16, zipf=True)
+    comp = sbr.data.CompressedInteractions(60, 120, ptr, it, np.zeros(len(it), dtype=np.uint64))
+
+    def build():
+        return (sbr.ewma.Hyperparameters.new(120, 12).from_seed(bytes([7] * 16)).embedding_dim(32).learning_rate(0.16)
+                .l2_penalty(0.0004).loss(sbr.Loss.Hinge).optimizer(sbr.Optimizer.Adagrad).num_epochs(2).num_threads(2)
+                .batch_sequences(6).build())
+
+    a = build()
+    a.fit(comp)
+    sbr.persistence.save_model(a, str(tmp_path / "two"))
+    b = sbr.persistence.load_model(str(tmp_path / "two"))
+    assert len(b._replicas()) == 2 and b.params.get_rng() == a.params.get_rng()
+    la, lb = a.fit(comp), b.fit(comp)
+    assert la == lb
+    for ra, rb in zip(a._replicas(), b._replicas()):
+        for p in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.EWMA_ALPHA):
+            assert_same_bits(ra.get_param(p), rb.get_param(p), f"resumed replica {p.name}")
 
 
 def test_batch_of_one_is_per_sequence_sgd():

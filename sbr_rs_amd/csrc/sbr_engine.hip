@@ -402,7 +402,7 @@ struct DevicePacked { /* device image of one or more Packed, concatenated */
 struct WorkBuffers {
     sbr::WorkView v{};
     void release() {
-        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.X); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
+        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.X); hipFree(v.zeros); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
         hipFree(v.partials); hipFree(v.loss); hipFree(v.tries); hipFree(v.part_loss); hipFree(v.part_tries);
         v = sbr::WorkView{};
     }
@@ -424,7 +424,11 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         SBRCHK(dmalloc(&v.part_loss, 2048));
         SBRCHK(dmalloc(&v.part_tries, 2048));
         if (m->ng) {
-            SBRCHK(dmalloc(&v.dZ, (rmax + 64) * d * (uint64_t)m->ng)); /* + 64 dump rows (BPTT kernel) */
+            const uint64_t rchunk = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS * SBR_DW_CHUNK_ROWS;
+            v.dz_dump_row0 = (int)rchunk; /* the dense-gradient GEMM reads dZ to the end of the last chunk: dump rows lie behind it */
+            SBRCHK(dmalloc(&v.dZ, (rchunk + 64) * d * (uint64_t)m->ng));
+            SBRCHK(dmalloc(&v.zeros, 256));
+            HIPCHK(hipMemset(v.zeros, 0, 256 * sizeof(float)));
             SBRCHK(dmalloc(&v.dHrec, bmax * d));
             SBRCHK(dmalloc(&v.dCrec, bmax * d));
             const uint64_t nch = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;

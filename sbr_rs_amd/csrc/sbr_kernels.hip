@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
                                       &dz[0][j], &dz[1][j], &dz[2][j], &dz[3][j], &dco);
                     dc[k][j] = dco;
                 }
-                float* dzrow = live ? dZ + (size_t)(row_begin + b0 + i) * NGD : dZ + (size_t)(w.dump_row0 + i) * NGD;
+                float* dzrow = live ? dZ + (size_t)(row_begin + b0 + i) * NGD : dZ + (size_t)(w.dz_dump_row0 + i) * NGD;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int src = NG == 4 ? g : g + 1;
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         // epilogue: dX to HBM (branch-free), recurrent dh into columns [0, D) of the tile
         {
             float* dX = launder(blk.dX);
-            float* dump = launder(w.dZ) + (size_t)w.dump_row0 * NGD;
+            float* dump = launder(w.dZ) + (size_t)w.dz_dump_row0 * NGD;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -1301,6 +1301,115 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
             for (int q = 0; q < 16; ++q) {
                 const int k = tk * 128 + wk * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
                 if (k < K2 && j < NGD) part[(size_t)k * NGD + j] = acc[a][b][q];
+            }
+        }
+}
+
+// Same product for shapes whose 128x128 tiles are full (K2 and NG*D multiples of 128: d = 128, d = 256, d = 64
+// with four gates), written on the recurrent kernels' recipe: branch-free slab fetches (rows past the end of the
+// last chunk are clamped to a valid row for X / H and find ZEROS in dZ — the engine clears dZ's rows between R
+// and the end of R's chunk — so they add +0 to every chain; first-step rows take their h_{t-1} from a row of
+// zeros), so that every wait count is static, and the LDS operand reads of iteration s+1 are issued before the
+// MFMAs of iteration s.
+template <int D, int NG>
+__global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+    constexpr int K2 = 2 * D;
+    constexpr int NGD = NG * D;
+    constexpr int TJ = NGD / 128;
+    constexpr int SLAB = 32;
+    constexpr int NTILE = (K2 / 128) * TJ;
+    static_assert(K2 % 128 == 0 && NGD % 128 == 0, "full tiles only");
+    __shared__ float Xs[SLAB * 128];
+    __shared__ float Zs[SLAB * 128];
+    __shared__ int s_prev[SBR_DW_CHUNK_ROWS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave >> 1, wj = wave & 1;
+    const int wid = blockIdx.x;
+    const int tile = (wid >> 3) % NTILE;
+    const int c = (wid >> 3) / NTILE * 8 + (wid & 7);  // XCD-aware: all tiles of a chunk on one XCD (see lstm_dw_kernel)
+    if (c * SBR_DW_CHUNK_ROWS >= mb.R) return;
+    const int tk = tile / TJ, tj = tile % TJ;
+    const int r0 = c * SBR_DW_CHUNK_ROWS;
+    const int last = mb.R - 1;
+    for (int i = tid; i < SBR_DW_CHUNK_ROWS; i += 256) s_prev[i] = mb.prev_row[r0 + i <= last ? r0 + i : last];
+    __syncthreads();
+    const int l31 = lane & 31;
+    const int hh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+    const int c4 = (tid & 31) * 4;
+    const int srow = tid >> 5;
+    const int kcol = tk * 128 + c4;
+    const int jcol = tj * 128 + c4;
+    const bool xpart = kcol < D;  // this thread's k columns are input (x) columns; otherwise previous-hidden columns
+    float4 xr[4], zr[4];
+    auto fetch = [&](int slab) {
+        const float* X = launder(w.X);
+        const float* H = launder(blk.H);
+        const float* dZ = launder(w.dZ);
+        const float* zero = launder(w.zeros);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lr = slab * SLAB + srow + 8 * i;
+            const int row = r0 + lr <= last ? r0 + lr : last;
+            const int pr = s_prev[lr];
+            const float* src = xpart ? X + ((size_t)row * D + kcol) : (pr >= 0 ? H + ((size_t)pr * D + (kcol - D)) : zero + (kcol - D));
+            xr[i] = ld4(src);
+            zr[i] = ld4(dZ + ((size_t)(r0 + lr) * NGD + jcol));  // rows past R: cleared by the engine
+        }
+    };
+    int nr = mb.R - r0;
+    nr = nr < SBR_DW_CHUNK_ROWS ? nr : SBR_DW_CHUNK_ROWS;
+    const int nslabs = (nr + SLAB - 1) / SLAB;
+    float bias_acc = 0.0f;
+    const bool do_bias = tk == 0 && tid < 128;
+    fetch(0);
+    for (int slab = 0; slab < nslabs; ++slab) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            st4(&Xs[(srow + 8 * i) * 128 + c4], xr[i]);
+            st4(&Zs[(srow + 8 * i) * 128 + c4], zr[i]);
+        }
+        __syncthreads();
+        fetch(slab + 1 < nslabs ? slab + 1 : slab);  // unconditional (static operation count); the last one is unused
+        const float* xa = &Xs[hh * 128 + wk * 64 + l31];
+        const float* zb = &Zs[hh * 128 + wj * 64 + l31];
+        float a0 = xa[0], a1 = xa[32], b0 = zb[0], b1 = zb[32];
+#pragma unroll
+        for (int s = 0; s < SLAB / 2; ++s) {
+            const int sn = s + 1 < SLAB / 2 ? s + 1 : s;
+            const float na0 = xa[sn * 256], na1 = xa[sn * 256 + 32];
+            const float nb0 = zb[sn * 256], nb1 = zb[sn * 256 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (do_bias) {  // bias-gradient row: plain add chain over the rows of the chunk (rows past R add +0)
+            const int rows_here = nr - slab * SLAB < SLAB ? nr - slab * SLAB : SLAB;
+            for (int r = 0; r < rows_here; ++r) bias_acc = bias_acc + Zs[r * 128 + tid];
+        }
+        __syncthreads();
+    }
+    if (do_bias) w.partials[((size_t)c * (K2 + 1) + K2) * NGD + tj * 128 + tid] = bias_acc;
+    float* part = w.partials + (size_t)c * (K2 + 1) * NGD;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = tj * 128 + wj * 64 + b * 32 + l31;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = tk * 128 + wk * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+                part[(size_t)k * NGD + j] = acc[a][b][q];
             }
         }
 }
@@ -2275,10 +2384,25 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
     DISPATCH_D(m.d, {
         const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
-        if (m.ng == 4)
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
-        else
-            hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+        constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
+        /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here (they lie below the
+         * dump rows, which start at the chunk-aligned capacity) */
+        const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
+        if (m.ng == 4) {
+            if constexpr (full4) {
+                if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
+                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            } else {
+                hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            }
+        } else {
+            if constexpr (full3) {
+                if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
+                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            } else {
+                hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            }
+        }
     });
     const size_t n = (size_t)(K2 + 1) * NGD;
     hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);

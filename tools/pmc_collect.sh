@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/pmc}; shift
 mkdir -p "$out"
 export TMPDIR=/tmp
-args="--steps 2 --warmup 1 --standalone-steps 2 --no-cpu-baseline --no-mrr $*"
+args="--steps 2 --warmup 1 --standalone-steps 2 --no-cpu-baseline --no-mrr --cold-items 0 --batch-sweep= $*"
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
 declare -A G
 G[sq_cycles]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU"

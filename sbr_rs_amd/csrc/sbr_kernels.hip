@@ -477,6 +477,56 @@ __device__ __forceinline__ T* launder(T* p) {
     return (T*)g;
 }
 
+// Two LSTM cells at once on packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE
+// operations per issue slot).  The operation sequence per cell is exactly sbr_lstm_cell_fwd's / sbr_tanh_pq's
+// (sbr_numerics.h, sbr_approx.h) — same bits; only min/max and the divisions stay scalar.  The cell epilogue is
+// VALU time that the f32 MFMAs cannot hide, so halving its instruction count is worth doing by hand.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ void tanh_pq_x2(v2f x, v2f* p, v2f* q) {
+    x.x = __builtin_fminf(__builtin_fmaxf(x.x, -SBR_TANH_CLAMP), SBR_TANH_CLAMP);
+    x.y = __builtin_fminf(__builtin_fmaxf(x.y, -SBR_TANH_CLAMP), SBR_TANH_CLAMP);
+    const v2f x2 = x * x;
+    v2f n = pk_splat(-2.76076847742355e-16f);
+    n = pk_fma(n, x2, pk_splat(2.00018790482477e-13f));
+    n = pk_fma(n, x2, pk_splat(-8.60467152213735e-11f));
+    n = pk_fma(n, x2, pk_splat(5.12229709037114e-08f));
+    n = pk_fma(n, x2, pk_splat(1.48572235717979e-05f));
+    n = pk_fma(n, x2, pk_splat(6.37261928875436e-04f));
+    n = pk_fma(n, x2, pk_splat(4.89352455891786e-03f));
+    *p = n * x;
+    v2f dq = pk_splat(1.19825839466702e-06f);
+    dq = pk_fma(dq, x2, pk_splat(1.18534705686654e-04f));
+    dq = pk_fma(dq, x2, pk_splat(2.26843463243900e-03f));
+    dq = pk_fma(dq, x2, pk_splat(4.89352518554385e-03f));
+    *q = dq;
+}
+template <bool COUPLED>
+__device__ __forceinline__ void lstm_cell_fwd_x2(v2f zi, v2f zf, v2f zg, v2f zo, v2f c_prev, v2f* gi, v2f* gf, v2f* gg, v2f* go,
+                                                  v2f* c, v2f* h) {
+    const v2f half = pk_splat(0.5f), one = pk_splat(1.0f);
+    v2f pi = pk_splat(0.0f), qi = one, pf, qf, pg, qg, po, qo;
+    if (!COUPLED) tanh_pq_x2(half * zi, &pi, &qi);
+    tanh_pq_x2(half * zf, &pf, &qf);
+    tanh_pq_x2(zg, &pg, &qg);
+    tanh_pq_x2(half * zo, &po, &qo);
+    const v2f q_if = qi * qf, q_go = qg * qo;
+    const v2f den = q_if * q_go;
+    const v2f r = (v2f){1.0f / den.x, 1.0f / den.y};
+    const v2f r_if = r * q_go, r_go = r * q_if;
+    const v2f f = pk_fma(half, pf * (r_if * qi), half);
+    const v2f i = COUPLED ? one - f : pk_fma(half, pi * (r_if * qf), half);
+    const v2f g = pg * (r_go * qo);
+    const v2f o = pk_fma(half, po * (r_go * qg), half);
+    const v2f cc = pk_fma(f, c_prev, i * g);
+    v2f pc, qc;
+    tanh_pq_x2(cc, &pc, &qc);
+    const v2f tc = (v2f){pc.x / qc.x, pc.y / qc.y};
+    *gi = i; *gf = f; *gg = g; *go = o; *c = cc;
+    *h = o * tc;
+}
+
 template <int D, int NG, int RT, int UPW>
 __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles, int dump_row0) {
     constexpr int K2 = 2 * D;
@@ -697,23 +747,37 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 for (int p = 0; p < UPW; ++p) {
                     const int u = (wv * UPW + p) * 16 + j16;
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int i = rt * 16 + kq * 4 + reg;
-                        // branch-free stores: the lanes of finished sequences write to the dump rows behind G
-                        const bool live = i < nrows;
-                        const size_t r = (size_t)(row_begin + b0 + i);
-                        float zi, zf, zg, zo;
-                        if (NG == 4) { zi = acc[rt][p][0][reg]; zf = acc[rt][p][1][reg]; zg = acc[rt][p][2][reg]; zo = acc[rt][p][NG - 1][reg]; }
-                        else { zi = 0.0f; zf = acc[rt][p][0][reg]; zg = acc[rt][p][1][reg]; zo = acc[rt][p][2][reg]; }
-                        float gi, gf, gg, go, cc, hh;
-                        sbr_lstm_cell_fwd(zi, zf, zg, zo, cst[rt][p][reg], NG == 3, &gi, &gf, &gg, &go, &cc, &hh);
-                        cst[rt][p][reg] = cc;
-                        float* dumprow = Gb + ((size_t)(dump_row0 + i) * 4 * D + u);
-                        float* G = live ? Gb + (r * 4 * D + u) : dumprow;
-                        G[0] = gi; G[D] = gf; G[2 * D] = gg; G[3 * D] = go;
-                        *(live ? Cb + (r * D + u) : dumprow) = cc;
-                        *(live ? Hb + (r * D + u) : dumprow) = hh;
-                        As[i * LDA + D + u] = hh;
+                    for (int rp = 0; rp < 4; rp += 2) {  // two cells per pass (packed f32 arithmetic)
+                        v2f zi2, zf2, zg2, zo2;
+                        if (NG == 4) {
+                            zi2 = (v2f){acc[rt][p][0][rp], acc[rt][p][0][rp + 1]};
+                            zf2 = (v2f){acc[rt][p][1][rp], acc[rt][p][1][rp + 1]};
+                            zg2 = (v2f){acc[rt][p][2][rp], acc[rt][p][2][rp + 1]};
+                            zo2 = (v2f){acc[rt][p][NG - 1][rp], acc[rt][p][NG - 1][rp + 1]};
+                        } else {
+                            zi2 = pk_splat(0.0f);
+                            zf2 = (v2f){acc[rt][p][0][rp], acc[rt][p][0][rp + 1]};
+                            zg2 = (v2f){acc[rt][p][1][rp], acc[rt][p][1][rp + 1]};
+                            zo2 = (v2f){acc[rt][p][2][rp], acc[rt][p][2][rp + 1]};
+                        }
+                        v2f gi2, gf2, gg2, go2, cc2, hh2;
+                        lstm_cell_fwd_x2<NG == 3>(zi2, zf2, zg2, zo2, (v2f){cst[rt][p][rp], cst[rt][p][rp + 1]}, &gi2, &gf2, &gg2, &go2, &cc2, &hh2);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int reg = rp + e;
+                            const int i = rt * 16 + kq * 4 + reg;
+                            // branch-free stores: the lanes of finished sequences write to the dump rows behind G
+                            const bool live = i < nrows;
+                            const size_t r = (size_t)(row_begin + b0 + i);
+                            const float gi = gi2[e], gf = gf2[e], gg = gg2[e], go = go2[e], cc = cc2[e], hh = hh2[e];
+                            cst[rt][p][reg] = cc;
+                            float* dumprow = Gb + ((size_t)(dump_row0 + i) * 4 * D + u);
+                            float* G = live ? Gb + (r * 4 * D + u) : dumprow;
+                            G[0] = gi; G[D] = gf; G[2 * D] = gg; G[3 * D] = go;
+                            *(live ? Cb + (r * D + u) : dumprow) = cc;
+                            *(live ? Hb + (r * D + u) : dumprow) = hh;
+                            As[i * LDA + D + u] = hh;
+                        }
                     }
                 }
         }

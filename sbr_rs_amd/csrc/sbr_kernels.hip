@@ -2499,7 +2499,13 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
     (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
     DISPATCH_D(d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(grid_for_groups((long long)total / 2 + 1, gpb)), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
+        /* 4 workgroups per CU: with 8 the update's waves fill the register file and the dense-gradient GEMM on the side
+         * stream cannot become resident beside it (measured: 14.04 ms per step at 2048, 13.92 at 1024; the update alone
+         * takes the same 1.13-1.2 ms either way) */
+        static const int seg_grid_cap = std::getenv("SBR_SEG_GRID") ? std::atoi(std::getenv("SBR_SEG_GRID")) : 1024;
+        int seg_grid = grid_for_groups((long long)total / 2 + 1, gpb);
+        if (seg_grid > seg_grid_cap) seg_grid = seg_grid_cap;
+        hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(seg_grid), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
         hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
         hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
         hipLaunchKernelGGL((seg_finish_kernel<DD, Emit>), dim3(64), dim3(256), 0, s, keys_sorted, sc, emit);

@@ -699,13 +699,15 @@ def test_full_size_properties():
     g[0].close()
 
 
-@pytest.mark.parametrize("kind,d", [(ModelKind.LSTM_NORMAL, 128), (ModelKind.EWMA, 32), (ModelKind.LSTM_COUPLED, 256)])
-def test_long_sequences(kind, d):
-    """max_sequence_length 300 with users of up to 700 interactions: several chunks per user (short chunk
-    first, data.rs:406-431), 299 dependent time steps inside one kernel launch, minibatches whose tiles differ
-    in length by two orders of magnitude."""
+@pytest.mark.parametrize("kind,d,T", [(ModelKind.LSTM_NORMAL, 128, 300), (ModelKind.EWMA, 32, 300), (ModelKind.LSTM_COUPLED, 256, 300),
+                                      (ModelKind.LSTM_NORMAL, 128, 256), (ModelKind.LSTM_COUPLED, 64, 200), (ModelKind.LSTM_NORMAL, 32, 257)])
+def test_long_sequences(kind, d, T):
+    """max_sequence_length up to 300 with users of up to 700 interactions: several chunks per user (short chunk
+    first, data.rs:406-431), minibatches whose tiles differ in length by two orders of magnitude.  T <= 256 (255
+    dependent time steps inside one launch of the sequence-resident kernels, the longest they take) and T > 256
+    (per-step kernels) both."""
     ptr, it = synthetic_interactions(40, 500, 700, seed=61, min_len=1, zipf=True)
-    hp = hparams(500, 300, d, int(kind), LOSS_WARP, epochs=1, B=16)
+    hp = hparams(500, T, d, int(kind), LOSS_WARP, epochs=1, B=16)
     g, o = make_pair(hp)
     assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
     assert_params_equal(g, o, kind, "long sequences")

@@ -41,6 +41,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
 #endif
 #define SBR_MAX_T 256 /* longest supported max_sequence_length of the sequence-resident kernels */
+/* 64-sequence tiles (one workgroup per CU) pay off only with enough tiles per CU to balance the dependent step chains;
+ * below these counts of 64-sequence tiles the 32-sequence form (two workgroups per CU) is used.  Measured on the bench
+ * workload (ms forward / BPTT, 32- vs 64-sequence tiles): B = 16384: 1.50 / 1.77 vs 2.42 / 2.42; B = 40000 (625 tiles):
+ * 2.97 / 2.83 vs 3.13 / 3.11; B = 50000 (782 tiles): 4.79 / 4.39 vs 4.15 / 4.45; B = 65536: 4.82 / 4.35 vs 4.52 / 4.34. */
+#ifndef SBR_FWD_RT4_MIN_TILES
+#define SBR_FWD_RT4_MIN_TILES 700
+#endif
+#ifndef SBR_BWD_RT4_MIN_TILES
+#define SBR_BWD_RT4_MIN_TILES 1100
+#endif
 #ifndef SBR_FWD_UPW
 #define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
 #endif
@@ -2327,8 +2337,12 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
                 constexpr int UPW = 1;
-                static const int rt_env = std::getenv("SBR_FWD_RT") ? std::atoi(std::getenv("SBR_FWD_RT")) : SBR_FWD_RT;
-                if (rt_env >= 4 && DD >= 64) { /* 64-sequence tiles, one workgroup per CU, 256 registers per wave */
+                /* 64-sequence tiles (one workgroup per CU, 256 registers per wave) when there are enough of them to balance
+                 * the CUs; 32-sequence tiles (two workgroups per CU) for small minibatches, where the longest tile's dependent
+                 * steps set the kernel time.  SBR_SEQ_RT = 2 / 4 forces one form. */
+                static const int rt_env = std::getenv("SBR_SEQ_RT") ? std::atoi(std::getenv("SBR_SEQ_RT")) : 0;
+                const bool big = rt_env ? rt_env >= 4 : (mb.B + 63) / 64 >= SBR_FWD_RT4_MIN_TILES;
+                if (big && DD >= 64) {
                     constexpr int RT = 4;
                     const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
                     if (m.ng == 4)
@@ -2405,13 +2419,20 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
     if (m.d <= 128 && tm_host <= SBR_MAX_T) { /* sequence-resident BPTT: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
-                if constexpr (DD >= 64) { /* 64-sequence tiles, one workgroup per CU */
-                    const int ntiles = (b_host + 63) / 64;
-                    if (m.ng == 4)
-                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
-                    else
-                        hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
-                } else {
+                static const int rt_env = std::getenv("SBR_SEQ_RT") ? std::atoi(std::getenv("SBR_SEQ_RT")) : 0;
+                const bool big = rt_env ? rt_env >= 4 : (b_host + 63) / 64 >= SBR_BWD_RT4_MIN_TILES;
+                bool launched = false;
+                if constexpr (DD >= 64) {
+                    if (big) { /* 64-sequence tiles, one workgroup per CU (see launch_recurrent_forward) */
+                        const int ntiles = (b_host + 63) / 64;
+                        if (m.ng == 4)
+                            hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                        else
+                            hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3, 4>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                        launched = true;
+                    }
+                }
+                if (!launched) {
                     const int ntiles = (b_host + 31) / 32;
                     if (m.ng == 4)
                         hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 2>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);

@@ -734,12 +734,18 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
         }
         PROF_MARK(2)
         int row_begin_next = 0, nrows_next = 0;
-        if (more) {
-            tid = thread_id();
-            step_rows(t + 1, &row_begin_next, &nrows_next);
-            prefetch_x();  // x_{t+1}: lands under the epilogue
-            if (t + 2 < nsteps) prefetch_idx(t + 2);
-        }
+        if (more) step_rows(t + 1, &row_begin_next, &nrows_next);
+        auto request_next_x = [&]() {
+            if (more) {
+                tid = thread_id();
+                prefetch_x();
+                if (t + 2 < nsteps) prefetch_idx(t + 2);
+            }
+        };
+        // 256-register form: x_{t+1} is gathered here and lands under the epilogue.  128-register form: after the epilogue
+        // (its registers would otherwise be spilled across it, and a spill of a just-requested row is a wait for the
+        // gather); the other resident workgroup covers the latency.
+        if constexpr (RT >= 4) request_next_x();
         PROF_MARK(3)
         __syncthreads();  // every wave is done reading As
         PROF_MARK(4)
@@ -788,10 +794,14 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                             *(live ? Hb + (r * D + u) : dumprow) = hh;
                             As[i * LDA + D + u] = hh;
                         }
+                        // 128-register form: one cell pair at a time (interleaving the pairs for instruction-level parallelism
+                        // is what pushed this form into scratch)
+                        if constexpr (RT < 4) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
         }
         PROF_MARK(5)
+        if constexpr (RT < 4) request_next_x();
         row_begin = row_begin_next;
         nrows = nrows_next;
         if (more) stage();  // the x region of As is free since the barrier above

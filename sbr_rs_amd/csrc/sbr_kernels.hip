@@ -58,10 +58,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// All-reduce over the L lanes of a group in the contract's tree order: p += p[lane ^ off] for off = L/2 ... 1
+// (the dot order of sbr_numerics.h).  Every step is a cross-lane move inside the VALU — v_permlane32_swap /
+// v_permlane16_swap (gfx950) for off = 32 / 16, DPP row rotate / shifts / quad permutes below — instead of a
+// ds_bpermute round trip through the LDS crossbar per step (five dependent ones per dot product made the
+// score kernel issue-bound).  Float addition is commutative, so "mine + theirs" has the same bits in both lanes.
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float p) {  // every lane has an in-row source for the controls used here
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), CTRL, 0xF, 0xF, true));
+}
 template <int L>
 __device__ __forceinline__ float group_allreduce(float p) {
-#pragma unroll
-    for (int off = L / 2; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, 64);
+    if constexpr (L >= 64) {
+        const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    if constexpr (L >= 32) {
+        const v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(p), false, false);
+        p = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    if constexpr (L >= 16) p = p + dpp_read<0x128>(p);  // row_ror:8 = lane ^ 8 inside a row of 16
+    if constexpr (L >= 8) {  // lane ^ 4: banks 0, 2 of a row read 4 lanes up, banks 1, 3 read 4 lanes down
+        unsigned t = __builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x104, 0xF, 0x5, false);  // row_shl:4
+        t = __builtin_amdgcn_update_dpp(t, __float_as_uint(p), 0x114, 0xF, 0xA, false);            // row_shr:4
+        p = p + __uint_as_float(t);
+    }
+    if constexpr (L >= 4) p = p + dpp_read<0x4E>(p);  // quad_perm [2,3,0,1] = lane ^ 2
+    if constexpr (L >= 2) p = p + dpp_read<0xB1>(p);  // quad_perm [1,0,3,2] = lane ^ 1
     return p;
 }
 // optimiser element update: Adagrad (acc = sum of squares) or Adam (acc = second moment, mom = first)
@@ -124,6 +148,8 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+    static_assert(SBR_WARP_MAX_TRIES <= 8, "one candidate per lane of an 8-lane group");
+    const bool spread = L >= 8 && max_tries > 1;
     double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
     unsigned int tries_part = 0;
     for (int base = wave * GPW; base < mb.R; base += nwaves * GPW) {
@@ -135,8 +161,11 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
         const uint32_t ctr = mb.ctr[rr];
         const float4 ep = ld4(m.E + (size_t)pi * D + 4 * lg);
         const float bp = m.b[pi];
+        // WARP: lane lg of the group draws candidate lg & 7 — the five draws of the row cost one evaluation of the
+        // 64-bit hash instead of one per try (every lane would compute the same value); try k reads lane k's
+        uint32_t draws = sbr_neg_draw(epoch_key, ctr, spread ? (uint32_t)(lg & 7) : 0u, m.num_items);
         // first candidate is always scored: issue its gather together with the positive's
-        uint32_t cand = sbr_neg_draw(epoch_key, ctr, 0u, m.num_items);
+        uint32_t cand = spread ? (uint32_t)__shfl((int)draws, grp * L, 64) : draws;
         float4 ec = ld4(m.E + (size_t)cand * D + 4 * lg);
         float bc = m.b[cand];
         const float pos = bp + group_allreduce<L>(dot4(h, ep));
@@ -146,7 +175,7 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
         for (int k = 0; k < max_tries; ++k) {
             if (k > 0) {
                 if (__all(done)) break;
-                cand = sbr_neg_draw(epoch_key, ctr, (uint32_t)k, m.num_items);
+                cand = spread ? (uint32_t)__shfl((int)draws, grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr, (uint32_t)k, m.num_items);
                 if (!done) {
                     ec = ld4(m.E + (size_t)cand * D + 4 * lg);
                     bc = m.b[cand];

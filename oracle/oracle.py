@@ -67,6 +67,7 @@ def lib():
         L.orc_fit_step.argtypes = [vp, C.c_uint64]
         L.orc_fit_epoch_async.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
+        L.orc_fit_end_lagged.argtypes = [vp, fp]
         L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
         L.orc_model_fit.argtypes = [vp, vp, vp, C.c_uint64, fp]
         L.orc_user_representation.argtypes = [vp, vp, C.c_uint64, vp]
@@ -189,6 +190,12 @@ class OraclePlan:
         loss, ex = C.c_float(), C.c_uint64()
         _check(lib().orc_fit_end(self._h, C.byref(loss), C.byref(ex)))
         return loss.value, ex.value
+
+    def end_lagged(self) -> float:
+        """The figure the reference's `fit` returns (stale loss-node values, sequence_model.rs:157 before :160)."""
+        loss = C.c_float()
+        _check(lib().orc_fit_end_lagged(self._h, C.byref(loss)))
+        return loss.value
 
     def debug_fetch(self, which: int, rows: int, device: int = 0) -> np.ndarray:
         d = self.model.dim

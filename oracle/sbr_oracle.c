@@ -73,6 +73,9 @@ typedef struct orc_plan {
     uint64_t examples;
     double loss_dev[16];    /* per partition (sequence_model.rs:173-177 sums the partitions' ratios) */
     uint64_t examples_dev[16];
+    /* the figure the reference actually returns: see orc_lagged_loss_update */
+    float lagged_dev[16];
+    float* lagged_node;     /* [ndev][max_sequence_length]: value left in the loss node of each length */
     uint64_t epochs_prepared;
     uint64_t epoch_key_epoch;
 } orc_plan;
@@ -324,6 +327,7 @@ int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
     p->Rmax = (int)(m->hp.batch_sequences * (T - 1));
     p->loc = (orc_local*)calloc(ndev, sizeof(orc_local));
     for (int q = 0; q < ndev; ++q) orc_local_alloc(&p->loc[q], p->Rmax, (int)T, m->d, m->ng);
+    p->lagged_node = (float*)calloc((size_t)ndev * T, sizeof(float));
     *out = p;
     return SBR_OK;
 }
@@ -332,6 +336,7 @@ void orc_fit_plan_destroy(orc_plan* p) {
     if (!p) return;
     for (int q = 0; q < p->ndev; ++q) orc_local_free(&p->loc[q]);
     free(p->loc); free(p->seq_start); free(p->seq_len); free(p->part_rng); free(p->fit_seed); free(p->items);
+    free(p->lagged_node);
     free(p);
 }
 
@@ -502,6 +507,26 @@ static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
     L->examples = (uint64_t)L->R;
 }
 
+/* The loss figure the reference returns.  sequence_model.rs:157 adds `loss.value().scalar_sum()` of the node
+ * losses[loss_idx] BEFORE :160 runs `loss.forward()` on it, so what a worker accumulates for a sequence of n items
+ * is the value the previous forward pass left in that node — the summed loss L_{n-2} of the worker's previous
+ * sequence of the same length (0 the first time; wyrm keeps a node's value until the next forward, recalled).
+ * Accumulated in f32 like the reference's `loss_value`; sequences of one minibatch in minibatch order (with
+ * batch_sequences = 1 this is the reference's order).  The engine reports the true sums (orc_fit_end); this figure
+ * exists so that the two can be told apart (tests/test_oracle.py::test_lagged_loss_figure). */
+static void orc_lagged_loss_update(orc_plan* p, int q) {
+    const orc_local* L = &p->loc[q];
+    float* node = p->lagged_node + (size_t)q * p->m->hp.max_sequence_length;
+    for (int b = 0; b < L->B; ++b) {
+        float sum = 0.0f; /* L_t = L_{t-1} + l_t (lstm.rs:322-328) */
+        int steps = 0;
+        for (int t = 0; t < L->Tm && b < L->off[t + 1] - L->off[t]; ++t, ++steps) sum = sum + L->loss[L->off[t] + b];
+        if (steps == 0) continue;
+        p->lagged_dev[q] = p->lagged_dev[q] + node[steps - 1];
+        node[steps - 1] = sum;
+    }
+}
+
 /* BPTT (≙ loss.backward(1.0), sequence_model.rs:161) + dense gradient of this device.
  * Dense reduction order: packed rows are cut into chunks of ORC_DW_CHUNK_ROWS; inside a chunk a
  * row-ascending fma chain from 0; chunk partials added in chunk order. */
@@ -629,6 +654,7 @@ int orc_fit_step_local(orc_plan* p, int q, uint64_t mb) {
     orc_pack(p, q, mb, L);
     orc_forward(p->m, L);
     orc_score(p->m, L, orc_epoch_key_of(p->fit_seed[q], p->epoch_key_epoch));
+    orc_lagged_loss_update(p, q);
     orc_backward(p->m, L);
     return SBR_OK;
 }
@@ -954,6 +980,15 @@ int orc_fit_end(orc_plan* p, float* out_loss, uint64_t* out_examples) {
     for (int q = 0; q < p->ndev; ++q) total += p->loss_dev[q] / (1.0 + (double)p->examples_dev[q]);
     if (out_loss) *out_loss = (float)total;
     if (out_examples) *out_examples = p->examples;
+    return SBR_OK;
+}
+
+/* ≙ the value `fit` returns in the reference: sum over the workers of (stale node values) / (1 + examples) */
+int orc_fit_end_lagged(orc_plan* p, float* out_loss) {
+    if (!p || !out_loss) return SBR_ERR_INVALID_ARGUMENT;
+    float total = 0.0f;
+    for (int q = 0; q < p->ndev; ++q) total = total + p->lagged_dev[q] / (1.0f + (float)p->examples_dev[q]);
+    *out_loss = total;
     return SBR_OK;
 }
 

@@ -221,6 +221,36 @@ def test_fit_is_deterministic_and_recallable(oracle_lib):
     assert not np.array_equal(a.get_param(Param.ITEM_EMBEDDING), b.get_param(Param.ITEM_EMBEDDING))
 
 
+def test_lagged_loss_figure(oracle_lib):
+    """the reference adds a loss node's value BEFORE running its forward pass
+    (sequence_model.rs:157 vs :160), i.e. the loss of the worker's previous sequence of the same length.  The
+    oracle exposes that figure beside the true sums: with equal-length sequences and one sequence per step it
+    is the true sum minus the last sequence's loss."""
+    n_users, n = 9, 7
+    rng = np.random.default_rng(3)
+    ptr = np.arange(0, (n_users + 1) * n, n, dtype=np.uint64)
+    items = rng.integers(0, 50, size=n_users * n).astype(np.uint32)
+    hp = hparams(50, 10, 16, int(ModelKind.LSTM_NORMAL), LOSS_HINGE, B=1, epochs=1)
+    plan = OracleModel(hp).fit_begin(ptr, items)
+    per_sequence = []
+    for mb in range(plan.epoch_prepare()):
+        plan.step(mb)
+        rows = plan.minibatch_rows(mb)
+        assert rows == n - 1
+        acc = np.float32(0.0)
+        for l in plan.debug_fetch(Debug.LOSS, rows):
+            acc = np.float32(acc + l)
+        per_sequence.append(acc)
+    true_loss, examples = plan.end()
+    assert examples == n_users * (n - 1)
+    assert true_loss == pytest.approx(float(np.sum(per_sequence, dtype=np.float64)) / (1 + examples), rel=1e-6)
+    lagged = np.float32(0.0)
+    for v in per_sequence[:-1]:  # sequence k reads what sequence k-1 left in the node; the first reads 0
+        lagged = np.float32(lagged + v)
+    assert plan.end_lagged() == np.float32(lagged / np.float32(1 + examples))
+    assert plan.end_lagged() < true_loss
+
+
 def test_mrr_masks_all_history_and_counts_ties(oracle_lib):
     """evaluation.rs:30-41 on a hand-checkable model: zero embeddings => score = bias."""
     m = OracleModel(hparams(6, 4, 16, int(ModelKind.EWMA), LOSS_HINGE))

@@ -53,7 +53,7 @@ typedef enum sbr_parallelism { SBR_PAR_ASYNCHRONOUS = 0, SBR_PAR_SYNCHRONOUS = 1
 typedef struct sbr_hparams {
     uint32_t num_items;
     uint32_t max_sequence_length;
-    uint32_t embedding_dim; /* 16, 32, 64, 128 or 256 */
+    uint32_t embedding_dim; /* 1 .. 256; widths other than 16 / 32 / 64 / 128 / 256 are stored zero-padded to the next one */
     float learning_rate;
     float l2_penalty;
     int32_t model;       /* sbr_model_kind */

@@ -11,7 +11,7 @@ import subprocess
 
 import numpy as np
 
-from sbr_rs_amd._abi import SbrHparams, Status
+from sbr_rs_amd._abi import SbrHparams, Status, storage_dim
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsbr_oracle.so")
@@ -68,6 +68,7 @@ def lib():
         L.orc_fit_epoch_async.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
         L.orc_fit_end_lagged.argtypes = [vp, fp]
+        L.orc_model_padding_is_zero.argtypes = [vp]
         L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
         L.orc_model_fit.argtypes = [vp, vp, vp, C.c_uint64, fp]
         L.orc_user_representation.argtypes = [vp, vp, C.c_uint64, vp]
@@ -198,7 +199,7 @@ class OraclePlan:
         return loss.value
 
     def debug_fetch(self, which: int, rows: int, device: int = 0) -> np.ndarray:
-        d = self.model.dim
+        d = self.model.storage_dim
         which = int(which)
         if which in (0, 4, 5):
             out = np.zeros((rows, d), dtype=np.float32)
@@ -228,9 +229,10 @@ class OracleModel:
         h = C.c_void_p()
         _check(lib().orc_model_create(C.byref(hp), C.byref(h)))
         self._h = h
+        self.storage_dim = storage_dim(self.dim)
 
     def dense_count(self) -> int:
-        d = self.dim
+        d = self.storage_dim
         ng = {0: 4, 1: 3, 2: 0}[int(self.hp.model)]
         return (2 * d + 1) * ng * d if ng else d
 
@@ -250,6 +252,10 @@ class OracleModel:
 
     def global_epoch(self) -> int:
         return lib().orc_model_get_epoch(self._h)
+
+    def padding_is_zero(self) -> bool:
+        """Every stored element beyond embedding_dim (parameters and optimiser state) is still zero."""
+        return bool(lib().orc_model_padding_is_zero(self._h))
 
     def optimizer_steps(self) -> int:
         return lib().orc_model_get_opt_steps(self._h)

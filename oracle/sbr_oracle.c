@@ -34,7 +34,8 @@
 
 typedef struct orc_model {
     sbr_hparams hp;
-    int d, ng; /* ng = gate blocks in W: 4 (normal) / 3 (coupled) / 0 (ewma) */
+    int d, ng; /* ng = gate blocks in W: 4 (normal) / 3 (coupled) / 0 (ewma); d = storage width (orc_storage_dim) */
+    int dl;    /* embedding_dim as the caller sees it */
     float *E, *Eacc, *b, *bacc;
     float *W, *Wacc, *bW, *bWacc; /* W [2d][ng*d] */
     float *alpha, *alpha_acc;
@@ -81,7 +82,15 @@ typedef struct orc_plan {
 } orc_plan;
 
 /* ------------------------------------------------------------------------------------------ */
-static int orc_dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
+/* The contract's dot orders (orc_numerics.h) are stated for widths 16 .. 256 in powers of two.  Any other
+ * embedding_dim e <= 256 (lstm.rs:86-89 takes any usize) is DEFINED as the model of the next width up whose extra
+ * embedding columns, weight rows / columns and alpha entries are zero: such a unit computes z = 0, c = 0, h = 0,
+ * receives zero gradients and is left at zero by Adagrad / Adam, so that model is the e-wide model with +0 terms
+ * in its sums (orc_model_padding_is_zero checks the invariant after training). */
+static int orc_storage_dim(uint32_t e) {
+    for (uint32_t p = 16; p <= 256; p *= 2) if (e >= 1 && e <= p) return (int)p;
+    return 0;
+}
 
 /* ≙ Hyperparameters::build_params (lstm.rs:174-194, ewma.rs:167-198): E ~ N(0,(1/d)^2) drawn
  * row-major from the model RNG (embedding_init, lstm.rs:22-25: rand 0.5 Normal, f64 -> f32), biases 0,
@@ -95,16 +104,17 @@ static int orc_dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d ==
  *         that the RNG the driver shuffles with is where the reference's is. */
 int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
-    if (!orc_dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
+    if (!orc_storage_dim(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 ||
         hp->num_devices == 0 || hp->num_devices > 16 || hp->batch_sequences == 0)
         return SBR_ERR_INVALID_ARGUMENT;
     if (hp->optimizer != SBR_OPT_ADAGRAD && hp->optimizer != SBR_OPT_ADAM) return SBR_ERR_INVALID_ARGUMENT;
     orc_model* m = (orc_model*)calloc(1, sizeof(orc_model));
     m->hp = *hp;
-    int d = m->d = (int)hp->embedding_dim;
+    int dl = m->dl = (int)hp->embedding_dim;
+    int d = m->d = orc_storage_dim(hp->embedding_dim);
     m->ng = hp->model == SBR_MODEL_LSTM_NORMAL ? 4 : hp->model == SBR_MODEL_LSTM_COUPLED ? 3 : 0;
     size_t I = hp->num_items;
-    m->E = (float*)malloc(I * d * sizeof(float));
+    m->E = (float*)calloc(I * d, sizeof(float));
     m->Eacc = (float*)calloc(I * d, sizeof(float));
     m->b = (float*)calloc(I, sizeof(float));
     m->bacc = (float*)calloc(I, sizeof(float));
@@ -112,22 +122,23 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
     m->c1 = m->c2 = 1.0f;
     if (adam) { m->Em = (float*)calloc(I * d, sizeof(float)); m->bm = (float*)calloc(I, sizeof(float)); }
     orc_rng_from_seed(&m->rng, hp->seed);
-    double std_e = 1.0 / (double)d;
-    for (size_t i = 0; i < I * (size_t)d; ++i) m->E[i] = orc_rng_normal_f32(&m->rng, 0.0, std_e);
+    double std_e = 1.0 / (double)dl; /* row-major, embedding_dim values per row */
+    for (size_t r = 0; r < I; ++r)
+        for (int c = 0; c < dl; ++c) m->E[r * d + c] = orc_rng_normal_f32(&m->rng, 0.0, std_e);
     if (m->ng) {
         size_t nw = (size_t)2 * d * m->ng * d;
-        m->W = (float*)malloc(nw * sizeof(float));
+        m->W = (float*)calloc(nw, sizeof(float));
         m->Wacc = (float*)calloc(nw, sizeof(float));
         m->bW = (float*)calloc((size_t)m->ng * d, sizeof(float));
         m->bWacc = (float*)calloc((size_t)m->ng * d, sizeof(float));
         if (adam) { m->Wm = (float*)calloc(nw, sizeof(float)); m->bWm = (float*)calloc((size_t)m->ng * d, sizeof(float)); }
-        double std_w = 1.0 / sqrt((double)(2 * d));
+        double std_w = 1.0 / sqrt((double)(2 * dl));
         int nz = m->ng * d;
         for (int gate = 0; gate < 4; ++gate) { /* wyrm order: forget, update gate, update value, output gate */
             int block = m->ng == 4 ? (gate == 0 ? 1 : gate == 1 ? 0 : gate) : (gate == 0 ? 0 : gate == 1 ? -1 : gate - 1);
-            for (int row = 0; row < 2 * d; ++row) {
-                int k = row < d ? d + row : row - d; /* wyrm rows: hidden first; here rows are [x ; h] */
-                for (int u = 0; u < d; ++u) {
+            for (int row = 0; row < 2 * dl; ++row) {
+                int k = row < dl ? d + row : row - dl; /* wyrm rows: hidden first; here rows are [x ; h] */
+                for (int u = 0; u < dl; ++u) {
                     float v = orc_rng_normal_f32(&m->rng, 0.0, std_w);
                     if (block >= 0) m->W[(size_t)k * nz + block * d + u] = v;
                 }
@@ -137,8 +148,8 @@ int orc_model_create(const sbr_hparams* hp, orc_model** out) {
         m->alpha = (float*)calloc(d, sizeof(float));
         m->alpha_acc = (float*)calloc(d, sizeof(float));
         if (adam) m->alpha_m = (float*)calloc(d, sizeof(float));
-        double std_fc = sqrt(2.0 / (double)(d + d)); /* dense_init, ewma.rs:38-41 */
-        for (int i = 0; i < 2 * d * d; ++i) (void)orc_rng_normal_f32(&m->rng, 0.0, std_fc);
+        double std_fc = sqrt(2.0 / (double)(dl + dl)); /* dense_init, ewma.rs:38-41 */
+        for (int i = 0; i < 2 * dl * dl; ++i) (void)orc_rng_normal_f32(&m->rng, 0.0, std_fc);
     }
     *out = m;
     return SBR_OK;
@@ -153,45 +164,84 @@ void orc_model_destroy(orc_model* m) {
     free(m);
 }
 
-static float* orc_param_ptr(orc_model* m, int which, uint64_t* count) {
-    uint64_t I = m->hp.num_items, d = (uint64_t)m->d, ng = (uint64_t)m->ng;
+/* parameter arrays in the caller's shapes (embedding_dim dl): E [I][dl], W [2 dl][ng dl], bW [ng dl], alpha [dl];
+ * kind: 0 flat, 1 rows of the item table, 2 LSTM weight matrix, 3 LSTM bias */
+static float* orc_param_ptr(orc_model* m, int which, uint64_t* count, int* kind) {
+    uint64_t I = m->hp.num_items, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
+    float* p = NULL; uint64_t n = 0; int k = 0;
     switch (which) {
-        case SBR_PARAM_ITEM_EMBEDDING: *count = I * d; return m->E;
-        case SBR_PARAM_ITEM_EMBEDDING_ACC: *count = I * d; return m->Eacc;
-        case SBR_PARAM_ITEM_BIAS: *count = I; return m->b;
-        case SBR_PARAM_ITEM_BIAS_ACC: *count = I; return m->bacc;
-        case SBR_PARAM_LSTM_W: *count = 2 * d * ng * d; return m->W;
-        case SBR_PARAM_LSTM_W_ACC: *count = 2 * d * ng * d; return m->Wacc;
-        case SBR_PARAM_LSTM_B: *count = ng * d; return m->bW;
-        case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return m->bWacc;
-        case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return m->alpha;
-        case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return m->alpha_acc;
-        case SBR_PARAM_ITEM_EMBEDDING_M: *count = m->Em ? I * d : 0; return m->Em;
-        case SBR_PARAM_ITEM_BIAS_M: *count = m->bm ? I : 0; return m->bm;
-        case SBR_PARAM_LSTM_W_M: *count = m->Wm ? 2 * d * ng * d : 0; return m->Wm;
-        case SBR_PARAM_LSTM_B_M: *count = m->bWm ? ng * d : 0; return m->bWm;
-        case SBR_PARAM_EWMA_ALPHA_M: *count = m->alpha_m ? d : 0; return m->alpha_m;
+        case SBR_PARAM_ITEM_EMBEDDING: p = m->E; n = I * dl; k = 1; break;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: p = m->Eacc; n = I * dl; k = 1; break;
+        case SBR_PARAM_ITEM_BIAS: p = m->b; n = I; break;
+        case SBR_PARAM_ITEM_BIAS_ACC: p = m->bacc; n = I; break;
+        case SBR_PARAM_LSTM_W: p = m->W; n = 2 * dl * ng * dl; k = 2; break;
+        case SBR_PARAM_LSTM_W_ACC: p = m->Wacc; n = 2 * dl * ng * dl; k = 2; break;
+        case SBR_PARAM_LSTM_B: p = m->bW; n = ng * dl; k = 3; break;
+        case SBR_PARAM_LSTM_B_ACC: p = m->bWacc; n = ng * dl; k = 3; break;
+        case SBR_PARAM_EWMA_ALPHA: p = m->alpha; n = ng ? 0 : dl; break;
+        case SBR_PARAM_EWMA_ALPHA_ACC: p = m->alpha_acc; n = ng ? 0 : dl; break;
+        case SBR_PARAM_ITEM_EMBEDDING_M: p = m->Em; n = m->Em ? I * dl : 0; k = 1; break;
+        case SBR_PARAM_ITEM_BIAS_M: p = m->bm; n = m->bm ? I : 0; break;
+        case SBR_PARAM_LSTM_W_M: p = m->Wm; n = m->Wm ? 2 * dl * ng * dl : 0; k = 2; break;
+        case SBR_PARAM_LSTM_B_M: p = m->bWm; n = m->bWm ? ng * dl : 0; k = 3; break;
+        case SBR_PARAM_EWMA_ALPHA_M: p = m->alpha_m; n = m->alpha_m ? dl : 0; break;
     }
-    *count = 0;
-    return NULL;
+    *count = n;
+    if (kind) *kind = k;
+    return p;
+}
+/* stored position of logical element i of a parameter array */
+static size_t orc_param_stored_index(const orc_model* m, int kind, uint64_t count, uint64_t i) {
+    uint64_t d = (uint64_t)m->d, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
+    switch (kind) {
+        case 1: return (size_t)((i / dl) * d + i % dl);
+        case 2: { uint64_t kl = i / (ng * dl), j = i % (ng * dl), k = kl < dl ? kl : d + (kl - dl); return (size_t)(k * ng * d + (j / dl) * d + j % dl); }
+        case 3: return (size_t)((i / dl) * d + i % dl);
+        default: (void)count; return (size_t)i;
+    }
 }
 int orc_model_param_count(orc_model* m, int which, uint64_t* out) {
-    orc_param_ptr(m, which, out);
+    orc_param_ptr(m, which, out, NULL);
     return SBR_OK;
 }
 int orc_model_get_param(orc_model* m, int which, float* out, uint64_t count) {
-    uint64_t n;
-    float* p = orc_param_ptr(m, which, &n);
+    uint64_t n; int kind;
+    float* p = orc_param_ptr(m, which, &n, &kind);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
-    memcpy(out, p, n * sizeof(float));
+    for (uint64_t i = 0; i < n; ++i) out[i] = p[orc_param_stored_index(m, kind, n, i)];
     return SBR_OK;
 }
 int orc_model_set_param(orc_model* m, int which, const float* in, uint64_t count) {
-    uint64_t n;
-    float* p = orc_param_ptr(m, which, &n);
+    uint64_t n; int kind;
+    float* p = orc_param_ptr(m, which, &n, &kind);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
-    memcpy(p, in, n * sizeof(float));
+    for (uint64_t i = 0; i < n; ++i) p[orc_param_stored_index(m, kind, n, i)] = in[i]; /* the padding keeps its zeros */
     return SBR_OK;
+}
+/* 1 if every padded element of every parameter and optimiser-state array is still zero (the fixed point the
+ * definition of a non-power-of-two embedding_dim rests on) */
+int orc_model_padding_is_zero(orc_model* m) {
+    uint64_t I = m->hp.num_items, d = (uint64_t)m->d, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
+    const float* tables[3] = {m->E, m->Eacc, m->Em};
+    for (int a = 0; a < 3; ++a)
+        if (tables[a])
+            for (uint64_t r = 0; r < I; ++r)
+                for (uint64_t c = dl; c < d; ++c) if (tables[a][r * d + c] != 0.0f) return 0;
+    const float* mats[3] = {m->W, m->Wacc, m->Wm};
+    for (int a = 0; a < 3; ++a)
+        if (mats[a])
+            for (uint64_t k = 0; k < 2 * d; ++k)
+                for (uint64_t j = 0; j < ng * d; ++j) {
+                    int pad = (k % d) >= dl || (j % d) >= dl;
+                    if (pad && mats[a][k * ng * d + j] != 0.0f) return 0;
+                }
+    const float* vecs[6] = {m->bW, m->bWacc, m->bWm, m->alpha, m->alpha_acc, m->alpha_m};
+    for (int a = 0; a < 6; ++a)
+        if (vecs[a]) {
+            uint64_t n = a < 3 ? ng * d : d;
+            for (uint64_t j = 0; j < n; ++j) if ((j % d) >= dl && vecs[a][j] != 0.0f) return 0;
+        }
+    return 1;
 }
 uint64_t orc_model_get_epoch(orc_model* m) { return m->global_epoch; }
 uint64_t orc_model_get_opt_steps(orc_model* m) { return m->opt_steps; }
@@ -1034,7 +1084,7 @@ int orc_model_fit(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
 /* ------------------------------------------------------------------------------------------ */
 /* ≙ user_representation (sequence_model.rs:182-211): last T items; empty history = one step
  * with the default index 0 (IndexInputNode::new(&[0;1]), lstm.rs:262-264). */
-int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, float* out) {
+static int orc_user_representation_stored(orc_model* m, const uint32_t* item_ids, uint64_t n, float* out) {
     int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
     uint64_t T = m->hp.max_sequence_length;
     uint32_t zero = 0;
@@ -1077,8 +1127,15 @@ int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, 
     return SBR_OK;
 }
 
+int orc_user_representation(orc_model* m, const uint32_t* item_ids, uint64_t n, float* out) { /* out: embedding_dim floats */
+    float rep[256];
+    int st = orc_user_representation_stored(m, item_ids, n, rep);
+    if (st == SBR_OK) memcpy(out, rep, sizeof(float) * (size_t)m->dl);
+    return st;
+}
+
 /* ≙ predict (sequence_model.rs:213-232): bias + dot ("chain" order); non-finite fails the call */
-int orc_predict(orc_model* m, const float* user, const uint32_t* item_ids, uint64_t n, float* out) {
+static int orc_predict_stored(orc_model* m, const float* user, const uint32_t* item_ids, uint64_t n, float* out) {
     for (uint64_t i = 0; i < n; ++i) {
         if (item_ids[i] >= m->hp.num_items) return SBR_ERR_INVALID_ARGUMENT;
         float s = m->b[item_ids[i]] + orc_dot_prediction(user, m->E + (size_t)item_ids[i] * m->d, m->d);
@@ -1086,6 +1143,12 @@ int orc_predict(orc_model* m, const float* user, const uint32_t* item_ids, uint6
         out[i] = s;
     }
     return SBR_OK;
+}
+
+int orc_predict(orc_model* m, const float* user, const uint32_t* item_ids, uint64_t n, float* out) { /* user: embedding_dim floats */
+    float rep[256] = {0.0f};
+    memcpy(rep, user, sizeof(float) * (size_t)m->dl);
+    return orc_predict_stored(m, rep, item_ids, n, out);
 }
 
 /* ≙ mrr_score (evaluation.rs:12-48) */
@@ -1104,9 +1167,9 @@ int orc_mrr_score(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
         if (n < 2) continue; /* evaluation.rs:20 */
         const uint32_t* it = item_ids + user_ptr[u];
         uint32_t test_item = it[n - 1];
-        st = orc_user_representation(m, it, n - 1, rep);
+        st = orc_user_representation_stored(m, it, n - 1, rep);
         if (st != SBR_OK) break;
-        st = orc_predict(m, rep, all, I, pred);
+        st = orc_predict_stored(m, rep, all, I, pred);
         if (st != SBR_OK) break;
         for (uint64_t t = 0; t + 1 < n; ++t) pred[it[t]] = ORC_F32_MIN; /* :30-32, ALL history items */
         float ts = pred[test_item];

@@ -87,6 +87,16 @@ class SbrHparams(C.Structure):
     ]
 
 
+def storage_dim(embedding_dim: int) -> int:
+    """Width the engine stores an embedding_dim in (16 / 32 / 64 / 128 / 256; the extra columns are zero and stay
+    zero — sbr_engine.hip `storage_dim`).  Parameters, user representations and predictions use embedding_dim;
+    the debug views and exchange blocks (`sbr_fit_debug_fetch`, dense gradient) use this width."""
+    for p in (16, 32, 64, 128, 256):
+        if 1 <= int(embedding_dim) <= p:
+            return p
+    raise ValueError(f"embedding_dim {embedding_dim}: 1..256 supported")
+
+
 def make_hparams(num_items, max_sequence_length, embedding_dim, learning_rate, l2_penalty, model, loss,
                  optimizer, parallelism, seed, num_epochs, num_devices=1, device_rank=0,
                  batch_sequences=1) -> SbrHparams:

@@ -52,19 +52,32 @@ sbr_status dmalloc(T** p, size_t count) {
 
 int dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
+/* Storage width of an embedding_dim: the kernels exist for 16 / 32 / 64 / 128 / 256 columns; any other
+ * embedding_dim <= 256 (the reference's builder takes any usize, lstm.rs:86-89) is stored in the next width up
+ * with the extra columns — of the embeddings, of every weight row and column, of alpha — ZERO.  That is a fixed
+ * point of the training step: a zero input/hidden unit with zero weights has z = 0, c = 0, h = 0 in the forward
+ * pass, receives a zero gradient from the loss (its embedding columns are zero) and from the recurrence (its
+ * weights are zero), so Adagrad/Adam leave it at zero — the padded model IS the embedding_dim-wide model, with
+ * +0 terms in its sums.  0 = unsupported. */
+int storage_dim(uint32_t e) {
+    for (uint32_t p = 16; p <= 256; p *= 2)
+        if (e >= 1 && e <= p) return (int)p;
+    return 0;
+}
+
 /* ≙ wyrm nn::lstm::Parameters::new as recalled: four [(hidden+input) x hidden]
  * xavier_normal matrices (std 1/sqrt(rows)) drawn one after the other — forget, update gate, update
  * value, output gate — rows = hidden part first; a coupled layer draws all four and ignores the update
  * gate's.  Engine layout: W[2d][ng*d], rows [x ; h], column blocks i,f,g,o (coupled: f,g,o). */
-void draw_lstm_weights(sbr_xorshift* rng, int d, int ng, std::vector<float>* w) {
-    const double std_w = 1.0 / std::sqrt((double)(2 * d));
+void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<float>* w) { /* dl = embedding_dim, d = storage width */
+    const double std_w = 1.0 / std::sqrt((double)(2 * dl));
     const int nz = ng * d;
     w->assign((size_t)2 * d * nz, 0.0f);
     for (int gate = 0; gate < 4; ++gate) {
         const int block = ng == 4 ? (gate == 0 ? 1 : gate == 1 ? 0 : gate) : (gate == 0 ? 0 : gate == 1 ? -1 : gate - 1);
-        for (int row = 0; row < 2 * d; ++row) {
-            const int k = row < d ? d + row : row - d;
-            for (int u = 0; u < d; ++u) {
+        for (int row = 0; row < 2 * dl; ++row) {
+            const int k = row < dl ? d + row : row - dl;
+            for (int u = 0; u < dl; ++u) {
                 const float v = sbr_rand_normal_f32(rng, 0.0, std_w);
                 if (block >= 0) (*w)[(size_t)k * nz + block * d + u] = v;
             }
@@ -267,7 +280,8 @@ struct SharedTable {
 struct sbr_model {
     sbr_hparams hp;
     std::shared_ptr<SharedTable> shared; /* partitioned group: the table arrays belong to this object */
-    int d = 0, ng = 0;
+    int d = 0, ng = 0; /* d = storage width (storage_dim of hp.embedding_dim) */
+    int dl = 0;        /* embedding_dim as the caller sees it */
     int device = 0;
     sbr::ModelView mv;
     sbr_xorshift rng;
@@ -588,7 +602,7 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
                                     const sbr_xorshift* rng_after_table, sbr_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 || hp->num_devices == 0 ||
+    if (!storage_dim(hp->embedding_dim) || hp->num_items == 0 || hp->max_sequence_length < 3 || hp->num_devices == 0 ||
         hp->num_devices > 16 || hp->device_rank >= hp->num_devices || hp->batch_sequences == 0 ||
         hp->model < 0 || hp->model > 2 || hp->loss < 0 || hp->loss > 2)
         return SBR_ERR_INVALID_ARGUMENT;
@@ -598,7 +612,8 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
     sbr_model* m = new (std::nothrow) sbr_model();
     if (!m) return SBR_ERR_OUT_OF_MEMORY;
     m->hp = *hp;
-    m->d = (int)hp->embedding_dim;
+    m->dl = (int)hp->embedding_dim;
+    m->d = storage_dim(hp->embedding_dim);
     m->ng = hp->model == SBR_MODEL_LSTM_NORMAL ? 4 : hp->model == SBR_MODEL_LSTM_COUPLED ? 3 : 0;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return SBR_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { delete m; return SBR_ERR_HIP; }
@@ -645,20 +660,23 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         hipMemsetAsync(v.Eacc, 0, I * d * 4, m->stream);
         hipMemsetAsync(v.b, 0, I * 4, m->stream);
         hipMemsetAsync(v.bacc, 0, I * 4, m->stream);
-        std::vector<float> host(I * d);
-        const double std_e = 1.0 / (double)d; /* embedding_init, lstm.rs:22-25 */
-        for (size_t i = 0; i < host.size(); ++i) host[i] = sbr_rand_normal_f32(&m->rng, 0.0, std_e);
+        std::vector<float> host(I * d, 0.0f);
+        const uint64_t dl = (uint64_t)m->dl;
+        const double std_e = 1.0 / (double)dl; /* embedding_init, lstm.rs:22-25: row-major, embedding_dim values per row */
+        for (uint64_t row = 0; row < I; ++row)
+            for (uint64_t c = 0; c < dl; ++c) host[row * d + c] = sbr_rand_normal_f32(&m->rng, 0.0, std_e);
         if (hipMemcpy(v.E, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
     } else if (table_init == TABLE_OWN_ROWS_DEFERRED) {
         /* every rank walks the whole initialisation stream (the RNG has no skip-ahead through the normal
          * sampler's rejections) and keeps the rows it owns; they are written once the peers' parts are mapped */
         const uint64_t S = shared->slice, r0 = std::min<uint64_t>(I, (uint64_t)hp->device_rank * S), r1 = std::min<uint64_t>(I, r0 + S);
-        m->pending_E.resize((size_t)((r1 - r0) * d));
-        const double std_e = 1.0 / (double)d;
-        for (uint64_t i = 0; i < I * d; ++i) {
+        m->pending_E.assign((size_t)((r1 - r0) * d), 0.0f);
+        const uint64_t dl = (uint64_t)m->dl;
+        const double std_e = 1.0 / (double)dl;
+        for (uint64_t i = 0; i < I * dl; ++i) {
             const float val = sbr_rand_normal_f32(&m->rng, 0.0, std_e);
-            const uint64_t row = i / d;
-            if (row >= r0 && row < r1) m->pending_E[(size_t)(i - r0 * d)] = val;
+            const uint64_t row = i / dl;
+            if (row >= r0 && row < r1) m->pending_E[(size_t)((row - r0) * d + i % dl)] = val;
         }
         m->partition_finalized = false;
     } else {
@@ -683,7 +701,7 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         hipMemsetAsync(v.bW, 0, nb * 4, m->stream);
         hipMemsetAsync(v.bWacc, 0, nb * 4, m->stream);
         std::vector<float> host;
-        draw_lstm_weights(&m->rng, m->d, m->ng, &host);
+        draw_lstm_weights(&m->rng, m->dl, m->d, m->ng, &host);
         if (hipMemcpy(v.W, host.data(), nw * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(SBR_ERR_HIP);
         sbr::launch_repack_lstm(v, m->stream);
     } else {
@@ -697,8 +715,9 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         hipMemsetAsync(v.alpha_acc, 0, d * 4, m->stream);
         /* the reference also draws the two unused d x d dense_init matrices fc1, fc2 from this RNG
          * (ewma.rs:179-188): drawn and dropped, so the driver's shuffles start where the reference's do */
-        const double std_fc = std::sqrt(2.0 / (double)(d + d));
-        for (uint64_t i = 0; i < 2 * d * d; ++i) (void)sbr_rand_normal_f32(&m->rng, 0.0, std_fc);
+        const uint64_t dl = (uint64_t)m->dl;
+        const double std_fc = std::sqrt(2.0 / (double)(dl + dl));
+        for (uint64_t i = 0; i < 2 * dl * dl; ++i) (void)sbr_rand_normal_f32(&m->rng, 0.0, std_fc);
     }
     if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(SBR_ERR_HIP);
     *out = m;
@@ -745,28 +764,63 @@ sbr_status sbr_model_synchronize(sbr_model* m) {
     return SBR_OK;
 }
 
-static float* param_ptr(sbr_model* m, int32_t which, uint64_t* count) {
-    const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, ng = (uint64_t)m->ng;
+/* Parameter arrays as the caller sees them: shapes in embedding_dim (dl) — E [I][dl], W [2 dl][ng dl] (rows [x ; h],
+ * column blocks per gate), bW [ng dl], alpha [dl].  Storage is in the padded width d (storage_dim): `stored` is the
+ * device array's element count, `shape` says how logical elements map into it. */
+enum ParamShape { SHAPE_FLAT = 0, SHAPE_ROWS = 1, SHAPE_LSTM_W = 2, SHAPE_LSTM_B = 3 };
+static float* param_ptr(sbr_model* m, int32_t which, uint64_t* count, uint64_t* stored = nullptr, int* shape = nullptr) {
+    const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
     sbr::ModelView& v = m->mv;
+    float* p = nullptr;
+    uint64_t n = 0, ns = 0;
+    int sh = SHAPE_FLAT;
     switch (which) {
-        case SBR_PARAM_ITEM_EMBEDDING: *count = I * d; return v.E;
-        case SBR_PARAM_ITEM_EMBEDDING_ACC: *count = I * d; return v.Eacc;
-        case SBR_PARAM_ITEM_BIAS: *count = I; return v.b;
-        case SBR_PARAM_ITEM_BIAS_ACC: *count = I; return v.bacc;
-        case SBR_PARAM_LSTM_W: *count = 2 * d * ng * d; return v.W;
-        case SBR_PARAM_LSTM_W_ACC: *count = 2 * d * ng * d; return v.Wacc;
-        case SBR_PARAM_LSTM_B: *count = ng * d; return v.bW;
-        case SBR_PARAM_LSTM_B_ACC: *count = ng * d; return v.bWacc;
-        case SBR_PARAM_EWMA_ALPHA: *count = ng ? 0 : d; return v.alpha;
-        case SBR_PARAM_EWMA_ALPHA_ACC: *count = ng ? 0 : d; return v.alpha_acc;
-        case SBR_PARAM_ITEM_EMBEDDING_M: *count = v.Em ? I * d : 0; return v.Em;
-        case SBR_PARAM_ITEM_BIAS_M: *count = v.bm ? I : 0; return v.bm;
-        case SBR_PARAM_LSTM_W_M: *count = v.Wm ? 2 * d * ng * d : 0; return v.Wm;
-        case SBR_PARAM_LSTM_B_M: *count = v.bWm ? ng * d : 0; return v.bWm;
-        case SBR_PARAM_EWMA_ALPHA_M: *count = v.alpha_m ? d : 0; return v.alpha_m;
+        case SBR_PARAM_ITEM_EMBEDDING: p = v.E; n = I * dl; ns = I * d; sh = SHAPE_ROWS; break;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: p = v.Eacc; n = I * dl; ns = I * d; sh = SHAPE_ROWS; break;
+        case SBR_PARAM_ITEM_BIAS: p = v.b; n = ns = I; break;
+        case SBR_PARAM_ITEM_BIAS_ACC: p = v.bacc; n = ns = I; break;
+        case SBR_PARAM_LSTM_W: p = v.W; n = 2 * dl * ng * dl; ns = 2 * d * ng * d; sh = SHAPE_LSTM_W; break;
+        case SBR_PARAM_LSTM_W_ACC: p = v.Wacc; n = 2 * dl * ng * dl; ns = 2 * d * ng * d; sh = SHAPE_LSTM_W; break;
+        case SBR_PARAM_LSTM_B: p = v.bW; n = ng * dl; ns = ng * d; sh = SHAPE_LSTM_B; break;
+        case SBR_PARAM_LSTM_B_ACC: p = v.bWacc; n = ng * dl; ns = ng * d; sh = SHAPE_LSTM_B; break;
+        case SBR_PARAM_EWMA_ALPHA: p = v.alpha; n = ng ? 0 : dl; ns = ng ? 0 : d; break;
+        case SBR_PARAM_EWMA_ALPHA_ACC: p = v.alpha_acc; n = ng ? 0 : dl; ns = ng ? 0 : d; break;
+        case SBR_PARAM_ITEM_EMBEDDING_M: p = v.Em; n = v.Em ? I * dl : 0; ns = v.Em ? I * d : 0; sh = SHAPE_ROWS; break;
+        case SBR_PARAM_ITEM_BIAS_M: p = v.bm; n = ns = v.bm ? I : 0; break;
+        case SBR_PARAM_LSTM_W_M: p = v.Wm; n = v.Wm ? 2 * dl * ng * dl : 0; ns = v.Wm ? 2 * d * ng * d : 0; sh = SHAPE_LSTM_W; break;
+        case SBR_PARAM_LSTM_B_M: p = v.bWm; n = v.bWm ? ng * dl : 0; ns = v.bWm ? ng * d : 0; sh = SHAPE_LSTM_B; break;
+        case SBR_PARAM_EWMA_ALPHA_M: p = v.alpha_m; n = v.alpha_m ? dl : 0; ns = v.alpha_m ? d : 0; break;
     }
-    *count = 0;
-    return nullptr;
+    *count = n;
+    if (stored) *stored = ns;
+    if (shape) *shape = sh;
+    return p;
+}
+
+/* copy between the caller's logical array and the stored (padded) array, host side; to_stored fills the padding with 0 */
+static void param_repack(const sbr_model* m, int shape, const float* src, float* dst, bool to_stored) {
+    const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
+    auto move = [&](uint64_t logical, uint64_t stored, uint64_t n) {
+        if (to_stored) std::memcpy(dst + stored, src + logical, n * 4);
+        else std::memcpy(dst + logical, src + stored, n * 4);
+    };
+    switch (shape) {
+        case SHAPE_ROWS:
+            for (uint64_t r = 0; r < I; ++r) move(r * dl, r * d, dl);
+            break;
+        case SHAPE_LSTM_W:
+            for (uint64_t kl = 0; kl < 2 * dl; ++kl) {
+                const uint64_t k = kl < dl ? kl : d + (kl - dl);
+                for (uint64_t g = 0; g < ng; ++g) move(kl * ng * dl + g * dl, k * ng * d + g * d, dl);
+            }
+            break;
+        case SHAPE_LSTM_B:
+            for (uint64_t g = 0; g < ng; ++g) move(g * dl, g * d, dl);
+            break;
+        default:
+            move(0, 0, dl);  /* alpha */
+            break;
+    }
 }
 
 sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* out_count) {
@@ -777,23 +831,37 @@ sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* ou
 
 sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uint64_t count) {
     if (!m || !host_out) return SBR_ERR_INVALID_ARGUMENT;
-    uint64_t n = 0;
-    float* p = param_ptr(m, which, &n);
+    uint64_t n = 0, stored = 0;
+    int shape = SHAPE_FLAT;
+    float* p = param_ptr(m, which, &n, &stored, &shape);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
-    HIPCHK(hipMemcpy(host_out, p, n * 4, hipMemcpyDeviceToHost));
+    if (stored == n) {
+        HIPCHK(hipMemcpy(host_out, p, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(stored);
+        HIPCHK(hipMemcpy(tmp.data(), p, stored * 4, hipMemcpyDeviceToHost));
+        param_repack(m, shape, tmp.data(), host_out, false);
+    }
     return SBR_OK;
 }
 
 sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count) {
     if (!m || !host_in) return SBR_ERR_INVALID_ARGUMENT;
-    uint64_t n = 0;
-    float* p = param_ptr(m, which, &n);
+    uint64_t n = 0, stored = 0;
+    int shape = SHAPE_FLAT;
+    float* p = param_ptr(m, which, &n, &stored, &shape);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
-    HIPCHK(hipMemcpy(p, host_in, n * 4, hipMemcpyHostToDevice));
+    if (stored == n) {
+        HIPCHK(hipMemcpy(p, host_in, n * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(stored, 0.0f);
+        param_repack(m, shape, host_in, tmp.data(), true);
+        HIPCHK(hipMemcpy(p, tmp.data(), stored * 4, hipMemcpyHostToDevice));
+    }
     if (which == SBR_PARAM_LSTM_W) {
         sbr::launch_repack_lstm(m->mv, m->stream);
         HIPCHK(hipStreamSynchronize(m->stream));
@@ -1884,7 +1952,7 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
  * into every replica's address space. */
 sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, sbr_model** out_models) {
     if (!hp || !out_models || n == 0 || n > 16) return SBR_ERR_INVALID_ARGUMENT;
-    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0) return SBR_ERR_INVALID_ARGUMENT;
+    if (!storage_dim(hp->embedding_dim) || hp->num_items == 0) return SBR_ERR_INVALID_ARGUMENT;
     int ndevices = 0;
     if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
     for (uint32_t r = 0; r < n; ++r) out_models[r] = nullptr;
@@ -1895,7 +1963,7 @@ sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, s
     if (flags & SBR_GROUP_PARTITION_ITEM_TABLE) {
         shared = std::make_shared<SharedTable>();
         const uint64_t S = ((uint64_t)hp->num_items + n - 1) / n;
-        st = shared->create(hp->num_items, hp->embedding_dim, hp->optimizer == SBR_OPT_ADAM, devices, S);
+        st = shared->create(hp->num_items, (uint32_t)storage_dim(hp->embedding_dim), hp->optimizer == SBR_OPT_ADAM, devices, S);
     }
     for (uint32_t r = 0; r < n && st == SBR_OK; ++r) {
         sbr_hparams h = *hp;
@@ -1926,7 +1994,7 @@ sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out) {
 sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out) {
     if (!hp || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (!dim_ok(hp->embedding_dim) || hp->num_items == 0 || hp->num_devices == 0 || hp->num_devices > 16 ||
+    if (!storage_dim(hp->embedding_dim) || hp->num_items == 0 || hp->num_devices == 0 || hp->num_devices > 16 ||
         hp->device_rank >= hp->num_devices)
         return SBR_ERR_INVALID_ARGUMENT;
     /* a partitioned table is updated in place by its owners after a rendezvous: no staleness-one pipeline */
@@ -1937,7 +2005,7 @@ sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out) 
     auto shared = std::make_shared<SharedTable>();
     shared->local_rank = (int)hp->device_rank;
     const uint64_t S = ((uint64_t)hp->num_items + hp->num_devices - 1) / hp->num_devices;
-    SBRCHK(shared->plan(hp->num_items, hp->embedding_dim, hp->optimizer == SBR_OPT_ADAM, (int)hp->num_devices, S, device));
+    SBRCHK(shared->plan(hp->num_items, (uint32_t)storage_dim(hp->embedding_dim), hp->optimizer == SBR_OPT_ADAM, (int)hp->num_devices, S, device));
     std::vector<int> device_of_rank(hp->num_devices, device); /* only this rank's entry is used */
     SBRCHK(shared->create_parts(device_of_rank));
     return model_create_impl(hp, shared, TABLE_OWN_ROWS_DEFERRED, nullptr, out);
@@ -2099,7 +2167,7 @@ sbr_status sbr_user_representation(sbr_model* m, const uint32_t* item_ids, uint6
     float* H = nullptr;
     std::vector<int> rep_row;
     SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
-    hipError_t e = hipMemcpy(out_dim, H + (size_t)rep_row[0] * m->d, (size_t)m->d * 4, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpy(out_dim, H + (size_t)rep_row[0] * m->d, (size_t)m->dl * 4, hipMemcpyDeviceToHost);
     hipFree(H);
     return e == hipSuccess ? SBR_OK : SBR_ERR_HIP;
 }
@@ -2115,7 +2183,8 @@ sbr_status sbr_predict(sbr_model* m, const float* user_dim, const uint32_t* item
     uint32_t* d_items = nullptr;
     sbr_status st = SBR_OK;
     if ((st = dmalloc(&d_user, m->d)) == SBR_OK && (st = dmalloc(&d_items, n)) == SBR_OK && (st = dmalloc(&d_out, n)) == SBR_OK) {
-        hipMemcpy(d_user, user_dim, (size_t)m->d * 4, hipMemcpyHostToDevice);
+        hipMemset(d_user, 0, (size_t)m->d * 4);
+        hipMemcpy(d_user, user_dim, (size_t)m->dl * 4, hipMemcpyHostToDevice);
         hipMemcpy(d_items, item_ids, n * 4, hipMemcpyHostToDevice);
         sbr::launch_predict(m->mv, d_user, d_items, n, d_out, m->stream);
         if (hipStreamSynchronize(m->stream) != hipSuccess || hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) != hipSuccess)

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._abi import NUM_KERNEL_FAMILIES, KernelFamily, SbrHparams, Status
+from ._abi import NUM_KERNEL_FAMILIES, KernelFamily, SbrHparams, Status, storage_dim
 from .errors import EngineError, FittingError, PredictionError
 
 
@@ -156,7 +156,7 @@ class FitPlan:
         return ent.value, uniq.value
 
     def debug_fetch(self, which: int, rows: int) -> np.ndarray:
-        d = self.model.dim
+        d = self.model.storage_dim
         which = int(which)
         if which in (0, 4, 5):
             out = np.zeros((rows, d), dtype=np.float32)
@@ -187,8 +187,9 @@ class Model:
         self.hp = hp
         self.dim = int(hp.embedding_dim)
         h = C.c_void_p()
-        _check(self._L.sbr_model_create(C.byref(hp), C.byref(h)))
+        _check(self._L.sbr_model_create(C.byref(hp), C.byref(h)))  # rejects an embedding_dim outside 1..256
         self._h = h
+        self.storage_dim = storage_dim(self.dim)
 
     @classmethod
     def _from_handle(cls, hp: SbrHparams, handle) -> "Model":
@@ -196,6 +197,7 @@ class Model:
         m._L = _lib.load()
         m.hp = hp
         m.dim = int(hp.embedding_dim)
+        m.storage_dim = storage_dim(m.dim)
         m._h = handle
         return m
 
@@ -205,7 +207,7 @@ class Model:
         return bool(v.value)
 
     def dense_count(self) -> int:
-        d = self.dim
+        d = self.storage_dim
         ng = {0: 4, 1: 3, 2: 0}[int(self.hp.model)]
         return (2 * d + 1) * ng * d if ng else d
 

@@ -251,6 +251,41 @@ def test_lagged_loss_figure(oracle_lib):
     assert plan.end_lagged() < true_loss
 
 
+@pytest.mark.parametrize("kind,loss,d,opt", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 24, 0),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 40, 1),
+    (ModelKind.EWMA, LOSS_HINGE, 100, 0),
+    (ModelKind.EWMA, LOSS_WARP, 5, 1),
+])
+def test_any_embedding_dim_is_a_zero_padded_model(oracle_lib, kind, loss, d, opt):
+    """embedding_dim is any usize in the reference (lstm.rs:86-89).  Widths other than 16 .. 256 in powers of two are
+    defined as the next width up with zero padding; the padding is a fixed point of training, parameters keep the
+    caller's shapes, and the init stream draws embedding_dim values per row with std 1 / embedding_dim."""
+    items, T = 90, 10
+    ptr, it = synthetic_interactions(40, items, T + 3, seed=5, zipf=True)
+    m = OracleModel(hparams(items, T, d, int(kind), loss, B=4, epochs=3, opt=opt))
+    ng = {ModelKind.LSTM_NORMAL: 4, ModelKind.LSTM_COUPLED: 3, ModelKind.EWMA: 0}[kind]
+    assert m.param_count(Param.ITEM_EMBEDDING) == items * d
+    assert m.param_count(Param.LSTM_W) == 2 * d * ng * d
+    E0 = m.get_param(Param.ITEM_EMBEDDING).reshape(items, d)
+    assert abs(float(E0.std()) * d - 1.0) < 0.15 and np.all(E0 != 0.0)
+    loss_value = m.fit(ptr, it)
+    assert np.isfinite(loss_value) and m.padding_is_zero()
+    assert not np.array_equal(m.get_param(Param.ITEM_EMBEDDING).reshape(items, d), E0)
+    u = m.user_representation(np.array([1, 2, 3], dtype=np.uint32))
+    assert u.shape == (d,) and np.all(np.isfinite(u))
+    assert m.predict(u, np.arange(items, dtype=np.uint32)).shape == (items,)
+    mrr, ranks = m.mrr_score(ptr, it)
+    assert 0.0 < mrr <= 1.0
+    # the first embedding_dim draws of the stream do not depend on the storage width: a 16-wide and a 5-wide model
+    # with the same seed start with the same normal stream scaled by their own 1 / embedding_dim
+    if d == 5:
+        wide = OracleModel(hparams(items, T, 16, int(kind), loss, B=4))
+        a = wide.get_param(Param.ITEM_EMBEDDING)[:5].astype(np.float64) * 16.0
+        b = E0.ravel()[:5].astype(np.float64) * 5.0
+        assert np.allclose(a, b, rtol=1e-6)
+
+
 def test_mrr_masks_all_history_and_counts_ties(oracle_lib):
     """evaluation.rs:30-41 on a hand-checkable model: zero embeddings => score = bias."""
     m = OracleModel(hparams(6, 4, 16, int(ModelKind.EWMA), LOSS_HINGE))

@@ -50,7 +50,7 @@ def make_pair(hp):
 
 
 @pytest.mark.parametrize("kind", [ModelKind.EWMA, ModelKind.LSTM_NORMAL, ModelKind.LSTM_COUPLED])
-@pytest.mark.parametrize("d", [16, 32, 128])
+@pytest.mark.parametrize("d", [16, 32, 128, 24, 100])
 def test_init_matches(kind, d):
     hp = hparams(97, 12, d, int(kind), LOSS_HINGE, B=4)
     g, o = make_pair(hp)
@@ -71,6 +71,11 @@ CASES = [
     (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 80, 30, 8, 3),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, 90, 30, 10, 16),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 256, 100, 20, 6, 5),
+    # embedding_dim that is not one of the kernels' widths: stored in the next width up, extra columns zero
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 48, 150, 45, 14, 9),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 100, 90, 30, 10, 16),
+    (ModelKind.EWMA, LOSS_WARP, 24, 200, 60, 20, 8),
+    (ModelKind.EWMA, LOSS_BPR, 200, 120, 25, 10, 7),
 ]
 
 
@@ -536,9 +541,44 @@ def test_non_finite_prediction_error():
     assert np.all(np.isfinite(g.predict(u, np.array([0, 1, 2], dtype=np.uint32))))
 
 
+@pytest.mark.parametrize("kind,loss,d,opt", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 48, 0),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 20, 1),
+    (ModelKind.EWMA, LOSS_HINGE, 100, 0),
+    (ModelKind.EWMA, LOSS_WARP, 7, 1),
+])
+def test_any_embedding_dim_fit_predict_mrr(kind, loss, d, opt):
+    """The reference's builder takes any embedding_dim (lstm.rs:86-89).  Other widths than 16..256 in powers of two
+    are stored zero-padded; parameters, representations and predictions keep the caller's width, the fit equals the
+    oracle's bit for bit, and the padding is still zero afterwards (the fixed point the definition rests on)."""
+    items, T = 130, 12
+    ptr, it = synthetic_interactions(50, items, T + 4, seed=23, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, B=8, epochs=3, opt=opt)
+    g, o = make_pair(hp)
+    assert g.param_count(Param.ITEM_EMBEDDING) == items * d
+    lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    assert_params_equal(g, o, kind, "after fit")
+    assert o.padding_is_zero()
+    hist = np.array([3, 5, 8, 13], dtype=np.uint32)
+    ug, uo = g.user_representation(hist), o.user_representation(hist)
+    assert ug.shape == (d,)
+    assert_same_bits(ug, uo, "user representation")
+    ids = np.arange(items, dtype=np.uint32)
+    assert_same_bits(g.predict(ug, ids), o.predict(uo, ids), "predict")
+    mg, rg = g.mrr_score(ptr, it)
+    mo, ro = o.mrr_score(ptr, it)
+    assert np.array_equal(rg, ro) and mg == mo
+    # set_param round trip in the caller's shapes
+    E = g.get_param(Param.ITEM_EMBEDDING)
+    g.set_param(Param.ITEM_EMBEDDING, E)
+    assert_same_bits(g.get_param(Param.ITEM_EMBEDDING), E, "E round trip")
+
+
 def test_invalid_arguments():
-    with pytest.raises(EngineError):
-        Model(hparams(10, 8, 24, int(ModelKind.EWMA), LOSS_HINGE))  # unsupported dim
+    for bad_dim in (0, 257):
+        with pytest.raises(EngineError):
+            Model(hparams(10, 8, bad_dim, int(ModelKind.EWMA), LOSS_HINGE))  # embedding_dim 1..256
     g = Model(hparams(10, 8, 16, int(ModelKind.EWMA), LOSS_HINGE))
     with pytest.raises(EngineError):
         g.predict(np.zeros(16, np.float32), np.array([10], dtype=np.uint32))  # item id out of range

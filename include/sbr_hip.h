@@ -173,6 +173,12 @@ sbr_status sbr_fit_step_owner_reduce(sbr_fit_plan* p, const void* device_recv, v
  * of step k+1. */
 sbr_status sbr_fit_step_owner_reduce_on(sbr_fit_plan* p, const void* device_recv, void* device_own_chunk, void* hip_stream);
 sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, const void* device_dense_all);
+/* sbr_fit_step_apply_table in two halves: the item-table rows (needs only the gathered chunks, so it can be enqueued
+ * while the dense-gradient GEMM is still running on the engine's side stream), then the dense parameters (after
+ * sbr_fit_step_dense has joined that GEMM and the dense blocks have been gathered).  Rows first — it opens the
+ * optimiser step —, dense second, once each per step; same bits as the one-call form. */
+sbr_status sbr_fit_step_apply_rows(sbr_fit_plan* p, const void* device_table);
+sbr_status sbr_fit_step_apply_dense(sbr_fit_plan* p, const void* device_dense_all);
 
 /* The same multi-device fit driven from ONE process (≙ fit with num_threads(n) on one host,
  * sequence_model.rs:90-102): models[r] was created with num_devices = n, device_rank = r, the same

@@ -564,7 +564,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 4; }
+uint32_t sbr_abi_version(void) { return 5; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -1421,11 +1421,11 @@ sbr_status sbr_fit_step_owner_reduce_on(sbr_fit_plan* p, const void* device_recv
 
 /* the part of an exchanged step that every device applies identically: step counter, loss header,
  * dense parameters (device-order sum of the gathered dense blocks) */
-static sbr_status apply_dense_blocks(sbr_fit_plan* p, const void* device_dense_all) {
+static sbr_status apply_dense_blocks(sbr_fit_plan* p, const void* device_dense_all, bool begins_step = true) {
     sbr_model* m = p->m;
     const uint64_t db = (8 + dense_count(m)) * 4;
     const uint8_t* dall = reinterpret_cast<const uint8_t*>(device_dense_all);
-    begin_optimizer_step(m);
+    if (begins_step) begin_optimizer_step(m);
     sbr::launch_accumulate_loss(dall, db, p->ndev, p->loss_acc, p->ex_acc, m->stream);
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
@@ -1444,6 +1444,32 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         sbr::launch_table_apply(m->mv, contiguous_chunks(p, device_table), slice_rows(p), m->stream);
     }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* sbr_fit_step_apply_table in two halves, so that the item-table half does not have to wait for the dense-gradient
+ * GEMM: rows first (it opens the optimiser step), dense second, once each per step. */
+sbr_status sbr_fit_step_apply_rows(sbr_fit_plan* p, const void* device_table) {
+    if (!p || !device_table) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    if (m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    begin_optimizer_step(m);
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_table_apply(m->mv, contiguous_chunks(p, device_table), slice_rows(p), m->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_step_apply_dense(sbr_fit_plan* p, const void* device_dense_all) {
+    if (!p || !device_dense_all) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    if (m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    SBRCHK(apply_dense_blocks(p, device_dense_all, /*begins_step=*/false));
     HIPCHK(hipGetLastError());
     return SBR_OK;
 }

@@ -42,6 +42,7 @@ class StepBackend(Protocol):
     def dense(self): ...                                           # -> dense block [dense_bytes]
     def owner_reduce(self, recv): ...                              # -> own chunk [chunk]
     def apply_table(self, table, dense_all) -> None: ...
+    # optional: apply_rows(table) + apply_dense(dense_all) = apply_table in two halves (rows first)
     def buffers(self, world: int): ...                             # -> (recv, table, dense_all)
     def end(self): ...                                             # -> (loss, examples)
 
@@ -58,12 +59,20 @@ def exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=
         # the production transport and keeps everything on the device.
         _staged_exchange(backend, dist, group, send, recv, table, dense_all)
         return
+    # the dense-gradient GEMM (the engine's side stream) runs beside the whole sparse exchange — scatter, all-to-all,
+    # owner reduction and the all-gather of the reduced chunks are all enqueued before dense() joins it
     dist.all_to_all_single(recv, send, group=group)
     own = backend.owner_reduce(recv)
-    dense = backend.dense()  # joins the dense-gradient GEMM, which ran beside the all-to-all
     dist.all_gather_into_tensor(table, own, group=group)
+    apply_rows = getattr(backend, "apply_rows", None)
+    if apply_rows is not None:
+        apply_rows(table)  # the item-table update does not need the dense gradient either
+    dense = backend.dense()
     dist.all_gather_into_tensor(dense_all, dense, group=group)
-    backend.apply_table(table, dense_all)
+    if apply_rows is not None:
+        backend.apply_dense(dense_all)
+    else:
+        backend.apply_table(table, dense_all)
 
 
 def _staged_exchange(backend, dist, group, send, recv, table, dense_all, dense=None) -> None:
@@ -227,6 +236,12 @@ class HipBackend:
 
     def apply_table(self, table, dense_all) -> None:
         self.plan.step_apply_table(table.data_ptr(), dense_all.data_ptr())
+
+    def apply_rows(self, table) -> None:
+        self.plan.step_apply_rows(table.data_ptr())
+
+    def apply_dense(self, dense_all) -> None:
+        self.plan.step_apply_dense(dense_all.data_ptr())
 
     def buffers(self, world: int):
         t = self.torch

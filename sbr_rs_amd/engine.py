@@ -139,6 +139,13 @@ class FitPlan:
     def step_apply_table(self, table_ptr: int, dense_all_ptr: int):
         _check(self._L.sbr_fit_step_apply_table(self._h, C.c_void_p(table_ptr), C.c_void_p(dense_all_ptr)))
 
+    def step_apply_rows(self, table_ptr: int):
+        """Item-table half of step_apply_table (opens the optimiser step; does not wait for the dense-gradient GEMM)."""
+        _check(self._L.sbr_fit_step_apply_rows(self._h, C.c_void_p(table_ptr)))
+
+    def step_apply_dense(self, dense_all_ptr: int):
+        _check(self._L.sbr_fit_step_apply_dense(self._h, C.c_void_p(dense_all_ptr)))
+
     def end(self):
         loss, ex = C.c_float(), C.c_uint64()
         _check(self._L.sbr_fit_end(self._h, C.byref(loss), C.byref(ex)))

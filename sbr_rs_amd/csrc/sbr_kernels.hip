@@ -51,6 +51,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_BWD_RT4_MIN_TILES
 #define SBR_BWD_RT4_MIN_TILES 1100
 #endif
+#ifndef SBR_BWD256_MIN_TILES
+#define SBR_BWD256_MIN_TILES 320
+#endif
 #ifndef SBR_FWD_UPW
 #define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
 #endif
@@ -2372,6 +2375,9 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         });
         return;
     }
+    /* d = 256 keeps the per-step launches here: 16 unit tiles x 32-row tiles fill the chip at every step, and the
+     * resident form would stream the 2 MiB of weights per 32 rows (measured 8.3 vs 7.9 ms at 20 000 sequences); the
+     * BPTT kernel below does take the resident form at d = 256 (7.3 vs 9.3 ms) */
     if (m.d <= 128 && tm_host <= SBR_MAX_T) { /* sequence-resident kernel: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
@@ -2455,13 +2461,20 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         return;
     }
     bool stepwise = true;
-    if (m.d <= 128 && tm_host <= SBR_MAX_T) { /* sequence-resident BPTT: one launch for all time steps */
+    /* d = 256: 16 waves per workgroup leave 128 registers per wave, i.e. only the 32-sequence form, one workgroup per CU;
+     * its time has a floor of ~4.8 ms (the longest tile's 63 dependent steps), so below ~320 tiles the per-step launches
+     * are faster (ms resident / per-step at 8 192, 12 288, 16 384, 20 000 sequences: 4.84 / 4.32, 4.83 / 5.74, 5.27 / 6.92,
+     * 7.0 / 9.3) */
+    const char* min_tiles_env = std::getenv("SBR_BWD256_MIN_TILES"); /* tests force either form */
+    const int min_tiles_256 = min_tiles_env ? std::atoi(min_tiles_env) : SBR_BWD256_MIN_TILES;
+    const bool resident = m.d <= 128 || (m.d == 256 && (b_host + 31) / 32 >= min_tiles_256);
+    if (resident && tm_host <= SBR_MAX_T) { /* sequence-resident BPTT: one launch for all time steps */
         DISPATCH_D(m.d, {
-            if constexpr (DD <= 128) {
+            if constexpr (DD <= 256) {
                 static const int rt_env = std::getenv("SBR_SEQ_RT") ? std::atoi(std::getenv("SBR_SEQ_RT")) : 0;
                 const bool big = rt_env ? rt_env >= 4 : (b_host + 63) / 64 >= SBR_BWD_RT4_MIN_TILES;
                 bool launched = false;
-                if constexpr (DD >= 64) {
+                if constexpr (DD >= 64 && DD <= 128) {  /* d = 256: 16 waves per workgroup leave 128 registers per wave */
                     if (big) { /* 64-sequence tiles, one workgroup per CU (see launch_recurrent_forward) */
                         const int ntiles = (b_host + 63) / 64;
                         if (m.ng == 4)

@@ -107,6 +107,28 @@ def test_one_minibatch_intermediates(kind, loss, d, items, users, T, B):
         assert_params_equal(g, o, kind, f"after mb{mb}")
 
 
+@pytest.mark.parametrize("kind,loss", [(ModelKind.LSTM_NORMAL, LOSS_WARP), (ModelKind.LSTM_COUPLED, LOSS_HINGE)])
+@pytest.mark.parametrize("min_tiles", ["1", "1000000"])
+def test_d256_bptt_both_forms(monkeypatch, kind, loss, min_tiles):
+    """d = 256 BPTT: the sequence-resident kernel (large minibatches) and the per-step launches (small ones) give
+    the oracle's bits; SBR_BWD256_MIN_TILES forces one or the other."""
+    monkeypatch.setenv("SBR_BWD256_MIN_TILES", min_tiles)
+    items, T, B = 120, 9, 70  # three 32-sequence tiles, the last one ragged
+    ptr, it = synthetic_interactions(90, items, T + 3, seed=17, zipf=True)
+    hp = hparams(items, T, 256, int(kind), loss, B=B, lr=0.05)
+    g, o = make_pair(hp)
+    pg, po = g.fit_begin(ptr, it), o.fit_begin(ptr, it)
+    assert pg.epoch_prepare() == po.epoch_prepare()
+    R = po.minibatch_rows(0)
+    pg.step_local(0)
+    po.step_local(0)
+    for which in (Debug.HIDDEN, Debug.COEF, Debug.DINPUT, Debug.DENSE_GRAD):
+        assert_same_bits(pg.debug_fetch(which, R), po.debug_fetch(which, R), f"{which.name}")
+    pg.step_apply(0)
+    po.step_apply(_export(po))
+    assert_params_equal(g, o, kind, "after the step")
+
+
 def test_warp_retry_loop_all_trip_counts():
     """sample_warp_negative (sequence_model.rs:47-68): every trip count 1..5 occurs, including
     rows where no candidate violates and the 5th draw is used anyway."""

@@ -31,6 +31,7 @@
 namespace sbr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define EWMA_CHUNK_SEQS 256
@@ -57,6 +58,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_FWD_UPW
 #define SBR_FWD_UPW 1  /* 16-unit tiles per wave */
 #endif
+
+// word 3 of a raw buffer resource on gfx9-class targets (32-bit data format, no swizzle)
+#define SBR_BUFFER_RSRC_FLAGS 0x00020000
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -656,14 +660,18 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
     // of the step, with the cell epilogue and a barrier to land under.
     constexpr int PF = NS < 4 ? NS : (RT >= 4 ? 4 : 2);
     f32x4 ring[PF][UPW][NG];
+    // Weight fragments come through a buffer resource: the address is {resource (scalar registers), one per-lane
+    // byte offset that never changes, a scalar offset for (wave, gate, k-block)} — the request costs no vector ALU
+    // work.  (As a global load with a 64-bit per-lane address it was 14 VALU instructions per k-block, on the
+    // pipe the MFMAs run on.)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Wp, (short)0, K2 * NG * D * 4, SBR_BUFFER_RSRC_FLAGS);
+    const uint32_t lane_byte = (uint32_t)(tid0 & 63) * 16u;
     auto load_b = [&](f32x4 (*dst)[NG], int S) {
-        const float* wbase = launder(m.Wp) + (size_t)(wv * UPW * NG) * NS * 256;
-        const uint32_t lane_off = (uint32_t)(thread_id() & 63) * 4u;
 #pragma unroll
         for (int p = 0; p < UPW; ++p)
 #pragma unroll
             for (int g = 0; g < NG; ++g)
-                dst[p][g] = *reinterpret_cast<const f32x4*>(wbase + (uint32_t)(((p * NG + g) * NS + S) * 256) + lane_off);
+                dst[p][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_byte, ((((wv * UPW + p) * NG + g) * NS + S) * 1024), 0));
     };
 #pragma unroll
     for (int j = 0; j < PF; ++j) load_b(ring[j], j);
@@ -680,10 +688,18 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
     // x of the step (row_begin, nrows) describe goes from registers into LDS and into X (the copy of the
     // gathered input rows that the dense-gradient GEMM streams instead of re-gathering E, which lets that GEMM
     // run concurrently with the sparse update of E)
+    // Stores of a step go through buffer resources that span exactly the tile's live rows of that step: base =
+    // first row of the tile, num_records = live rows x row bytes.  Lanes of finished sequences fall outside the
+    // range and the hardware drops their stores — branch-free without dump rows, and the address is {resource, an
+    // invariant per-lane byte offset, a scalar / immediate offset}: no per-store vector ALU work (64-bit per-lane
+    // addresses and live/dump selects were a fifth of the epilogue's VALU instructions).
+    auto row_rsrc = [&](float* base, int row_floats, int first_row, int live_rows) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)first_row * row_floats), (short)0, live_rows * row_floats * 4,
+                                                 SBR_BUFFER_RSRC_FLAGS);
+    };
     auto stage = [&]() {
         tid = thread_id();
-        float* X = launder(w.X);
-        float* dump = launder(w.G) + (size_t)dump_row0 * 4 * D;
+        const __amdgpu_buffer_rsrc_t rsX = row_rsrc(w.X, D, row_begin + b0, nrows);
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int idx = tid + it * NT;
@@ -693,8 +709,8 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 float2* dst = reinterpret_cast<float2*>(&As[i * LDA + c4]);
                 dst[0] = make_float2(xn[it].x, xn[it].y);
                 dst[1] = make_float2(xn[it].z, xn[it].w);
-                float* dst_x = i < nrows ? X + ((size_t)(row_begin + b0 + i) * D + c4) : dump + (i * 4 * D + c4);
-                st4(dst_x, xn[it]);
+                // row i, columns c4 .. c4+3 of the tile's rows = byte idx * 16
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, 0);
             }
         }
     };
@@ -786,9 +802,11 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
         j16 = lane & 15;
         kq = lane >> 4;
         {
-            float* Gb = launder(w.G);
-            float* Cb = launder(w.C);
-            float* Hb = launder(H);
+            const __amdgpu_buffer_rsrc_t rsG = row_rsrc(w.G, 4 * D, row_begin + b0, nrows);
+            const __amdgpu_buffer_rsrc_t rsC = row_rsrc(w.C, D, row_begin + b0, nrows);
+            const __amdgpu_buffer_rsrc_t rsH = row_rsrc(H, D, row_begin + b0, nrows);
+            const int vG = (kq * 4 * 4 * D + wv * UPW * 16 + j16) * 4;  // byte offsets of (row kq*4, unit wv*UPW*16 + j16)
+            const int vC = (kq * 4 * D + wv * UPW * 16 + j16) * 4;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -814,16 +832,16 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                         for (int e = 0; e < 2; ++e) {
                             const int reg = rp + e;
                             const int i = rt * 16 + kq * 4 + reg;
-                            // branch-free stores: the lanes of finished sequences write to the dump rows behind G
-                            const bool live = i < nrows;
-                            const size_t r = (size_t)(row_begin + b0 + i);
                             const float gi = gi2[e], gf = gf2[e], gg = gg2[e], go = go2[e], cc = cc2[e], hh = hh2[e];
                             cst[rt][p][reg] = cc;
-                            float* dumprow = Gb + ((size_t)(dump_row0 + i) * 4 * D + u);
-                            float* G = live ? Gb + (r * 4 * D + u) : dumprow;
-                            G[0] = gi; G[D] = gf; G[2 * D] = gg; G[3 * D] = go;
-                            *(live ? Cb + (r * D + u) : dumprow) = cc;
-                            *(live ? Hb + (r * D + u) : dumprow) = hh;
+                            // row i = rt*16 + kq*4 + reg: (rt, reg, p) go into the scalar offset, the gate into the immediate
+                            const int sG = ((rt * 16 + reg) * 4 * D + p * 16) * 4, sC = ((rt * 16 + reg) * D + p * 16) * 4;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hh), rsH, vC, sC, 0);
                             As[i * LDA + D + u] = hh;
                         }
                         // 128-register form: one cell pair at a time (interleaving the pairs for instruction-level parallelism
@@ -1075,22 +1093,26 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
     float4 pg[CITER][4], pc[CITER], pcp[CITER], pen[CITER], pep[CITER];
     float pcoef[CITER];
     uint32_t nidx[CITER], oidx[CITER];
-    // packed row of item k at step t; lanes of finished sequences are sent to the tile's first row (valid memory)
-    auto item_row = [&](int tid, int k, int rb, int nr) {
-        const int i = (tid + k * NT) / Q;
-        return (size_t)(rb + b0 + (i < nr ? i : 0));
+    // Row-addressed arrays are read and written through buffer resources that span the tile's live rows of the step
+    // (base = first row, num_records = live rows x row bytes): reads of finished sequences' lanes return 0, their
+    // stores are dropped, and the address is {resource, invariant per-lane byte offset, scalar / immediate offset} —
+    // no per-access vector ALU work (see the forward kernel).
+    auto row_rsrc = [&](const void* base, int row_bytes, int first_row, int live_rows) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + (size_t)first_row * row_bytes), (short)0,
+                                                 live_rows * row_bytes, SBR_BUFFER_RSRC_FLAGS);
     };
-    auto request_ids = [&](int t) {  // negatives / targets of step t
+    // item k of this thread = (row i, units u .. u+3) with idx = tid + k*NT, i = idx / Q, u = (idx % Q) * 4
+    static_assert(NT % Q == 0, "item k of a thread is NT / Q rows below item 0, same units");
+    auto request_ids = [&](int t) {  // negatives / targets of step t (0 for finished sequences: a valid row of E)
         const int tid = thread_id();
         int rb, nr;
         step_rows(t, &rb, &nr);
-        const uint32_t* neg = launder(blk.neg);
-        const uint32_t* out = launder(blk.out_idx);
+        const __amdgpu_buffer_rsrc_t rsN = row_rsrc(blk.neg, 4, rb + b0, nr), rsO = row_rsrc(blk.out_idx, 4, rb + b0, nr);
+        const int vo = (tid / Q) * 4;  // item 0's row; item k is NT / Q rows further
 #pragma unroll
         for (int k = 0; k < CITER; ++k) {
-            const size_t r = item_row(tid, k, rb, nr);
-            nidx[k] = neg[r];
-            oidx[k] = out[r];
+            nidx[k] = __builtin_amdgcn_raw_buffer_load_b32(rsN, vo, k * (NT / Q) * 4, 0);
+            oidx[k] = __builtin_amdgcn_raw_buffer_load_b32(rsO, vo, k * (NT / Q) * 4, 0);
         }
     };
     auto request_gathers = [&](int t) {  // E[neg], E[target], coef of step t (ids requested a step earlier)
@@ -1098,13 +1120,13 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         int rb, nr;
         step_rows(t, &rb, &nr);
         const float* E = launder(m.E);
-        const float* coef = launder(blk.coef);
+        const __amdgpu_buffer_rsrc_t rsK = row_rsrc(blk.coef, 4, rb + b0, nr);
 #pragma unroll
         for (int k = 0; k < CITER; ++k) {
             const int u = ((tid + k * NT) % Q) * 4;
             pen[k] = ld4(E + ((size_t)nidx[k] * D + u));
             pep[k] = ld4(E + ((size_t)oidx[k] * D + u));
-            pcoef[k] = coef[item_row(tid, k, rb, nr)];
+            pcoef[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsK, (tid / Q) * 4, k * (NT / Q) * 4, 0));
         }
     };
     // cell state rows: the cell phase of step t needs c_t (pc) and c_{t-1} (pcp); c_{t-1} is step t-1's c_t, so one
@@ -1113,32 +1135,33 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         const int tid = thread_id();
         int rb, nr_live;
         step_rows(t, &rb, &nr_live);
-        const float* C = launder(w.C);
+        const __amdgpu_buffer_rsrc_t rsC = row_rsrc(w.C, D * 4, rb + b0, nr_live);
 #pragma unroll
-        for (int k = 0; k < CITER; ++k) {
-            const int u = ((tid + k * NT) % Q) * 4;
-            dst[k] = ld4(C + (item_row(tid, k, rb, nr_live) * D + u));
-        }
+        for (int k = 0; k < CITER; ++k)  // row i, units u..u+3 of a D-wide row = byte idx * 16
+            dst[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, tid * 16, k * NT * 16, 0));
     };
     auto request_gates = [&](int t) {  // gate values of step t
         const int tid = thread_id();
         int rb, nr;
         step_rows(t, &rb, &nr);
-        const float* G = launder(w.G);
+        const __amdgpu_buffer_rsrc_t rsG = row_rsrc(w.G, 4 * D * 4, rb + b0, nr);
+        const int vg = (tid / Q) * (4 * D * 4) + (tid % Q) * 16;  // item 0; item k is k * NT / Q rows further (NT is a multiple of Q)
 #pragma unroll
         for (int k = 0; k < CITER; ++k) {
-            const int u = ((tid + k * NT) % Q) * 4;
-            const float* g = G + (item_row(tid, k, rb, nr) * 4 * D + u);
-            pg[k][0] = ld4(g); pg[k][1] = ld4(g + D); pg[k][2] = ld4(g + 2 * D); pg[k][3] = ld4(g + 3 * D);
+            const int so = k * (NT / Q) * (4 * D * 4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pg[k][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vg + g * D * 4, so, 0));
         }
     };
 
     f32x4 ring0[PF], ring1[PF];
+    // buffer resource + invariant per-lane byte offset + scalar offset: no vector ALU work per request (see the forward kernel)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.WTp, (short)0, 2 * D * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
+    const uint32_t lane_byte = (uint32_t)(tid0 & 63) * 16u;
     auto load_ring = [&](int slot, int S) {
-        const float* wt = launder(m.WTp);
-        const uint32_t lane_off = (uint32_t)(thread_id() & 63) * 4u;
-        ring0[slot] = *reinterpret_cast<const f32x4*>(wt + (size_t)wv * NSZ * 256 + (uint32_t)(S * 256) + lane_off);
-        ring1[slot] = *reinterpret_cast<const f32x4*>(wt + (size_t)(UT + wv) * NSZ * 256 + (uint32_t)(S * 256) + lane_off);
+        ring0[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_byte, (wv * NSZ + S) * 1024, 0));
+        ring1[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane_byte, ((UT + wv) * NSZ + S) * 1024, 0));
     };
     // ---- prologue: everything step ts = nsteps-1 needs
     const int ts = nsteps - 1;
@@ -1168,13 +1191,13 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         // (a) cell backward
         {
             const int tid = thread_id();
-            float* dZ = launder(w.dZ);
+            const __amdgpu_buffer_rsrc_t rsZ = row_rsrc(w.dZ, NGD * 4, row_begin + b0, nrows);
+            const int vz = (tid / Q) * (NGD * 4) + (tid % Q) * 16;
 #pragma unroll
             for (int k = 0; k < CITER; ++k) {
                 const int idx = tid + k * NT;
                 const int i = idx / Q;
                 const int u = (idx % Q) * 4;
-                const bool live = i < nrows;
                 const bool carried = i < nrows_above;  // the sequence has a step t+1: recurrent dh and dc exist
                 const float2 r01 = *reinterpret_cast<const float2*>(&Zs[i * LDZ + u]);
                 const float2 r23 = *reinterpret_cast<const float2*>(&Zs[i * LDZ + u + 2]);
@@ -1197,11 +1220,11 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
                                       &dz[0][j], &dz[1][j], &dz[2][j], &dz[3][j], &dco);
                     dc[k][j] = dco;
                 }
-                float* dzrow = live ? dZ + (size_t)(row_begin + b0 + i) * NGD : dZ + (size_t)(w.dz_dump_row0 + i) * NGD;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int src = NG == 4 ? g : g + 1;
-                    st4(dzrow + g * D + u, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3]));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3])), rsZ,
+                                                           vz + g * D * 4, k * (NT / Q) * (NGD * 4), 0);
                     float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + g * D + u]);
                     dst[0] = make_float2(dz[src][0], dz[src][1]);
                     dst[1] = make_float2(dz[src][2], dz[src][3]);
@@ -1278,15 +1301,15 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         BPROF(5)
         // epilogue: dX to HBM (branch-free), recurrent dh into columns [0, D) of the tile
         {
-            float* dX = launder(blk.dX);
-            float* dump = launder(w.dZ) + (size_t)w.dz_dump_row0 * NGD;
+            const __amdgpu_buffer_rsrc_t rsX = row_rsrc(blk.dX, D * 4, row_begin + b0, nrows);
+            const int vx = (kq * 4 * D + wv * 16 + c16) * 4;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int i = rt * 16 + kq * 4 + reg;
-                    float* dst = i < nrows ? dX + ((size_t)(row_begin + b0 + i) * D + wv * 16 + c16) : dump + (i * NGD + wv * 16 + c16);
-                    *dst = acc[0][rt][reg];
+                    const float dx = acc[0][rt][reg];  // (a bit_cast applied directly to the vector element reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dx), rsX, vx, (rt * 16 + reg) * D * 4, 0);
                     Zs[i * LDZ + wv * 16 + c16] = acc[1][rt][reg];
                 }
         }

@@ -1489,7 +1489,30 @@ __global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView m
     const int jcol = tj * 128 + c4;
     const bool xpart = kcol < D;  // this thread's k columns are input (x) columns; otherwise previous-hidden columns
     float4 xr[4], zr[4];
+    // Slab fetches through buffer resources (scalar base, invariant per-lane byte offset, scalar slab offset): dZ and X
+    // rows of the chunk are contiguous; the previous-hidden rows are addressed by prev_row x row bytes, and a first-step
+    // row (prev_row = -1) becomes an out-of-range offset, which reads as zeros.  Needs a 128-column tile to lie entirely
+    // in the x or in the h half (D >= 128) and H below 4 GiB; otherwise the 64-bit per-lane addresses below.
+    const bool small_h = (size_t)mb.R * D * 4 < ((size_t)1 << 32);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(w.dZ + (size_t)r0 * NGD), (short)0, SBR_DW_CHUNK_ROWS * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
+    const int xrows = mb.R - r0 < SBR_DW_CHUNK_ROWS ? mb.R - r0 : SBR_DW_CHUNK_ROWS;
+    const __amdgpu_buffer_rsrc_t rsXc = __builtin_amdgcn_make_buffer_rsrc((void*)(w.X + (size_t)r0 * D), (short)0, xrows * D * 4, SBR_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)blk.H, (short)0, small_h ? (int)((size_t)mb.R * D * 4) : 0, SBR_BUFFER_RSRC_FLAGS);
     auto fetch = [&](int slab) {
+        if (D >= 128 && small_h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lr = slab * SLAB + srow + 8 * i;
+                if (tk * 128 < D) {  // x columns (uniform per workgroup); rows past R are out of range and read as zeros: they meet zeros in dZ
+                    xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsXc, (srow * D + kcol) * 4, (slab * SLAB + 8 * i) * D * 4, 0));
+                } else {
+                    const int pr = s_prev[lr];
+                    xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsH, pr >= 0 ? (int)((uint32_t)pr * (uint32_t)(D * 4) + (uint32_t)((kcol - D) * 4)) : -16, 0, 0));
+                }
+                zr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (srow * NGD + jcol) * 4, (slab * SLAB + 8 * i) * NGD * 4, 0));
+            }
+            return;
+        }
         const float* X = launder(w.X);
         const float* H = launder(blk.H);
         const float* dZ = launder(w.dZ);

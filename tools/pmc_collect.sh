@@ -18,5 +18,5 @@ for g in "${!G[@]}"; do
   timeout 600 rocprofv3 --kernel-trace --pmc ${G[$g]} -d "$out/$g" -o run -- python bench.py $args > "$out/$g.log" 2>&1
   echo "$g rc=$?" >> "$out/status.txt"
 done
-find "$out" -name '*.db' -size +20M -delete
+# (the caller summarises the databases and deletes them: gpurun_out/ has a 64 MiB limit)
 ls -laR "$out" > "$out/listing.txt"

@@ -42,15 +42,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
 #endif
 #define SBR_MAX_T 256 /* longest supported max_sequence_length of the sequence-resident kernels */
-/* 64-sequence tiles (one workgroup per CU) pay off only with enough tiles per CU to balance the dependent step chains;
- * below these counts of 64-sequence tiles the 32-sequence form (two workgroups per CU) is used.  Measured on the bench
- * workload (ms forward / BPTT, 32- vs 64-sequence tiles): B = 16384: 1.50 / 1.77 vs 2.42 / 2.42; B = 40000 (625 tiles):
- * 2.97 / 2.83 vs 3.13 / 3.11; B = 50000 (782 tiles): 4.79 / 4.39 vs 4.15 / 4.45; B = 65536: 4.82 / 4.35 vs 4.52 / 4.34. */
+/* Two forms of the sequence-resident kernels: 32-sequence tiles at two workgroups per CU (128 registers per wave) and
+ * 64-sequence tiles at one (256 registers; half the weight traffic per row, but nothing to fill a workgroup's barrier
+ * waits with).  Since the address arithmetic left the vector ALU the 32-sequence form is the faster one up to ~1 500
+ * 64-sequence tiles and equal beyond (ms forward / BPTT on the bench workload, 32- vs 64-sequence tiles: 30 000
+ * sequences 2.21 / 2.31 vs 2.78 / 2.48; 50 000 (782 tiles) 3.92 / 3.99 vs 4.03 / 4.34; 100 000 (1 563 tiles)
+ * 7.73-7.96 / 7.78-8.04 vs 7.66-7.76 / 7.91-7.93).  SBR_SEQ_RT = 2 / 4 forces one form. */
 #ifndef SBR_FWD_RT4_MIN_TILES
-#define SBR_FWD_RT4_MIN_TILES 700
+#define SBR_FWD_RT4_MIN_TILES 1500
 #endif
 #ifndef SBR_BWD_RT4_MIN_TILES
-#define SBR_BWD_RT4_MIN_TILES 1100
+#define SBR_BWD_RT4_MIN_TILES 3000
 #endif
 #ifndef SBR_BWD256_MIN_TILES
 #define SBR_BWD256_MIN_TILES 320
@@ -2428,10 +2430,9 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         DISPATCH_D(m.d, {
             if constexpr (DD <= 128) {
                 constexpr int UPW = 1;
-                /* 64-sequence tiles (one workgroup per CU, 256 registers per wave) when there are enough of them to balance
-                 * the CUs; 32-sequence tiles (two workgroups per CU) for small minibatches, where the longest tile's dependent
-                 * steps set the kernel time.  SBR_SEQ_RT = 2 / 4 forces one form. */
-                static const int rt_env = std::getenv("SBR_SEQ_RT") ? std::atoi(std::getenv("SBR_SEQ_RT")) : 0;
+                /* 32-sequence tiles (two workgroups per CU) or 64-sequence tiles (one): see SBR_FWD_RT4_MIN_TILES */
+                const char* rt_str = std::getenv("SBR_SEQ_RT"); /* read per call: the tests force either form */
+                const int rt_env = rt_str ? std::atoi(rt_str) : 0;
                 const bool big = rt_env ? rt_env >= 4 : (mb.B + 63) / 64 >= SBR_FWD_RT4_MIN_TILES;
                 if (big && DD >= 64) {
                     constexpr int RT = 4;
@@ -2517,7 +2518,8 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
     if (resident && tm_host <= SBR_MAX_T) { /* sequence-resident BPTT: one launch for all time steps */
         DISPATCH_D(m.d, {
             if constexpr (DD <= 256) {
-                static const int rt_env = std::getenv("SBR_SEQ_RT") ? std::atoi(std::getenv("SBR_SEQ_RT")) : 0;
+                const char* rt_str = std::getenv("SBR_SEQ_RT"); /* read per call: the tests force either form */
+                const int rt_env = rt_str ? std::atoi(rt_str) : 0;
                 const bool big = rt_env ? rt_env >= 4 : (b_host + 63) / 64 >= SBR_BWD_RT4_MIN_TILES;
                 bool launched = false;
                 if constexpr (DD >= 64 && DD <= 128) {  /* d = 256: 16 waves per workgroup leave 128 registers per wave */

@@ -696,16 +696,21 @@ def test_hot_rows_take_the_chunked_reduction(kind, loss, d, mode):
         assert_params_equal(m, o, kind, f"hot rows {mode} replica {q}")
 
 
-@pytest.mark.parametrize("kind,loss,d", [
-    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128),
-    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64),
-    (ModelKind.EWMA, LOSS_WARP, 256),
+@pytest.mark.parametrize("kind,loss,d,rt", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "2"),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "4"),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "2"),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "4"),
+    (ModelKind.EWMA, LOSS_WARP, 256, None),
 ])
-def test_many_tiles_per_minibatch(kind, loss, d):
+def test_many_tiles_per_minibatch(monkeypatch, kind, loss, d, rt):
     """A minibatch of 9 000 sequences = 282 tiles of 32 sequences: more than the 256 slots over which the
     sequence-resident kernels fold their length-sorted tile list (second fold group reversed), 40+ chunks of
     1 024 packed rows in the dense-gradient GEMM, and a sparse update with ~10^5 keys — the regime the
-    benchmark runs in, at a size the oracle still finishes in seconds.  Whole-fit parity, bit for bit."""
+    benchmark runs in, at a size the oracle still finishes in seconds.  Whole-fit parity, bit for bit, in both
+    forms of the sequence-resident kernels (SBR_SEQ_RT: 32- / 64-sequence tiles)."""
+    if rt is not None:
+        monkeypatch.setenv("SBR_SEQ_RT", rt)
     users, items, T, B = 9500, 4001, 7, 9000
     ptr, it = synthetic_interactions(users, items, T, seed=53, min_len=3)
     hp = hparams(items, T, d, int(kind), loss, epochs=1, B=B)

@@ -54,6 +54,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_BWD_RT4_MIN_TILES
 #define SBR_BWD_RT4_MIN_TILES 3000
 #endif
+#ifndef SBR_DW_WPE
+#define SBR_DW_WPE 4 /* waves per SIMD the dense-gradient kernel's register budget is set for (110 registers at 16-row slabs) */
+#endif
+/* rows staged through LDS per barrier pair of the dense-gradient kernel: 16 (20 KB of LDS and 110 registers per workgroup,
+ * four workgroups per CU) measured 1-3 % ahead of 32 alone and beside the sparse update, 64 (two workgroups per CU) 10 % behind */
+#ifndef SBR_DW_SLAB
+#define SBR_DW_SLAB 16
+#endif
 #ifndef SBR_BWD256_MIN_TILES
 #define SBR_BWD256_MIN_TILES 320
 #endif
@@ -1453,11 +1461,12 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(ModelView m, MbView mb, Bl
 // zeros), so that every wait count is static, and the LDS operand reads of iteration s+1 are issued before the
 // MFMAs of iteration s.
 template <int D, int NG>
-__global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+__global__ __launch_bounds__(256, SBR_DW_WPE) void lstm_dw_full_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
     constexpr int K2 = 2 * D;
     constexpr int NGD = NG * D;
     constexpr int TJ = NGD / 128;
-    constexpr int SLAB = 32;
+    constexpr int SLAB = SBR_DW_SLAB;  // rows staged through LDS per barrier pair
+    constexpr int NI = SLAB / 8;       // 16-byte row pieces per thread and operand
     constexpr int NTILE = (K2 / 128) * TJ;
     static_assert(K2 % 128 == 0 && NGD % 128 == 0, "full tiles only");
     __shared__ float Xs[SLAB * 128];
@@ -1490,7 +1499,7 @@ __global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView m
     const int kcol = tk * 128 + c4;
     const int jcol = tj * 128 + c4;
     const bool xpart = kcol < D;  // this thread's k columns are input (x) columns; otherwise previous-hidden columns
-    float4 xr[4], zr[4];
+    float4 xr[NI], zr[NI];
     // Slab fetches through buffer resources (scalar base, invariant per-lane byte offset, scalar slab offset): dZ and X
     // rows of the chunk are contiguous; the previous-hidden rows are addressed by prev_row x row bytes, and a first-step
     // row (prev_row = -1) becomes an out-of-range offset, which reads as zeros.  Needs a 128-column tile to lie entirely
@@ -1503,7 +1512,7 @@ __global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView m
     auto fetch = [&](int slab) {
         if (D >= 128 && small_h) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const int lr = slab * SLAB + srow + 8 * i;
                 if (tk * 128 < D) {  // x columns (uniform per workgroup); rows past R are out of range and read as zeros: they meet zeros in dZ
                     xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsXc, (srow * D + kcol) * 4, (slab * SLAB + 8 * i) * D * 4, 0));
@@ -1520,7 +1529,7 @@ __global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView m
         const float* dZ = launder(w.dZ);
         const float* zero = launder(w.zeros);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int lr = slab * SLAB + srow + 8 * i;
             const int row = r0 + lr <= last ? r0 + lr : last;
             const int pr = s_prev[lr];
@@ -1537,7 +1546,7 @@ __global__ __launch_bounds__(256) void lstm_dw_full_kernel(ModelView m, MbView m
     fetch(0);
     for (int slab = 0; slab < nslabs; ++slab) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             st4(&Xs[(srow + 8 * i) * 128 + c4], xr[i]);
             st4(&Zs[(srow + 8 * i) * 128 + c4], zr[i]);
         }

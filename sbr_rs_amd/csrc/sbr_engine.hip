@@ -293,6 +293,7 @@ struct sbr_model {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
+    hipStream_t sorter = nullptr;        /* third stream: key sort of the sparse update, underneath the backward pass */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scored = nullptr, ev_sorted = nullptr;
     std::mutex mu;
     bool timing = false;
@@ -622,6 +623,14 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
      * lowest priority, so the update's workgroups are placed first whenever a slot frees up */
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    /* the key sort gets its own stream: on the GEMM's stream its tail — the passes that did not fit underneath the
+     * backward pass, whose workgroups fill every CU, so that the sort's kernels only run in slots that retiring
+     * workgroups free — delayed the GEMM, which does not need the sorted keys, by 0.36 ms per step.  Priority: normal
+     * (13.42-13.50 ms per step; high 13.62-13.74: the sort then wins every freed slot and the backward pass loses more
+     * than the update gains; low 13.58-13.63).  SBR_SORT_PRIO = high | normal | low is the A/B switch. */
+    const char* sort_prio_env = std::getenv("SBR_SORT_PRIO");
+    const int sort_prio = !sort_prio_env || sort_prio_env[0] == 'n' ? 0 : sort_prio_env[0] == 'h' ? prio_greatest : prio_least;
+    if (hipStreamCreateWithPriority(&m->sorter, hipStreamNonBlocking, sort_prio) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -740,6 +749,7 @@ void sbr_model_destroy(sbr_model* m) {
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
+    if (m->sorter) { hipStreamSynchronize(m->sorter); hipStreamDestroy(m->sorter); }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
     if (m->ev_scored) hipEventDestroy(m->ev_scored);
@@ -908,6 +918,7 @@ sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable) {
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     HIPCHK(hipStreamSynchronize(m->side));
+    HIPCHK(hipStreamSynchronize(m->sorter));
     m->overlap = enable != 0;
     return SBR_OK;
 }
@@ -1054,6 +1065,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     hipSetDevice(p->m->device);
     if (p->pending) { p->worker.join(); p->pending = false; }
     hipStreamSynchronize(p->m->side);
+    hipStreamSynchronize(p->m->sorter);
     hipStreamSynchronize(p->m->stream);
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
@@ -1282,15 +1294,16 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     }
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
     /* the sort of the sparse-update keys needs only the index arrays and the sampled negatives: it runs
-     * on the side stream underneath the backward pass (joined by step_apply / step_scatter) */
+     * on its own stream underneath the backward pass (joined by step_apply / step_scatter) */
     hipStream_t side = m->overlap ? m->side : m->stream;
+    hipStream_t sorter = m->overlap ? m->sorter : m->stream;
     HIPCHK(hipEventRecord(m->ev_scored, m->stream));
-    HIPCHK(hipStreamWaitEvent(side, m->ev_scored, 0));
+    HIPCHK(hipStreamWaitEvent(sorter, m->ev_scored, 0));
     {
-        ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, side);
-        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, side);
+        ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, sorter);
+        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, sorter);
     }
-    HIPCHK(hipEventRecord(m->ev_sorted, side));
+    HIPCHK(hipEventRecord(m->ev_sorted, sorter));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
@@ -1577,6 +1590,7 @@ sbr_status sbr_fit_sparse_stats(sbr_fit_plan* p, uint64_t* out_entries, uint64_t
     if (!p) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(p->m));
     HIPCHK(hipStreamSynchronize(p->m->side));
+    HIPCHK(hipStreamSynchronize(p->m->sorter));
     HIPCHK(hipStreamSynchronize(p->m->stream));
     uint32_t nheads = 0;
     HIPCHK(hipMemcpy(&nheads, p->seg.nheads, sizeof(nheads), hipMemcpyDeviceToHost));

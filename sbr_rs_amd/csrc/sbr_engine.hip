@@ -1284,26 +1284,35 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const sbr::MbView mv = mb_view(p, minibatch);
     const sbr::BlockView bv = block_view(m, block, p->rmax);
     const int* off_host = ep.off_host.data() + mb.off_base;
+    /* The sort of the sparse-update keys needs only the index arrays and the negatives: it runs on its own stream,
+     * underneath the backward pass (WARP: the negatives come out of the score kernel) or, for the single-negative losses
+     * whose negatives are a hash of the row counter, from the very start of the step (joined by step_apply / step_scatter). */
+    hipStream_t side = m->overlap ? m->side : m->stream;
+    hipStream_t sorter = m->overlap ? m->sorter : m->stream;
+    const bool early_sort = m->hp.loss != SBR_LOSS_WARP && !std::getenv("SBR_NO_EARLY_SORT"); /* the variable is the A/B switch */
+    const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
+    auto launch_sort = [&]() -> sbr_status {
+        HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* everything before: the previous step's readers of the keys, this step's score */
+        HIPCHK(hipStreamWaitEvent(sorter, m->ev_scored, 0));
+        {
+            ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, sorter);
+            sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, sorter,
+                                 early_sort ? &mv : nullptr, epoch_key, m->hp.num_items);
+        }
+        HIPCHK(hipEventRecord(m->ev_sorted, sorter));
+        return SBR_OK;
+    };
+    if (early_sort) SBRCHK(launch_sort());
     {
         ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
         sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
     }
     {
         ScopedTimer t(m, SBR_K_SCORE, 1);
-        sbr::launch_score(m->mv, mv, bv, p->wb.v, sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch), mb.R, m->stream);
+        sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
     }
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
-    /* the sort of the sparse-update keys needs only the index arrays and the sampled negatives: it runs
-     * on its own stream underneath the backward pass (joined by step_apply / step_scatter) */
-    hipStream_t side = m->overlap ? m->side : m->stream;
-    hipStream_t sorter = m->overlap ? m->sorter : m->stream;
-    HIPCHK(hipEventRecord(m->ev_scored, m->stream));
-    HIPCHK(hipStreamWaitEvent(sorter, m->ev_scored, 0));
-    {
-        ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, sorter);
-        sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, sorter);
-    }
-    HIPCHK(hipEventRecord(m->ev_sorted, sorter));
+    if (!early_sort) SBRCHK(launch_sort());
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);

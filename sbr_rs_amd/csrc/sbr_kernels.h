@@ -123,8 +123,11 @@ void launch_repack_lstm(const ModelView& m, hipStream_t s);
  * the position-addressed list + owner bounds (partitioned table) */
 size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits);
 size_t sparse_select_temp_bytes(size_t max_entries);
+/* early_mb != null (single-negative losses): keys from the minibatch's index arrays and the negative-draw hash, i.e.
+ * without waiting for the score kernel */
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s);
+                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s, const MbView* early_mb = nullptr,
+                     uint64_t epoch_key = 0, uint32_t num_items = 0);
 void launch_seg_apply(const ModelView& m, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted,
                       const SegScratch& sc, hipStream_t s);
 void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_host, int ndev, uint64_t slice_rows,

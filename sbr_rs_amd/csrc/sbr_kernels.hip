@@ -2097,6 +2097,17 @@ __global__ void build_own_keys_kernel(BlockView blk, uint32_t R, uint64_t* keys)
     }
 }
 
+// Single-negative losses (hinge, BPR): the negative of a packed row is a hash of (epoch key, row counter) alone — no score
+// decides it — so the keys can be built and sorted before the forward pass instead of after the score kernel.
+__global__ void build_own_keys_early_kernel(MbView mb, uint64_t epoch_key, uint32_t num_items, uint32_t R, uint64_t* keys) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+        uint64_t* k = keys + 3ull * r;
+        k[0] = ((uint64_t)mb.in_idx[r] << 32) | (3ull * r);
+        k[1] = ((uint64_t)mb.out_idx[r] << 32) | (3ull * r + 1);
+        k[2] = ((uint64_t)sbr_neg_draw(epoch_key, mb.ctr[r], 0u, num_items) << 32) | (3ull * r + 2);
+    }
+}
+
 // ---- partitioned item table: owner-computes over peer-readable gradient lists -----
 // Every device reduces its own entries per table row exactly as sparse_scatter_kernel does, but into a
 // LIST addressed by the position of the row's first key in the device's sorted key array
@@ -2415,10 +2426,17 @@ __global__ void selftest_mfma32_chain_kernel(const float* a, const float* b, int
         default: break;                                            \
     }
 
+/* Resident grids of the memory-bound grid-stride kernels: SBR_RESIDENT_WG_PER_CU workgroups of 256 threads per CU.  Eight
+ * would fill every wave slot of the chip; seven leave one wave per SIMD for whatever runs beside them on another stream
+ * (the key sort's short kernels could otherwise only advance at the main stream's kernel boundaries). */
+#ifndef SBR_RESIDENT_WG_PER_CU
+#define SBR_RESIDENT_WG_PER_CU 7
+#endif
 static inline int grid_for_groups(long long groups, int groups_per_block) {
+    static const int per_cu = std::getenv("SBR_RESIDENT_WG_PER_CU") ? std::atoi(std::getenv("SBR_RESIDENT_WG_PER_CU")) : SBR_RESIDENT_WG_PER_CU;
     long long g = (groups + groups_per_block - 1) / groups_per_block;
     if (g < 1) g = 1;
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > 256 * per_cu) g = 256 * per_cu;
     return (int)g;
 }
 
@@ -2661,10 +2679,15 @@ size_t sparse_select_temp_bytes(size_t max_entries) {
     return bytes;
 }
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
-                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s) {
+                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s, const MbView* early_mb,
+                     uint64_t epoch_key, uint32_t num_items) {
     if (rows_host == 0) return;
     const uint64_t total = 3ull * rows_host;
-    hipLaunchKernelGGL(build_own_keys_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, blk, rows_host, keys);
+    if (early_mb)
+        hipLaunchKernelGGL(build_own_keys_early_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, *early_mb, epoch_key, num_items,
+                           rows_host, keys);
+    else
+        hipLaunchKernelGGL(build_own_keys_kernel, dim3(grid_for_groups(rows_host, 256)), dim3(256), 0, s, blk, rows_host, keys);
     (void)rocprim::radix_sort_keys<rocprim::default_config, uint64_t*, uint64_t*>(sort_temp, sort_temp_bytes, keys, keys_sorted, total, 0, key_bits, s, false);
     /* segment heads (ascending) + sentinel: what the per-row reduction iterates over */
     size_t tb = sc.select_temp_bytes;

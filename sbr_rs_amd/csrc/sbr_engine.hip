@@ -428,8 +428,7 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
     sbr::WorkView& v = wb->v;
     if (m->ng) {
         SBRCHK(dmalloc(&v.C, rmax * d));
-        v.dump_row0 = (int)rmax;
-        SBRCHK(dmalloc(&v.G, (rmax + 64) * d * 4)); /* + 64 dump rows: where the sequence-resident kernels' lanes of finished sequences store (branch-free stores keep the in-order memory counter statically known) */
+        SBRCHK(dmalloc(&v.G, rmax * d * 4));
         SBRCHK(dmalloc(&v.X, rmax * d));
     }
     if (training) {
@@ -440,8 +439,7 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         SBRCHK(dmalloc(&v.part_tries, 2048));
         if (m->ng) {
             const uint64_t rchunk = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS * SBR_DW_CHUNK_ROWS;
-            v.dz_dump_row0 = (int)rchunk; /* the dense-gradient GEMM reads dZ to the end of the last chunk: dump rows lie behind it */
-            SBRCHK(dmalloc(&v.dZ, (rchunk + 64) * d * (uint64_t)m->ng));
+            SBRCHK(dmalloc(&v.dZ, rchunk * d * (uint64_t)m->ng)); /* the dense-gradient GEMM reads dZ to the end of the last chunk */
             SBRCHK(dmalloc(&v.zeros, 256));
             HIPCHK(hipMemset(v.zeros, 0, 256 * sizeof(float)));
             SBRCHK(dmalloc(&v.dHrec, bmax * d));

@@ -59,8 +59,6 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     uint32_t* tries;        /* [Rmax] */
     double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
     unsigned int* part_tries;
-    int dump_row0;          /* first of the 64 dump rows behind G (= Rmax) */
-    int dz_dump_row0;       /* first of the 64 dump rows behind dZ (= Rmax rounded up to the dense-gradient chunk) */
     float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM) */
 };
 

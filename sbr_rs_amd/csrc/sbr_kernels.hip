@@ -584,7 +584,7 @@ __device__ __forceinline__ void lstm_cell_fwd_x2(v2f zi, v2f zf, v2f zg, v2f zo,
 }
 
 template <int D, int NG, int RT, int UPW>
-__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles, int dump_row0) {
+__global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) : SBR_FWD_WPE) void lstm_fwd_seq_kernel(ModelView m, MbView mb, float* H, WorkView w, int ntiles) {
     constexpr int K2 = 2 * D;
     constexpr int LDA = K2 + 2;
     constexpr int NS = K2 / 16;
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_gemm_kernel(ModelView m, MbView 
 // requested one step earlier) are issued behind the first ring blocks of step t's GEMM and land under it;
 // the gate / cell-state rows of step t-1 are requested after the GEMM's last fragment request and land
 // under the epilogue; loaded values are not touched before the phase that needs them; stores are
-// branch-free (lanes of finished sequences write to dump rows) and step ts = nsteps-1 and the first ring
+// branch-free (lanes of finished sequences fall outside the step's buffer ranges) and step ts = nsteps-1 and the first ring
 // blocks are peeled, so that every wait count is static and exact.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NG, int RT>
@@ -2465,16 +2465,16 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
                     constexpr int RT = 4;
                     const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
                     if (m.ng == 4)
-                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
                     else
-                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
                 } else {
                     constexpr int RT = 2;
                     const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
                     if (m.ng == 4)
-                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
                     else
-                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles, w.dump_row0);
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
                 }
             }
         });
@@ -2597,8 +2597,7 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     DISPATCH_D(m.d, {
         const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
-        /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here (they lie below the
-         * dump rows, which start at the chunk-aligned capacity) */
+        /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */
         const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
         if (m.ng == 4) {
             if constexpr (full4) {

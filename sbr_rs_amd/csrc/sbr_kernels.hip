@@ -41,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_FWD_WPE
 #define SBR_FWD_WPE 3 /* min waves per SIMD asked of the compiler when a wave owns several unit tiles */
 #endif
-#define SBR_MAX_T 256 /* longest supported max_sequence_length of the sequence-resident kernels */
+#define SBR_MAX_T 1024 /* longest max_sequence_length the sequence-resident kernels take (their per-step row offsets live in LDS: 4 KB); beyond it, per-step launches */
 /* Two forms of the sequence-resident kernels: 32-sequence tiles at two workgroups per CU (128 registers per wave) and
  * 64-sequence tiles at one (256 registers; half the weight traffic per row, but nothing to fill a workgroup's barrier
  * waits with).  Since the address arithmetic left the vector ALU the 32-sequence form is the faster one up to ~1 500

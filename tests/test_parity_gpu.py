@@ -767,13 +767,14 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("kind,d,T", [(ModelKind.LSTM_NORMAL, 128, 300), (ModelKind.EWMA, 32, 300), (ModelKind.LSTM_COUPLED, 256, 300),
-                                      (ModelKind.LSTM_NORMAL, 128, 256), (ModelKind.LSTM_COUPLED, 64, 200), (ModelKind.LSTM_NORMAL, 32, 257)])
+                                      (ModelKind.LSTM_NORMAL, 128, 256), (ModelKind.LSTM_COUPLED, 64, 200), (ModelKind.LSTM_NORMAL, 32, 257),
+                                      (ModelKind.LSTM_NORMAL, 16, 1024), (ModelKind.LSTM_COUPLED, 16, 1030)])
 def test_long_sequences(kind, d, T):
-    """max_sequence_length up to 300 with users of up to 700 interactions: several chunks per user (short chunk
-    first, data.rs:406-431), minibatches whose tiles differ in length by two orders of magnitude.  T <= 256 (255
-    dependent time steps inside one launch of the sequence-resident kernels, the longest they take) and T > 256
-    (per-step kernels) both."""
-    ptr, it = synthetic_interactions(40, 500, 700, seed=61, min_len=1, zipf=True)
+    """max_sequence_length up to 1030 with users of up to 700 (T <= 300) or 2 500 interactions: several chunks per
+    user (short chunk first, data.rs:406-431), minibatches whose tiles differ in length by two orders of magnitude.
+    T <= 1024: up to 1 023 dependent time steps inside one launch of the sequence-resident kernels, the longest they
+    take; beyond that (and for the d = 256 forward pass) the per-step kernels."""
+    ptr, it = synthetic_interactions(40 if T <= 300 else 12, 500, 700 if T <= 300 else 2500, seed=61, min_len=1, zipf=True)
     hp = hparams(500, T, d, int(kind), LOSS_WARP, epochs=1, B=16)
     g, o = make_pair(hp)
     assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)

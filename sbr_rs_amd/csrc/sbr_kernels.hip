@@ -2529,10 +2529,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
             const int gpb = 4 * (64 / (DD / 4));
             hipLaunchKernelGGL((ewma_backward_kernel<DD>), dim3(grid_for_groups(b_host, gpb)), dim3(256), 0, s, m, mb, blk, w);
         });
-        const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
-        hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w.dab, b_host, m.d, w.partials);
-        hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w.partials, nch, m.d, m.alpha, blk.dense);
-        return;
+        return; /* dalpha: launch_dense_gradient (the side stream, beside the sparse update) */
     }
     bool stepwise = true;
     /* d = 256: 16 waves per workgroup leave 128 registers per wave, i.e. only the 32-sequence form, one workgroup per CU;
@@ -2590,7 +2587,13 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
 
 void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
                            int b_host, hipStream_t s) {
-    if (rows_host == 0 || m.ng == 0) return; /* EWMA's dalpha and the empty case are handled by launch_recurrent_backward */
+    if (rows_host == 0) return; /* the empty case is handled by launch_recurrent_backward */
+    if (m.ng == 0) { /* EWMA: dalpha from the per-sequence partials the backward scan left in w.dab */
+        const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
+        hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w.dab, b_host, m.d, w.partials);
+        hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w.partials, nch, m.d, m.alpha, blk.dense);
+        return;
+    }
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);

@@ -111,6 +111,17 @@ __device__ __forceinline__ void opt_update(const ModelView& m, float* w, float* 
     else sbr_adagrad(w, acc, g, m.lr, m.l2);
 }
 
+// A kernel-argument pointer passed through an empty asm: the compiler can no longer hoist "pointer + per-lane
+// offset" out of the time loop as a 64-bit VGPR pair that lives across it (those pairs were being spilled to
+// scratch, and a scratch reload is a vector-memory operation that waits for EVERYTHING outstanding).
+template <class T>
+__device__ __forceinline__ T* launder(T* p) {
+    typedef T __attribute__((address_space(1))) * global_ptr;  // keep the address space: a generic pointer would
+    global_ptr g = (global_ptr)p;                              // turn every access into a flat_ operation
+    asm volatile("" : "+s"(g));
+    return (T*)g;
+}
+
 __device__ __forceinline__ float dot4(float4 x, float4 y) {
     float p = x.x * y.x;
     p = sbr_fma(x.y, y.y, p);
@@ -221,6 +232,102 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
                 w.tries[r] = tries;
                 loss_part += (double)l;
                 tries_part += tries;
+            }
+        }
+    }
+    __shared__ double s_loss[4];
+    __shared__ unsigned int s_tries[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        loss_part += __shfl_xor(loss_part, off, 64);
+        tries_part += __shfl_xor(tries_part, off, 64);
+    }
+    if (lane == 0) {
+        s_loss[threadIdx.x >> 6] = loss_part;
+        s_tries[threadIdx.x >> 6] = tries_part;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
+    }
+}
+
+// Single-negative losses (hinge, BPR: one candidate, no retry loop): U rows per lane group and pass, all their gathers
+// in flight together, the ids of the next pass requested before this pass's rows (vector memory operations retire in
+// order, so they have long arrived when the next pass starts).  Without the retry loop the pass is pure memory-level
+// parallelism: 1.25 -> 1.1 ms at d = 256 against a 10 M-row table.  (With WARP's retry rounds in lockstep the same
+// idea loses — more rounds per row than a two-row group needs — so WARP keeps score_kernel.)
+template <int D, int U>
+__global__ __launch_bounds__(256) void score_single_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    constexpr int RPW = GPW * U;  // rows per wave and pass
+    const int lane = threadIdx.x & 63;
+    const int lg = lane % L;
+    const int grp = lane / L;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int R = mb.R, last = mb.R - 1;
+    const float* E = launder(m.E);
+    const float* bias = launder(m.b);
+    const float* Hh = launder(blk.H);
+    const uint32_t* out_idx = launder(mb.out_idx);
+    const uint32_t* in_idx = launder(mb.in_idx);
+    const uint32_t* ctrs = launder(mb.ctr);
+    double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
+    unsigned int tries_part = 0;
+    uint32_t pi_next[U], ctr_next[U], in_next[U];
+    auto request_ids = [&](int base) {  // rows past R are clamped to the last row (valid memory, results not stored)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u * GPW + grp;
+            const int rr = r < R ? r : last;
+            pi_next[u] = out_idx[rr];
+            ctr_next[u] = ctrs[rr];
+            in_next[u] = in_idx[rr];
+        }
+    };
+    int base = wave * RPW;
+    if (base < R) request_ids(base);
+    for (; base < R; base += nwaves * RPW) {
+        uint32_t pi[U], cand[U], ini[U];
+        float4 h[U], ep[U], ec[U];
+        float bp[U], bc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pi[u] = pi_next[u];
+            ini[u] = in_next[u];
+            cand[u] = sbr_neg_draw(epoch_key, ctr_next[u], 0u, m.num_items);
+        }
+        request_ids(base + nwaves * RPW);  // clamped: the request count does not depend on the pass
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u * GPW + grp;
+            const int rr = r < R ? r : last;
+            h[u] = ld4(Hh + (size_t)rr * D + 4 * lg);
+            ep[u] = ld4(E + (size_t)pi[u] * D + 4 * lg);
+            bp[u] = bias[pi[u]];
+            ec[u] = ld4(E + (size_t)cand[u] * D + 4 * lg);
+            bc[u] = bias[cand[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u * GPW + grp;
+            const float pos = bp[u] + group_allreduce<L>(dot4(h[u], ep[u]));
+            const float neg = bc[u] + group_allreduce<L>(dot4(h[u], ec[u]));
+            float g, l;
+            if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
+            else l = sbr_loss_hinge(pos, neg, &g);
+            if (r < R && lg == 0) {
+                blk.neg[r] = cand[u];
+                blk.coef[r] = g;
+                blk.in_idx[r] = ini[u];
+                blk.out_idx[r] = pi[u];
+                w.loss[r] = l;
+                w.tries[r] = 1u;
+                loss_part += (double)l;
+                tries_part += 1u;
             }
         }
     }
@@ -522,16 +629,6 @@ __global__ __launch_bounds__(NG * 64) void lstm_fwd_step_kernel(ModelView m, MbV
 // workgroups drift out of phase over the steps, so one workgroup's gathers/epilogue overlap
 // another's MFMAs (per-step launches start every workgroup in lockstep and serialise the phases).
 // ------------------------------------------------------------------------------------------------
-// A kernel-argument pointer passed through an empty asm: the compiler can no longer hoist "pointer + per-lane
-// offset" out of the time loop as a 64-bit VGPR pair that lives across it (those pairs were being spilled to
-// scratch, and a scratch reload is a vector-memory operation that waits for EVERYTHING outstanding).
-template <class T>
-__device__ __forceinline__ T* launder(T* p) {
-    typedef T __attribute__((address_space(1))) * global_ptr;  // keep the address space: a generic pointer would
-    global_ptr g = (global_ptr)p;                              // turn every access into a flat_ operation
-    asm volatile("" : "+s"(g));
-    return (T*)g;
-}
 
 // Two LSTM cells at once on packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE
 // operations per issue slot).  The operation sequence per cell is exactly sbr_lstm_cell_fwd's / sbr_tanh_pq's
@@ -2491,8 +2588,9 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
     }
 }
 
-static int score_grid(int d, int rows) {
-    const int gpb = 4 * (64 / (d / 4));
+#define SBR_SCORE_SINGLE_U 4 /* rows per lane group and pass of score_single_kernel */
+static int score_grid(int d, int rows, bool single_negative) {
+    const int gpb = 4 * (64 / (d / 4)) * (single_negative ? SBR_SCORE_SINGLE_U : 1);  // rows per workgroup and pass
     return grid_for_groups(rows, gpb);
 }
 
@@ -2500,7 +2598,11 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                   int rows_host, hipStream_t s) {
     if (rows_host > 0) {
         DISPATCH_D(m.d, {
-            hipLaunchKernelGGL((score_kernel<DD>), dim3(score_grid(DD, rows_host)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+            if (m.loss == SBR_LOSS_WARP)
+                hipLaunchKernelGGL((score_kernel<DD>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+            else
+                hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
+                                   epoch_key);
         });
     }
 }
@@ -2514,7 +2616,7 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
 
 void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
     hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, blk.header, rows_host, w.part_loss, w.part_tries,
-                       rows_host > 0 ? score_grid(m.d, rows_host) : 0);
+                       rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

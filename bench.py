@@ -74,7 +74,7 @@ def make_hp(args, world, rank, model_kind, loss, num_items, epochs=1, batch=None
                         bytes([42] * 16), epochs, world, rank, batch or args.batch_sequences)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, model_kind=0, loss_kind=2):
     """The oracle (kind "port") on a bounded sample of the same workload: every worker thread owns a
     model and one minibatch worth of users of the same generator and runs one epoch of it; fit time
     only.  Workers are independent (≙ the reference's rayon workers on their own partitions,
@@ -89,7 +89,7 @@ def cpu_baseline(args):
 
     def prepare(seed):
         ptr, items = synthetic_csr(users, args.items, args.max_len, seed=seed)
-        hp = make_hp(args, 1, 0, 0, 2, args.items, epochs=1, batch=min(args.batch_sequences, users))
+        hp = make_hp(args, 1, 0, model_kind, loss_kind, args.items, epochs=1, batch=min(args.batch_sequences, users))
         m = OracleModel(hp)
         plan = m.fit_begin(ptr, items)
         nmb = plan.epoch_prepare()
@@ -107,7 +107,7 @@ def cpu_baseline(args):
     single = one[3] / dt1
     out = {"value": single, "unit": "interactions/s", "cores": 1, "kind": "port",
            "sample": f"{users} users of the same generator ({one[3]} interactions, {one[2]} minibatch(es)), "
-                     f"LSTM+WARP dim {args.dim}, 1 epoch, single-thread C oracle, {dt1:.1f} s",
+                     f"{args.model}+{args.loss} dim {args.dim}, 1 epoch, single-thread C oracle, {dt1:.1f} s",
            "single_thread_value": single, "host_cores_available": os.cpu_count()}
     del one
     if workers > 1:
@@ -132,7 +132,7 @@ def cpu_baseline(args):
         rows = sum(j[3] for j in jobs)
         out.update({"value": rows / dtn, "cores": workers,
                     "sample": f"{workers} independent worker threads x {users} users of the same generator "
-                              f"({rows} interactions), LSTM+WARP dim {args.dim}, 1 epoch each, C oracle, {dtn:.1f} s wall "
+                              f"({rows} interactions), {args.model}+{args.loss} dim {args.dim}, 1 epoch each, C oracle, {dtn:.1f} s wall "
                               f"(single thread: {single:.0f} interactions/s)"})
     return out
 
@@ -483,7 +483,7 @@ def main():
             out["param_crc"] = {n: zlib.crc32(model.get_param(getattr(Param, n)).tobytes()) for n in names}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args)
+                out["cpu_baseline"] = cpu_baseline(args, model_kind, loss_kind)
             except Exception as e:  # the throughput line must survive a host-side problem (e.g. memory limits)
                 out["cpu_baseline"] = {"error": repr(e)}
         if world == 1 and not args.no_mrr:

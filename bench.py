@@ -74,6 +74,24 @@ def make_hp(args, world, rank, model_kind, loss, num_items, epochs=1, batch=None
                         bytes([42] * 16), epochs, world, rank, batch or args.batch_sequences)
 
 
+def measured_ceiling(row_bytes: int, cached_table: bool):
+    """Random-row gather rate this device sustains (tools/hbm_ceiling.hip, profiles/r02_hbm_ceiling.jsonl): the
+    figure the score kernel's REAL traffic is to be held against (the roofline fractions use the 8 TB/s spec)."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_ceiling.jsonl")
+    best = None
+    try:
+        for line in open(path):
+            r = json.loads(line)
+            if r.get("access") != "random row gather" or r.get("row_bytes") != row_bytes:
+                continue
+            if (r.get("table_GiB", 0) < 1.0) != cached_table:
+                continue
+            best = max(best or 0.0, float(r["GBps"]))
+    except Exception:
+        return None
+    return best
+
+
 def cpu_baseline(args, model_kind=0, loss_kind=2):
     """The oracle (kind "port") on a bounded sample of the same workload: every worker thread owns a
     model and one minibatch worth of users of the same generator and runs one epoch of it; fit time
@@ -410,6 +428,11 @@ def main():
                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
                         "avg_launch_ms": score["ms_per_launch"]}
+            ceil = measured_ceiling(4 * d, cached_table=args.items * d * 4 < (1 << 30))
+            if ceil and traffic:
+                roofline["measured_gather_ceiling"] = {"GBps": ceil, "source": "tools/hbm_ceiling.hip, profiles/r02_hbm_ceiling.jsonl",
+                                                       "real_traffic_GBps": traffic / (score["ms_per_launch"] * 1e-3) / 1e9,
+                                                       "real_traffic_frac_of_ceiling": traffic / (score["ms_per_launch"] * 1e-3) / 1e9 / ceil}
         # standalone kernel times (second pass): HBM figure of the sparse update (3 rows x
         # (gradient source 4d, w and G read, w and G written) + biases = 36d + 24 B per interaction) and MFMA
         # figures of the three GEMM-shaped kernels without their stream partners

@@ -440,6 +440,7 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         if (m->ng) {
             const uint64_t rchunk = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS * SBR_DW_CHUNK_ROWS;
             SBRCHK(dmalloc(&v.dZ, rchunk * d * (uint64_t)m->ng)); /* the dense-gradient GEMM reads dZ to the end of the last chunk */
+            v.wide_addresses = std::getenv("SBR_DW_WIDE_ADDRESSES") ? 1 : 0; /* read when the plan's buffers are made */
             SBRCHK(dmalloc(&v.zeros, 256));
             HIPCHK(hipMemset(v.zeros, 0, 256 * sizeof(float)));
             SBRCHK(dmalloc(&v.dHrec, bmax * d));

@@ -59,7 +59,8 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     uint32_t* tries;        /* [Rmax] */
     double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
     unsigned int* part_tries;
-    float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM) */
+    float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM, 64-bit address path) */
+    int wide_addresses;     /* 1: the dense-gradient GEMM takes its 64-bit per-lane address path even where the buffer path would do (tests) */
 };
 
 /* one chunk pointer per device: slices of one gathered buffer (collective transport), or the peers' own

@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(256, SBR_DW_WPE) void lstm_dw_full_kernel(ModelView
     // rows of the chunk are contiguous; the previous-hidden rows are addressed by prev_row x row bytes, and a first-step
     // row (prev_row = -1) becomes an out-of-range offset, which reads as zeros.  Needs a 128-column tile to lie entirely
     // in the x or in the h half (D >= 128) and H below 2 GiB; otherwise the 64-bit per-lane addresses below.
-    const bool small_h = (size_t)mb.R * D * 4 < ((size_t)1 << 31);  // byte offsets into H stay positive ints
+    const bool small_h = !w.wide_addresses && (size_t)mb.R * D * 4 < ((size_t)1 << 31);  // byte offsets into H stay positive ints
     const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(w.dZ + (size_t)r0 * NGD), (short)0, SBR_DW_CHUNK_ROWS * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
     const int xrows = mb.R - r0 < SBR_DW_CHUNK_ROWS ? mb.R - r0 : SBR_DW_CHUNK_ROWS;
     const __amdgpu_buffer_rsrc_t rsXc = __builtin_amdgcn_make_buffer_rsrc((void*)(w.X + (size_t)r0 * D), (short)0, xrows * D * 4, SBR_BUFFER_RSRC_FLAGS);

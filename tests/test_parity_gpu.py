@@ -696,6 +696,19 @@ def test_hot_rows_take_the_chunked_reduction(kind, loss, d, mode):
         assert_params_equal(m, o, kind, f"hot rows {mode} replica {q}")
 
 
+def test_dense_gradient_wide_address_path(monkeypatch):
+    """The dense-gradient GEMM reads H through a buffer resource while H is below 2 GiB and through 64-bit per-lane
+    addresses beyond; SBR_DW_WIDE_ADDRESSES forces the second path at a size the oracle can follow."""
+    monkeypatch.setenv("SBR_DW_WIDE_ADDRESSES", "1")
+    users, items, T, B = 1500, 901, 9, 1400
+    ptr, it = synthetic_interactions(users, items, T, seed=71, min_len=3)
+    for kind, loss in ((ModelKind.LSTM_NORMAL, LOSS_HINGE), (ModelKind.LSTM_COUPLED, LOSS_WARP)):
+        hp = hparams(items, T, 128, int(kind), loss, epochs=1, B=B)
+        g, o = make_pair(hp)
+        assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+        assert_params_equal(g, o, kind, "wide addresses")
+
+
 @pytest.mark.parametrize("kind,loss,d,rt", [
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "2"),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "4"),

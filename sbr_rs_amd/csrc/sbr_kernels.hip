@@ -829,6 +829,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
     auto step = [&](int t) {
         __syncthreads();  // x_t staged, h_{t-1} written by the previous epilogue
         PROF_MARK(1)
+        __builtin_amdgcn_s_setprio(0);
         tid = thread_id();
         lane = tid & 63;
         j16 = lane & 15;
@@ -904,6 +905,10 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
         PROF_MARK(3)
         __syncthreads();  // every wave is done reading As
         PROF_MARK(4)
+        // the cell epilogue at a raised wave priority: it is the short, latency-sensitive phase between two MFMA phases, and
+        // the other resident workgroup's MFMA stream otherwise wins the issue arbitration against it (forward -1.8 %; the
+        // same in BPTT starves the key sort that runs beside it, so only here)
+        __builtin_amdgcn_s_setprio(3);
         tid = thread_id();
         lane = tid & 63;
         j16 = lane & 15;

@@ -286,7 +286,7 @@ typedef enum sbr_kernel_family {
     SBR_K_DENSE_UPDATE = 4,
     SBR_K_SPARSE_UPDATE = 5,
     SBR_K_RANK = 6,
-    SBR_K_SPARSE_SORT = 7, /* key build + radix sort of the sparse update (side stream, under the backward pass) */
+    SBR_K_SPARSE_SORT = 7, /* key ordering of the sparse update: radix passes + segment heads (sbr_sort.hip) */
     SBR_K_FAMILIES = 8
 } sbr_kernel_family;
 sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable);
@@ -306,6 +306,11 @@ sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_cell_h, floa
 sbr_status sbr_selftest_dot_tree(const float* x, const float* y, uint32_t d, uint64_t nrows, float* out);
 sbr_status sbr_selftest_mfma(const float* a, const float* b, const float* c0, uint32_t k, float* out,
                              const float* a32, const float* b32, float* out32);
+/* The sparse update's key ordering alone (sbr_sort.hip; ≙ the per-row visiting order of Optimizer::step over the sparse
+ * gradients, sequence_model.rs:163-169): out_keys[n] = (rows[e] << 32 | e) in (row, e) order, row ids below 2^row_bits;
+ * out_head_pos[*out_nheads + 1] = positions where a new row starts, then n. */
+sbr_status sbr_selftest_sort(const uint32_t* rows, uint64_t n, uint32_t row_bits, uint64_t* out_keys, uint32_t* out_head_pos,
+                             uint32_t* out_nheads);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,7 @@ def load():
         "sbr_selftest_math": [vp, C.c_uint64, vp, vp, vp],
         "sbr_selftest_dot_tree": [vp, vp, C.c_uint32, C.c_uint64, vp],
         "sbr_selftest_mfma": [vp, vp, vp, C.c_uint32, vp, vp, vp, vp],
+        "sbr_selftest_sort": [vp, C.c_uint64, C.c_uint32, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -120,5 +121,5 @@ DECLARED_SYMBOLS = [
     "sbr_fit_step_scatter_shared", "sbr_fit_step_owner_reduce_peers", "sbr_fit_step_apply_table_peers",
     "sbr_partition_part_info", "sbr_partition_export_part", "sbr_partition_import_part", "sbr_partition_finalize",
     "sbr_fit_lists_export", "sbr_fit_lists_import", "sbr_fit_step_reduce_own", "sbr_fit_step_owner_apply", "sbr_selftest_math",
-    "sbr_selftest_dot_tree", "sbr_selftest_mfma",
+    "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort",
 ]

@@ -1039,12 +1039,6 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         if (st == SBR_OK) st = dmalloc(&p->seg.Pf, units);
         if (st == SBR_OK) st = dmalloc(&p->seg.head_pos, max_entries + 1);
         if (st == SBR_OK) st = dmalloc(&p->seg.nheads, 1);
-        if (st == SBR_OK) {
-            p->seg.select_temp_bytes = sbr::sparse_select_temp_bytes(max_entries);
-            uint8_t* tmp = nullptr;
-            st = dmalloc(&tmp, p->seg.select_temp_bytes);
-            p->seg.select_temp = tmp;
-        }
     }
     if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
@@ -1085,7 +1079,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     hipFree(p->loss_acc); hipFree(p->ex_acc);
     hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
     hipFree(p->seg.P); hipFree(p->seg.Pb); hipFree(p->seg.Pf);
-    hipFree(p->seg.head_pos); hipFree(p->seg.nheads); hipFree(p->seg.select_temp);
+    hipFree(p->seg.head_pos); hipFree(p->seg.nheads);
     hipFree(p->glist); hipFree(p->gblist); hipFree(p->gfl); hipFree(p->bounds_dev);
     hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
     delete p;
@@ -1287,21 +1281,31 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * underneath the backward pass (WARP: the negatives come out of the score kernel) or, for the single-negative losses
      * whose negatives are a hash of the row counter, from the very start of the step (joined by step_apply / step_scatter). */
     hipStream_t side = m->overlap ? m->side : m->stream;
-    hipStream_t sorter = m->overlap ? m->sorter : m->stream;
+    /* Where the key ordering of a WARP step runs (its negatives come out of the score kernel).  SBR_SORT_PLACE:
+     *   stream  its own stream from the end of the score kernel on: it takes whatever slots the backward pass's retiring
+     *           workgroups free, and is finished by the time the update needs the keys
+     *   pre     the main stream between score and backward pass (its ~0.1-0.2 ms are then on the critical path)
+     *   post    the main stream right after the backward pass, beside the start of the dense-gradient GEMM */
+    static const char* place_env = std::getenv("SBR_SORT_PLACE");
+    enum { SORT_OWN_STREAM, SORT_PRE, SORT_POST };
+    const int place = !m->overlap ? SORT_PRE : !place_env ? SORT_OWN_STREAM : !std::strcmp(place_env, "pre") ? SORT_PRE : !std::strcmp(place_env, "post") ? SORT_POST : SORT_OWN_STREAM;
+    hipStream_t sorter = place == SORT_OWN_STREAM ? m->sorter : m->stream;
     const bool early_sort = m->hp.loss != SBR_LOSS_WARP && !std::getenv("SBR_NO_EARLY_SORT"); /* the variable is the A/B switch */
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
-    auto launch_sort = [&]() -> sbr_status {
-        HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* everything before: the previous step's readers of the keys, this step's score */
-        HIPCHK(hipStreamWaitEvent(sorter, m->ev_scored, 0));
+    auto launch_sort = [&](hipStream_t on) -> sbr_status {
+        if (on != m->stream) {
+            HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* everything before: the previous step's readers of the keys, this step's score */
+            HIPCHK(hipStreamWaitEvent(on, m->ev_scored, 0));
+        }
         {
-            ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, sorter);
-            sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, sorter,
+            ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, on);
+            sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, on,
                                  early_sort ? &mv : nullptr, epoch_key, m->hp.num_items);
         }
-        HIPCHK(hipEventRecord(m->ev_sorted, sorter));
+        HIPCHK(hipEventRecord(m->ev_sorted, on));
         return SBR_OK;
     };
-    if (early_sort) SBRCHK(launch_sort());
+    if (early_sort) SBRCHK(launch_sort(m->overlap ? m->sorter : m->stream));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
         sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
@@ -1311,7 +1315,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
     }
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
-    if (!early_sort) SBRCHK(launch_sort());
+    if (!early_sort && place != SORT_POST) SBRCHK(launch_sort(sorter));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
@@ -1325,6 +1329,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
         sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side);
     }
+    if (!early_sort && place == SORT_POST) SBRCHK(launch_sort(m->stream));
     HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = true;
     p->last_R = mb.R;
@@ -2379,6 +2384,30 @@ sbr_status sbr_selftest_mfma(const float* a, const float* b, const float* c0, ui
     HIPCHK(hipMemcpy(out, dout, 256 * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out32, dout32, 1024 * 4, hipMemcpyDeviceToHost));
     hipFree(da); hipFree(db); hipFree(dc); hipFree(dout); hipFree(da32); hipFree(db32); hipFree(dout32);
+    return SBR_OK;
+}
+
+/* keys (rows[e] << 32 | e), e = 0..n-1, in (row, e) order on the engine's own key ordering (sbr_sort.hip), and the
+ * positions at which a new row starts */
+sbr_status sbr_selftest_sort(const uint32_t* rows, uint64_t n, uint32_t row_bits, uint64_t* out_keys, uint32_t* out_head_pos,
+                             uint32_t* out_nheads) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return SBR_ERR_NO_DEVICE;
+    if (!rows || !out_keys || !out_head_pos || !out_nheads || n == 0 || n >= (1ull << 32) || row_bits == 0 || row_bits > 32)
+        return SBR_ERR_INVALID_ARGUMENT;
+    uint32_t *drows, *dheads, *dn;
+    uint64_t *dtmp, *dout;
+    uint8_t* temp;
+    SBRCHK(dmalloc(&drows, n)); SBRCHK(dmalloc(&dheads, n + 1)); SBRCHK(dmalloc(&dn, 1));
+    SBRCHK(dmalloc(&dtmp, n)); SBRCHK(dmalloc(&dout, n));
+    SBRCHK(dmalloc(&temp, sbr::sparse_sort_temp_bytes(n, 32 + (int)row_bits)));
+    HIPCHK(hipMemcpy(drows, rows, n * 4, hipMemcpyHostToDevice));
+    sbr::launch_selftest_sort(drows, (uint32_t)n, (int)row_bits, dtmp, dout, temp, dheads, dn, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out_keys, dout, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_nheads, dn, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_head_pos, dheads, ((uint64_t)*out_nheads + 1) * 4, hipMemcpyDeviceToHost));
+    hipFree(drows); hipFree(dheads); hipFree(dn); hipFree(dtmp); hipFree(dout); hipFree(temp);
     return SBR_OK;
 }
 

@@ -83,8 +83,6 @@ struct SegScratch {
      * the sentinel head_pos[*nheads] = number of keys; produced right after the sort, on its stream */
     uint32_t* head_pos;
     uint32_t* nheads;
-    void* select_temp;
-    size_t select_temp_bytes;
 };
 
 /* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
@@ -116,12 +114,12 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
                         int ndev, hipStream_t s);
 void launch_repack_lstm(const ModelView& m, hipStream_t s);
-/* sparse: keys of the device's own entries -> radix sort (needs only indices and negatives, so it runs
- * underneath the backward pass) -> per-row reduction in the contract's chunked order -> one of three
- * consumers: optimiser update (single device), the owners' dense send chunks (replicated multi-device),
- * the position-addressed list + owner bounds (partitioned table) */
+/* sparse: keys of the device's own entries in (row, entry) order + the list of segment heads (sbr_sort.hip: a
+ * stable LSD radix sort over the row bits, key_bits = 32 + bits of a row id; needs only indices and negatives) ->
+ * per-row reduction in the contract's chunked order -> one of three consumers: optimiser update (single device),
+ * the owners' dense send chunks (replicated multi-device), the position-addressed list + owner bounds
+ * (partitioned table).  `keys` is a scratch array of the same size as `keys_sorted`. */
 size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits);
-size_t sparse_select_temp_bytes(size_t max_entries);
 /* early_mb != null (single-negative losses): keys from the minibatch's index arrays and the negative-draw hash, i.e.
  * without waiting for the score kernel */
 void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
@@ -141,6 +139,10 @@ void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t sli
 void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
                              uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 /* accumulate loss/examples headers of all blocks into the plan accumulators */
+/* owner side of the partitioned table: (row, device, position) keys of the peers' list heads in that order
+ * (generated in (device, position) order, so again a stable sort on the row bits) */
+void launch_merge_sort(const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp,
+                       size_t sort_temp_bytes, hipStream_t s);
 void launch_accumulate_loss(const uint8_t* all_blocks, uint64_t block_bytes, int ndev, double* loss_acc,
                             unsigned long long* ex_acc, hipStream_t s);
 /* prediction side */
@@ -153,6 +155,9 @@ void launch_selftest_math(const float* x, float* out_cell_h, float* out_sig, flo
 void launch_selftest_dot_tree(const float* x, const float* y, int d, uint64_t nrows, float* out, hipStream_t s);
 void launch_selftest_mfma_chain(const float* a, const float* b, const float* c0, int k, float* out, hipStream_t s);
 void launch_selftest_mfma32_chain(const float* a, const float* b, int k, float* out, hipStream_t s);
+/* the key ordering alone: keys (rows[e] << 32 | e) of n entries in (row, e) order + segment heads */
+void launch_selftest_sort(const uint32_t* rows, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, void* temp, uint32_t* head_pos,
+                          uint32_t* nheads, hipStream_t s);
 
 }  // namespace sbr
 #endif

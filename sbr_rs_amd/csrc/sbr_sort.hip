@@ -1,0 +1,359 @@
+// sbr_sort.hip — key ordering of the sparse update on gfx950: the (row, entry) keys of a minibatch's
+// gradient entries in (row, entry) order plus the list of row-segment heads, hand-written.
+//
+// What is ordered.  Entry e = 3 r + kind of packed row r (kind 0 = input row -> dX, 1 = target row, 2 = sampled
+// negative) has the key (table row << 32) | e.  The optimiser visits every touched table row once and adds its
+// entries in entry order (sbr_numerics.h, SBR_SEG_CHUNK); that is sequence_model.rs:163-169's optimizer.step over the
+// sparse gradients of the graph (/root/reference/src/models/sequence_model.rs:160-169, lstm.rs:272-291).
+//
+// How.  The entries are GENERATED in entry order, so a STABLE sort on the row bits alone yields (row, entry) order:
+// an LSD radix sort over ceil(log2 num_items) bits — one pass of <= 11 bits for a MovieLens-size catalogue, two
+// 10-bit passes for 1e6 items, three for 1e7 — instead of a general 64-bit sort over all 52 key bits.  The first
+// pass reads the index arrays directly (no key array is materialised first).  Per pass:
+//   radix_hist     one wave per 4096-key tile: digit histogram in LDS (ds_add), written to counts[bin][tile]
+//   radix_binscan  one wave per bin: exclusive scan over the tiles (contiguous), bin totals
+//   radix_scatter  one wave per tile: bin bases (a 64-lane scan of the totals) + the tile's offsets into LDS, then the
+//                  keys in order, 64 at a time: lanes with equal digits find each other with one v_cmp ballot per
+//                  digit bit (no LDS atomics with a return value: the rank inside the wave is a population count, so the
+//                  order is the entry order by construction), the highest lane of a digit group advances its offset
+// and afterwards the segment heads (positions whose row differs from the previous key's) are listed in ascending
+// order by a count / scan / write triple over the same tiles.  Nothing here depends on dispatch order or on
+// forward progress of other workgroups, so the kernels can run beside the MFMA-bound kernels on another stream.
+// Everything is integer work: results are exact and identical to any other stable sort.
+
+#include "sbr_kernels.h"
+
+#include "../../include/sbr_hip.h"
+#include "sbr_numerics.h"
+
+namespace sbr {
+
+namespace {
+
+constexpr int SORT_ITEMS = 64;                 // keys per lane of a wave-tile
+constexpr int SORT_TILE = 64 * SORT_ITEMS;     // keys per wave-tile
+constexpr int SORT_BATCH = 8;                  // keys per lane requested together
+constexpr int SORT_MAX_DIGIT_BITS = 11;
+constexpr int SORT_WAVES = 4;                  // wave-tiles per workgroup
+
+struct PassPlan {
+    int passes;
+    int digit_bits;  // same width for every pass (>= 6: the scatter kernel scans the bin totals with 64 lanes)
+};
+inline PassPlan plan_passes(int row_bits) {
+    if (row_bits < 1) row_bits = 1;
+    if (row_bits > 32) row_bits = 32;
+    PassPlan p;
+    p.passes = (row_bits + SORT_MAX_DIGIT_BITS - 1) / SORT_MAX_DIGIT_BITS;
+    p.digit_bits = (row_bits + p.passes - 1) / p.passes;
+    if (p.digit_bits < 6) p.digit_bits = 6;
+    return p;
+}
+inline uint32_t tiles_of(uint64_t n) { return (uint32_t)((n + SORT_TILE - 1) / SORT_TILE); }
+
+// ---- key sources -------------------------------------------------------------------------------
+struct SrcBlock {  // a device's own entries after the score kernel has chosen the negatives
+    const uint32_t *in_idx, *out_idx, *neg;
+    __device__ __forceinline__ uint64_t operator()(uint32_t e) const {
+        const uint32_t r = e / 3u, kind = e - 3u * r;
+        const uint32_t* a = kind == 0 ? in_idx : (kind == 1 ? out_idx : neg);
+        return ((uint64_t)a[r] << 32) | e;
+    }
+};
+struct SrcEarly {  // single-negative losses: the negative is a hash of the row counter, known before the forward pass
+    const uint32_t *in_idx, *out_idx, *ctr;
+    uint64_t epoch_key;
+    uint32_t num_items;
+    __device__ __forceinline__ uint64_t operator()(uint32_t e) const {
+        const uint32_t r = e / 3u, kind = e - 3u * r;
+        const uint32_t row = kind == 0 ? in_idx[r] : (kind == 1 ? out_idx[r] : sbr_neg_draw(epoch_key, ctr[r], 0u, num_items));
+        return ((uint64_t)row << 32) | e;
+    }
+};
+struct SrcKeys {  // a key array (passes after the first)
+    const uint64_t* k;
+    __device__ __forceinline__ uint64_t operator()(uint32_t e) const { return k[e]; }
+};
+struct SrcRows {  // self-test: entry e of a plain row array
+    const uint32_t* rows;
+    __device__ __forceinline__ uint64_t operator()(uint32_t e) const { return ((uint64_t)rows[e] << 32) | e; }
+};
+struct SrcMerge {  // partitioned table: (row, device, position) of every list head in the owner's row range
+    PeerLists pl;
+    int ndev;
+    __device__ __forceinline__ uint64_t operator()(uint32_t i) const {
+        int r = 0;
+        while (r + 1 < ndev && i >= pl.base[r + 1]) ++r;
+        const uint32_t p = pl.lo[r] + (i - pl.base[r]);
+        return (pl.fl[r][p] & 1u) ? ((pl.keys[r][p] >> 32) << 32) | ((uint64_t)r << 28) | (uint64_t)p : ~0ull;
+    }
+};
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// ---- one radix pass ----------------------------------------------------------------------------
+template <class Src>
+__global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
+                                                                     uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
+    uint32_t* h = lds + (size_t)wave * nb;
+    for (uint32_t b = lane; b < nb; b += 64) h[b] = 0u;
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
+    const uint64_t base = (uint64_t)tile * SORT_TILE;
+    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+        uint64_t k[SORT_BATCH];
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t e = base + (uint64_t)(i0 + j) * 64 + lane;
+            k[j] = e < n ? src((uint32_t)e) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t e = base + (uint64_t)(i0 + j) * 64 + lane;
+            if (e < n) atomicAdd(&h[((uint32_t)(k[j] >> 32) >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    if (tile < ntiles)
+        for (uint32_t b = lane; b < nb; b += 64) counts[(size_t)b * ntiles + tile] = h[b];
+}
+
+// one wave per bin: exclusive scan of the bin's tile counts (in place) and the bin total
+__global__ __launch_bounds__(256) void radix_binscan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t nb,
+                                                            uint32_t* __restrict__ bintotal) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t bin = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (bin >= nb) return;
+    uint32_t* row = counts + (size_t)bin * ntiles;
+    uint32_t running = 0;
+    constexpr int U = 8;  // 512 tiles' counts requested together
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64 * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u * 64 + lane;
+            v[u] = t < ntiles ? row[t] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + u * 64 + lane;
+            const uint32_t incl = wave_inclusive_scan(v[u], lane);
+            if (t < ntiles) row[t] = running + incl - v[u];
+            running += (uint32_t)__shfl((int)incl, 63, 64);
+        }
+    }
+    if (lane == 0) bintotal[bin] = running;
+}
+
+template <class Src>
+__global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
+                                                                        const uint32_t* __restrict__ counts,
+                                                                        const uint32_t* __restrict__ bintotal, uint64_t* __restrict__ out) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
+    uint32_t* h = lds + (size_t)wave * nb;
+    const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
+    const uint32_t tt = tile < ntiles ? tile : ntiles - 1;  // surplus waves compute on a valid tile and store nothing
+    {   // h[bin] = (keys of lower bins) + (keys of this bin in earlier tiles): lane l owns bins l*per .. l*per + per - 1
+        const uint32_t per = nb >> 6;
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; ++j) sum += bintotal[lane * per + j];
+        uint32_t run = wave_inclusive_scan(sum, lane) - sum;
+        for (uint32_t j = 0; j < per; ++j) {
+            const uint32_t b = lane * per + j;
+            h[b] = run + counts[(size_t)b * ntiles + tt];
+            run += bintotal[b];
+        }
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t)tile * SORT_TILE;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+        uint64_t k[SORT_BATCH];
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t e = base + (uint64_t)(i0 + j) * 64 + lane;
+            k[j] = (tile < ntiles && e < n) ? src((uint32_t)e) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t e = base + (uint64_t)(i0 + j) * 64 + lane;
+            const bool valid = tile < ntiles && e < n;
+            const uint32_t d = ((uint32_t)(k[j] >> 32) >> shift) & mask;
+            uint64_t same = __ballot(valid);  // lanes of this round that hold the same digit
+            for (int b = 0; b < digit_bits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t vote = __ballot(bit);
+                same &= bit ? vote : ~vote;
+            }
+            if (valid) {
+                const uint32_t pos = h[d] + (uint32_t)__popcll(same & lt);
+                out[pos] = k[j];
+                if ((same >> lane) == 1ull) h[d] += (uint32_t)__popcll(same);  // the group's highest lane, after every lane's read
+            }
+        }
+    }
+}
+
+// ---- segment heads -----------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(SORT_WAVES * 64) void head_tiles_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t ntiles,
+                                                                     uint32_t* __restrict__ tile_heads, uint32_t* __restrict__ head_pos) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
+    if (tile >= ntiles) return;
+    const uint64_t base = (uint64_t)tile * SORT_TILE;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t off = WRITE ? tile_heads[tile] : 0u;
+    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+        uint32_t row[SORT_BATCH], prev[SORT_BATCH];
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t p = base + (uint64_t)(i0 + j) * 64 + lane;
+            row[j] = p < n ? (uint32_t)(keys[p] >> 32) : 0u;
+            prev[j] = (p < n && p > 0) ? (uint32_t)(keys[p - 1] >> 32) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < SORT_BATCH; ++j) {
+            const uint64_t p = base + (uint64_t)(i0 + j) * 64 + lane;
+            const bool head = p < n && (p == 0 || row[j] != prev[j]);
+            const uint64_t m = __ballot(head);
+            if (WRITE && head) head_pos[off + (uint32_t)__popcll(m & lt)] = (uint32_t)p;
+            off += (uint32_t)__popcll(m);
+        }
+    }
+    if (!WRITE && lane == 0) tile_heads[tile] = off;
+}
+
+// exclusive scan of the tiles' head counts (in place), the head count and the sentinel head_pos[nheads] = n
+__global__ __launch_bounds__(1024) void head_scan_kernel(uint32_t* __restrict__ tile_heads, uint32_t ntiles, uint32_t n,
+                                                         uint32_t* __restrict__ nheads, uint32_t* __restrict__ head_pos) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < ntiles ? tile_heads[t] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w2 = 0; w2 < wave; ++w2) before += s_wave[w2];
+        if (t < ntiles) tile_heads[t] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *nheads = s_carry;
+        head_pos[s_carry] = n;
+    }
+}
+
+struct Scratch {
+    uint32_t *counts, *bintotal, *tile_heads;
+};
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline Scratch carve(void* temp, size_t max_entries, int row_bits) {
+    const PassPlan pp = plan_passes(row_bits);
+    const size_t nb = (size_t)1 << pp.digit_bits, nt = tiles_of(max_entries) + 1;
+    uint8_t* p = reinterpret_cast<uint8_t*>(temp);
+    Scratch s;
+    s.counts = reinterpret_cast<uint32_t*>(p);
+    p += align256(nb * nt * 4);
+    s.bintotal = reinterpret_cast<uint32_t*>(p);
+    p += align256(nb * 4);
+    s.tile_heads = reinterpret_cast<uint32_t*>(p);
+    return s;
+}
+
+// stable sort of n generated keys by their row bits: first pass from `first`, later passes between the two buffers,
+// the last pass always writes `out`
+template <class Src>
+void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
+    const PassPlan pp = plan_passes(row_bits);
+    const uint32_t ntiles = tiles_of(n), nb = 1u << pp.digit_bits;
+    const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
+    const size_t lds = (size_t)SORT_WAVES * nb * 4;
+    for (int p = 0; p < pp.passes; ++p) {
+        const int shift = p * pp.digit_bits;
+        uint64_t* dst = ((pp.passes - 1 - p) & 1) ? tmp : out;
+        const uint64_t* from = dst == out ? tmp : out;
+        if (p == 0) {
+            hipLaunchKernelGGL((radix_hist_kernel<Src>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts);
+        } else {
+            hipLaunchKernelGGL((radix_hist_kernel<SrcKeys>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
+                               sc.counts);
+        }
+        hipLaunchKernelGGL(radix_binscan_kernel, dim3((nb * 64 + 255) / 256), dim3(256), 0, s, sc.counts, ntiles, nb, sc.bintotal);
+        if (p == 0) {
+            hipLaunchKernelGGL((radix_scatter_kernel<Src>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts,
+                               sc.bintotal, dst);
+        } else {
+            hipLaunchKernelGGL((radix_scatter_kernel<SrcKeys>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
+                               sc.counts, sc.bintotal, dst);
+        }
+    }
+}
+
+void list_heads(const uint64_t* keys_sorted, uint32_t n, const Scratch& sc, uint32_t* head_pos, uint32_t* nheads, hipStream_t s) {
+    const uint32_t ntiles = tiles_of(n);
+    const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
+    hipLaunchKernelGGL((head_tiles_kernel<false>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+    hipLaunchKernelGGL(head_scan_kernel, dim3(1), dim3(1024), 0, s, sc.tile_heads, ntiles, n, nheads, head_pos);
+    hipLaunchKernelGGL((head_tiles_kernel<true>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+}
+
+}  // namespace
+
+size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits) {
+    const int row_bits = key_bits - 32;
+    const PassPlan pp = plan_passes(row_bits);
+    const size_t nb = (size_t)1 << pp.digit_bits, nt = tiles_of(max_entries) + 1;
+    return align256(nb * nt * 4) + align256(nb * 4) + align256((nt + 1) * 4);
+}
+
+void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, uint64_t* keys_sorted, void* sort_temp,
+                     size_t sort_temp_bytes, int key_bits, const SegScratch& sc, hipStream_t s, const MbView* early_mb,
+                     uint64_t epoch_key, uint32_t num_items) {
+    (void)sort_temp_bytes;
+    if (rows_host == 0) return;
+    const uint32_t total = 3u * rows_host;
+    const int row_bits = key_bits - 32;
+    const Scratch scr = carve(sort_temp, total, row_bits);
+    if (early_mb)
+        radix_sort(SrcEarly{early_mb->in_idx, early_mb->out_idx, early_mb->ctr, epoch_key, num_items}, total, row_bits, keys, keys_sorted, scr, s);
+    else
+        radix_sort(SrcBlock{blk.in_idx, blk.out_idx, blk.neg}, total, row_bits, keys, keys_sorted, scr, s);
+    list_heads(keys_sorted, total, scr, sc.head_pos, sc.nheads, s);
+}
+
+void launch_merge_sort(const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp,
+                       size_t sort_temp_bytes, hipStream_t s) {
+    (void)sort_temp_bytes;
+    if (total == 0) return;
+    radix_sort(SrcMerge{pl, ndev}, total, 32, mkeys, mkeys_sorted, carve(sort_temp, total, 32), s);
+}
+
+void launch_selftest_sort(const uint32_t* rows, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, void* temp, uint32_t* head_pos,
+                          uint32_t* nheads, hipStream_t s) {
+    if (n == 0) return;
+    const Scratch scr = carve(temp, n, row_bits);
+    radix_sort(SrcRows{rows}, n, row_bits, tmp, out, scr, s);
+    list_heads(out, n, scr, head_pos, nheads, s);
+}
+
+}  // namespace sbr

@@ -72,3 +72,34 @@ def test_mfma_is_fma_chain(L, k):
     ref32 = oracle.fma_chain_gemm(a32, b32)
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(out32.view(np.uint32), ref32.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,row_bits,dist", [
+    (1, 11, "uniform"), (63, 11, "uniform"), (381, 11, "uniform"), (4096, 11, "uniform"), (4097, 6, "uniform"),
+    (100_000, 11, "zipf"), (300_001, 20, "uniform"), (1_500_000, 20, "zipf"), (700_000, 24, "uniform"),
+    (50_000, 32, "uniform"), (20_000, 3, "uniform"), (123_457, 17, "one_row"),
+])
+def test_key_ordering_is_a_stable_sort_by_row(L, n, row_bits, dist):
+    """sbr_sort.hip against numpy's stable argsort: keys (row << 32 | e) in (row, e) order — one, two and three radix passes,
+    ragged last tiles, hot rows, a single row — and the ascending list of segment heads with its sentinel."""
+    rs = np.random.RandomState(n % 9973 + row_bits)
+    hi = (1 << row_bits) if row_bits < 32 else (1 << 32) - 1
+    if dist == "uniform":
+        rows = rs.randint(0, hi, size=n, dtype=np.int64)
+    elif dist == "zipf":
+        rows = np.minimum(rs.zipf(1.3, size=n) - 1, hi - 1)
+    else:
+        rows = np.full(n, hi - 1, dtype=np.int64)
+    rows = rows.astype(np.uint32)
+    keys = np.zeros(n, np.uint64)
+    heads = np.zeros(n + 1, np.uint32)
+    nheads = np.zeros(1, np.uint32)
+    assert L.sbr_selftest_sort(_p(rows), n, row_bits, _p(keys), _p(heads), _p(nheads)) == 0
+    order = np.argsort(rows, kind="stable")
+    want = (rows[order].astype(np.uint64) << np.uint64(32)) | order.astype(np.uint64)
+    assert np.array_equal(keys, want)
+    srt = rows[order]
+    want_heads = np.flatnonzero(np.concatenate([[True], srt[1:] != srt[:-1]])).astype(np.uint32)
+    assert int(nheads[0]) == want_heads.size
+    assert np.array_equal(heads[: want_heads.size], want_heads)
+    assert int(heads[want_heads.size]) == n

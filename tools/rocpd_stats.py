@@ -7,7 +7,7 @@ import sys
 
 
 def short(name: str) -> str:
-    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
     name = name.replace("void ", "").replace("sbr::", "")
     name = re.sub(r"rocprim::[a-z_:]*detail::", "rocprim::", name)
     return name[:100]

@@ -18,7 +18,7 @@ def main():
     t0 = rows[a][1]
     print(f"step {which}: {(rows[b][1] - t0) / 1e6:.3f} ms from forward launch to forward launch; columns: start ms, duration ms, queue, kernel")
     for r in rows[a:b]:
-        name = re.sub(r"\(.*$", "", r[0]).replace("void ", "").replace("sbr::", "")
+        name = re.sub(r"\(.*$", "", r[0].replace("(anonymous namespace)::", "")).replace("void ", "").replace("sbr::", "")
         name = re.sub(r"rocprim::[A-Za-z_0-9:]*detail::", "rocprim::", name)[:70]
         print(f"{(r[1] - t0) / 1e6:9.3f} {(r[2] - r[1]) / 1e6:8.3f}  q{r[3] if qcol else '-'}  {name}")
 

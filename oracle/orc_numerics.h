@@ -30,7 +30,6 @@
 
 #define ORC_WARP_TRIES 5        /* `for _ in 0..5`, sequence_model.rs:58 */
 #define ORC_DW_CHUNK_ROWS 1024  /* dense-gradient split: rows per chunk partial */
-#define ORC_DW_GROUP_CHUNKS 8   /* chunk partials are summed in order inside groups of this many chunks, the group sums in order */
 #define ORC_SEG_CHUNK 256       /* sparse-gradient split: entries per chunk partial */
 #define ORC_EWMA_CHUNK_SEQS 256
 #define ORC_F32_MIN (-3.40282347e+38f) /* std::f32::MIN, evaluation.rs:31 */

@@ -579,8 +579,7 @@ static void orc_lagged_loss_update(orc_plan* p, int q) {
 
 /* BPTT (≙ loss.backward(1.0), sequence_model.rs:161) + dense gradient of this device.
  * Dense reduction order: packed rows are cut into chunks of ORC_DW_CHUNK_ROWS; inside a chunk a
- * row-ascending fma chain from 0; the partials of ORC_DW_GROUP_CHUNKS consecutive chunks are added in
- * chunk order (the first one initialises), and the group sums are added in group order (likewise). */
+ * row-ascending fma chain from 0; chunk partials added in chunk order. */
 static void orc_backward(orc_model* m, orc_local* L) {
     int d = m->d, ng = m->ng, coupled = m->hp.model == SBR_MODEL_LSTM_COUPLED;
     if (ng) {
@@ -623,7 +622,6 @@ static void orc_backward(orc_model* m, orc_local* L) {
         /* dense: dW[k][j] = sum_r xh[r][k] dz[r][j]; row 2d = bias grad = sum_r dz[r][j] */
         size_t nd = (size_t)(2 * d + 1) * nz;
         float* part = (float*)malloc(sizeof(float) * nd);
-        float* group = (float*)malloc(sizeof(float) * nd);
         for (size_t i = 0; i < nd; ++i) L->dense[i] = 0.0f;
         int nchunks = (L->R + ORC_DW_CHUNK_ROWS - 1) / ORC_DW_CHUNK_ROWS;
         /* row -> (t, b) lookup */
@@ -651,14 +649,10 @@ static void orc_backward(orc_model* m, orc_local* L) {
                 float* pb = part + (size_t)2 * d * nz;
                 for (int j = 0; j < nz; ++j) pb[j] = pb[j] + dz[j];
             }
-            if (c % ORC_DW_GROUP_CHUNKS == 0) for (size_t i = 0; i < nd; ++i) group[i] = part[i];
-            else for (size_t i = 0; i < nd; ++i) group[i] = group[i] + part[i];
-            if (c % ORC_DW_GROUP_CHUNKS == ORC_DW_GROUP_CHUNKS - 1 || c == nchunks - 1) { /* the group is complete */
-                if (c / ORC_DW_GROUP_CHUNKS == 0) for (size_t i = 0; i < nd; ++i) L->dense[i] = group[i];
-                else for (size_t i = 0; i < nd; ++i) L->dense[i] = L->dense[i] + group[i];
-            }
+            if (c == 0) for (size_t i = 0; i < nd; ++i) L->dense[i] = part[i];
+            else for (size_t i = 0; i < nd; ++i) L->dense[i] = L->dense[i] + part[i];
         }
-        free(row_t); free(part); free(group); free(WT); free(dxh); free(dh_rec); free(dc_rec);
+        free(row_t); free(part); free(WT); free(dxh); free(dh_rec); free(dc_rec);
     } else {
         /* EWMA: ds_t = dH_t + a*ds_{t+1}; dX_t = (1-a)*ds_t (t>0) / ds_0; per-sequence partial
          * da_b = chain over t descending of fma(ds_t, s_{t-1} - x_t, .); sequences reduced in

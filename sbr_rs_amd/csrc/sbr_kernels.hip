@@ -7,7 +7,7 @@
 //                             (an f32 MFMA is a k-ordered fmaf chain on gfx950)
 //   * dense gradients       : v_mfma_f32_32x32x2_f32 over fixed 1024-row chunks, chunk partials
 //                             added in chunk order
-//   * sparse row gradients  : radix sort of (row, source) keys, per-row in-order reduction,
+//   * sparse row gradients  : (row, source) keys in key order (sbr_sort.hip), per-row in-order reduction,
 //                             one Adagrad read-modify-write per touched row
 // Reference call sites replaced: the wyrm graph built by Parameters::build
 // (/root/reference/src/models/lstm.rs:258-337, ewma.rs:266-352), driven by fit_sequence_model
@@ -57,9 +57,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
  * four workgroups per CU) measured 1-3 % ahead of 32 alone and beside the sparse update, 64 (two workgroups per CU) 10 % behind */
 #ifndef SBR_DW_SLAB
 #define SBR_DW_SLAB 16
-#endif
-#ifndef SBR_DW_DEPTH
-#define SBR_DW_DEPTH 8 /* k-steps (row pairs) a wave of the group-resident dense-gradient kernel requests ahead of its MFMAs */
 #endif
 #ifndef SBR_BWD256_MIN_TILES
 #define SBR_BWD256_MIN_TILES 320
@@ -1688,224 +1685,19 @@ __global__ __launch_bounds__(256, SBR_DW_WPE) void lstm_dw_full_kernel(ModelView
         }
 }
 
-// Sequence-free form of the same product for full 128x128 tiles: NO LDS, NO barriers.  An f32 MFMA takes 64 cycles for
-// 2 k-steps of a 32x32 tile, i.e. it consumes ONE A and ONE B float per lane per 64 cycles — so little operand bandwidth
-// that the operands can come straight from global memory into the MFMA's source registers: both operands are
-// "k-major" here (k = packed row; a row of xh = [x ; h_prev] and a row of dz are contiguous), and the 32x32x2 operand
-// layout is (lane & 31) -> column, (lane >> 5) -> k, so one 8-byte load per lane brings, for rows 2s and 2s+1, the
-// columns 2l and 2l+1 of a 64-column block: the even columns feed one MFMA tile, the odd columns the other (the output
-// tile is a column permutation that only the final store has to know about).  A wave owns a 64x64 output tile (2x2
-// MFMAs per k-step, 2 loads), four waves (2x2) a workgroup's 128x128 tile — they share nothing but the L1 — and every
-// wave runs a DEPTH-deep register ring of requests ahead of its MFMAs, with static wait counts.
-// The reduction order is the contract's (sbr_numerics.h): a chunk partial P is the MFMA chain from 0 over the chunk's
-// 1024 rows; the partials of a GROUP of 8 consecutive chunks are added in order (T = P, T += P ...), and a workgroup
-// that owns a whole group keeps T in registers and writes ONE partial per group (an eighth of the partial traffic of
-// the per-chunk form, and an eighth of the ordered reduction that follows).  Units = (tile, chunk range inside one
-// group): whole groups first, and the groups that would form a ragged last round are cut into single-chunk units
-// (same bits: their partials are added by the reduction kernel in the same order).
-struct DwPlan {
-    int gsplit;       /* groups [0, gsplit) are whole-group units, the chunks of the remaining groups single-chunk units */
-    int nch;          /* chunks of the minibatch */
-    int full_blocks;  /* workgroups of the whole-group part of the grid (a multiple of 8 * tiles) */
-    int hbase_rows;   /* sequences of the minibatch: prev_row[r] >= r - hbase_rows */
-};
-template <int D, int NG, int DEPTH, bool XPART>
-__device__ __forceinline__ void dw_group_body(const MbView& mb, const BlockView& blk, const WorkView& w, const DwPlan& plan) {
-    constexpr int K2 = 2 * D;
-    constexpr int NGD = NG * D;
-    constexpr int TJ = NGD / 128;
-    constexpr int NTILE = (K2 / 128) * TJ;
-    constexpr int G = SBR_DW_GROUP_CHUNKS;
-    constexpr int KSTEPS = SBR_DW_CHUNK_ROWS / 2;  // k-steps (row pairs) per chunk
-    static_assert(K2 % 128 == 0 && NGD % 128 == 0 && D % 64 == 0, "full tiles only");
-    static_assert(KSTEPS % DEPTH == 0 && ((KSTEPS / DEPTH) & (KSTEPS / DEPTH - 1)) == 0, "the ring divides a chunk into a power-of-two number of rounds");
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave >> 1, wj = wave & 1;
-    const int l31 = lane & 31, hh = lane >> 5;
-    // unit of this workgroup; XCD-aware order: all tiles of a group / chunk on one XCD (see lstm_dw_kernel)
-    int tile, c0, c1, slot;
-    {
-        const int wid = blockIdx.x;
-        if (wid < plan.full_blocks) {
-            tile = (wid >> 3) % NTILE;
-            const int g = (wid >> 3) / NTILE * 8 + (wid & 7);
-            if (g >= plan.gsplit) return;
-            c0 = g * G; c1 = c0 + G; slot = g;
-        } else {
-            const int w2 = wid - plan.full_blocks;
-            tile = (w2 >> 3) % NTILE;
-            const int c = plan.gsplit * G + (w2 >> 3) / NTILE * 8 + (w2 & 7);
-            if (c >= plan.nch) return;
-            c0 = c; c1 = c + 1; slot = plan.gsplit + (c - plan.gsplit * G);
-        }
-    }
-    const int tk = tile / TJ, tj = tile % TJ;
-    const int acol = tk * 128 + wk * 64 + 2 * l31;  // this lane's two xh columns
-    const int jcol = tj * 128 + wj * 64 + 2 * l31;  // and its two dz columns
-    constexpr bool xpart = XPART;                   // wave-uniform: the 64-column block lies in the x or in the h half
-    const bool do_bias = tk == 0 && wk == 0;        // these waves also carry the bias-gradient row of their 64 dz columns
-    const int r_begin = c0 * SBR_DW_CHUNK_ROWS;
-    int r_end = c1 * SBR_DW_CHUNK_ROWS;
-    if (r_end > mb.R) r_end = mb.R;
-    const int live = r_end - r_begin;  // rows of the unit that exist; loads past them are out of range and return zeros
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(w.dZ + (size_t)r_begin * NGD), (short)0, live * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(w.X + (size_t)r_begin * D), (short)0, live * D * 4, SBR_BUFFER_RSRC_FLAGS);
-    // previous-hidden rows: prev_row[r] lies in [r - sequences, r), so a window of H that starts `sequences` rows before
-    // the unit covers them with 32-bit byte offsets whatever the size of H
-    const int hbase = r_begin > plan.hbase_rows ? r_begin - plan.hbase_rows : 0;
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)(blk.H + (size_t)hbase * D), (short)0, (r_end - hbase) * D * 4, SBR_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(mb.prev_row + r_begin), (short)0, live * 4, SBR_BUFFER_RSRC_FLAGS);
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    f2 ra[DEPTH], rb[DEPTH];
-    const int vX = (hh * D + acol) * 4, vZ = (hh * NGD + jcol) * 4, vHc = (acol - D) * 4;
-    int pv = 0, pv_next = 0;  // prev_row of the 2 * DEPTH rows of a ring round, one row per lane (lanes 0 .. 2*DEPTH-1)
-    auto load_prev = [&](int round) {  // rows past the unit read as 0: a valid row that meets zeros in dz
-        return (int)__builtin_amdgcn_raw_buffer_load_b32(rsP, (lane & (2 * DEPTH - 1)) * 4, round * 2 * DEPTH * 4, 0);
-    };
-    auto load_step = [&](int j, int s, int prevs) {  // operands of k-step s (rows 2s, 2s+1 of the unit) into ring slot j
-        if (xpart) {
-            ra[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsX, vX, s * 2 * D * 4, 0));
-        } else {
-            const int p0 = __builtin_amdgcn_readlane(prevs, 2 * j), p1 = __builtin_amdgcn_readlane(prevs, 2 * j + 1);
-            const int pr = hh ? p1 : p0;  // first-step rows (-1) and rows below the window become out-of-range offsets: zeros
-            const unsigned off = pr >= hbase ? (unsigned)(pr - hbase) * (unsigned)(D * 4) + (unsigned)vHc : 0xFFFFFFF0u;
-            ra[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsH, (int)off, 0, 0));
-        }
-        rb[j] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rsZ, vZ, s * 2 * NGD * 4, 0));
-    };
-    f32x16 P[2][2], T[2][2];
-    float pb[2] = {0.f, 0.f}, tb[2] = {0.f, 0.f};
-    auto clear_p = [&]() {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) P[a][b][q] = 0.0f;
-        pb[0] = pb[1] = 0.0f;
-    };
-    auto mma_step = [&](int j) {
-        P[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].x, rb[j].x, P[0][0], 0, 0, 0);
-        P[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].x, rb[j].y, P[0][1], 0, 0, 0);
-        P[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].y, rb[j].x, P[1][0], 0, 0, 0);
-        P[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j].y, rb[j].y, P[1][1], 0, 0, 0);
-        if (do_bias) {  // bias row: plain add chain over the rows — row 2s sits in the lower half-wave, row 2s+1 in the upper
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const unsigned v = __builtin_bit_cast(unsigned, b ? rb[j].y : rb[j].x);
-                const u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {lower half's value, upper half's value}
-                pb[b] = (pb[b] + __uint_as_float(r.x)) + __uint_as_float(r.y);
-            }
-        }
-    };
-    clear_p();
-    if (!xpart) pv = load_prev(0);
-    if (!xpart) pv_next = load_prev(1);
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) load_step(j, j, pv);
-    // ONE loop over the ring rounds of all the unit's chunks (a loop per chunk would put a loop header — where the
-    // compiler must assume the shortest history, i.e. drain every request — at each chunk boundary); the end-of-chunk
-    // work is register arithmetic under a branch
-    constexpr int ROUNDS = KSTEPS / DEPTH;  // ring rounds per chunk
-    const int nrounds = (c1 - c0) * ROUNDS;
-    int s0 = 0;  // first k-step of the ring round in flight
-    // an explicit drain of the prologue's requests (once per unit): the loop header then merges "nothing outstanding" with
-    // the back edge's history, and every wait inside the loop gets its exact steady-state count
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
-#pragma unroll 1
-    for (int it = 0; it < nrounds; ++it) {
-        const int prevs = pv_next;  // prev rows of the round requested below (round it + 1)
-        if (!xpart) pv_next = load_prev(it + 2);
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            mma_step(j);
-            __builtin_amdgcn_sched_barrier(0);
-            load_step(j, s0 + DEPTH + j, prevs);  // past the unit's last row: out of range, zeros, never consumed
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        s0 += DEPTH;
-        if ((it & (ROUNDS - 1)) == ROUNDS - 1) {  // the chunk is complete: T = P for the group's first chunk, T += P afterwards
-            if (it < ROUNDS) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) T[a][b] = P[a][b];
-                tb[0] = pb[0]; tb[1] = pb[1];
-            } else {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) T[a][b][q] = T[a][b][q] + P[a][b][q];
-                tb[0] = tb[0] + pb[0]; tb[1] = tb[1] + pb[1];
-            }
-            clear_p();
-        }
-    }
-    float* part = w.partials + (size_t)slot * (K2 + 1) * NGD;
-    const int jout = tj * 128 + wj * 64 + 2 * l31;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = tk * 128 + wk * 64 + 2 * ((q & 3) + 8 * (q >> 2) + 4 * hh) + a;
-            *reinterpret_cast<float2*>(part + (size_t)k * NGD + jout) = make_float2(T[a][0][q], T[a][1][q]);
-        }
-    if (do_bias && hh == 0) *reinterpret_cast<float2*>(part + (size_t)K2 * NGD + jout) = make_float2(tb[0], tb[1]);
-}
-template <int D, int NG, int DEPTH>
-__global__ __launch_bounds__(256, 2) void lstm_dw_group_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, DwPlan plan) {
-    // the unit's tile decides whether this WAVE streams x columns or previous-hidden columns: two instances of the body, so
-    // that neither carries a branch around a memory operation (the wait counts stay static)
-    constexpr int TJ = NG * D / 128;
-    constexpr int NTILE = (2 * D / 128) * TJ;
-    const int wid = blockIdx.x < plan.full_blocks ? blockIdx.x : blockIdx.x - plan.full_blocks;
-    const int tk = ((wid >> 3) % NTILE) / TJ;
-    const int wk = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >> 1;
-    if (tk * 128 + wk * 64 < D) dw_group_body<D, NG, DEPTH, true>(mb, blk, w, plan);
-    else dw_group_body<D, NG, DEPTH, false>(mb, blk, w, plan);
-}
-
-// ordered reduction of the dense-gradient partials: slots [0, gsplit) hold whole-group sums, the slots after them one
-// chunk each (the chunks gsplit * G ... nch - 1, whose groups are summed here, in chunk order, before they join the total)
-__global__ void dense_reduce_local_kernel(const float* partials, int gsplit, int nchunks, size_t n, float* dense) {
+__global__ void dense_reduce_local_kernel(const float* partials, int nchunks, size_t n, float* dense) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    constexpr int G = SBR_DW_GROUP_CHUNKS;
-    float acc = 0.0f;
-    bool first = true;
-    int g = 0;
-    for (; g + 8 <= gsplit; g += 8) { /* loads run ahead of the ordered add chain */
+    float acc = partials[i];
+    int c = 1;
+    for (; c + 8 <= nchunks; c += 8) { /* loads run ahead of the ordered add chain */
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = partials[(size_t)(g + j) * n + i];
+        for (int j = 0; j < 8; ++j) v[j] = partials[(size_t)(c + j) * n + i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc = first ? v[j] : acc + v[j];
-            first = false;
-        }
+        for (int j = 0; j < 8; ++j) acc = acc + v[j];
     }
-    for (; g < gsplit; ++g) {
-        const float v = partials[(size_t)g * n + i];
-        acc = first ? v : acc + v;
-        first = false;
-    }
-    for (int c0 = gsplit * G; c0 < nchunks; c0 += G) { /* groups that arrive as single chunks */
-        const int c1 = c0 + G < nchunks ? c0 + G : nchunks;
-        float v[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) v[j] = c0 + j < c1 ? partials[(size_t)(gsplit + (c0 + j - gsplit * G)) * n + i] : 0.0f;
-        float gs = v[0];
-#pragma unroll
-        for (int j = 1; j < G; ++j)
-            if (c0 + j < c1) gs = gs + v[j];
-        acc = first ? gs : acc + gs;
-        first = false;
-    }
+    for (; c < nchunks; ++c) acc = acc + partials[(size_t)c * n + i];
     dense[i] = acc;
 }
 
@@ -2869,62 +2661,29 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
-    const size_t n = (size_t)(K2 + 1) * NGD;
-    int gsplit = 0; /* whole-group partials in slots [0, gsplit), then one slot per chunk */
-    bool done = false;
-    /* SBR_DW_KERNEL = staged (the LDS-staged per-chunk kernel) | group (default where it applies): the A/B and test switch */
-    static const char* which = std::getenv("SBR_DW_KERNEL");
-    const bool want_group = !(which && which[0] == 's') && !w.wide_addresses;
     DISPATCH_D(m.d, {
+        const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
-        /* the H window of a unit (sequences + one group of rows) must stay below 2 GiB of byte offsets */
-        const bool window_ok = ((size_t)b_host + (size_t)SBR_DW_GROUP_CHUNKS * SBR_DW_CHUNK_ROWS) * DD * 4 < ((size_t)1 << 31);
-        if constexpr (DD % 64 == 0 && (full4 || full3)) {
-            if (want_group && window_ok && ((m.ng == 4 && full4) || (m.ng == 3 && full3))) {
-                /* whole rounds of whole-group units; the groups of the ragged last round go as single-chunk units */
-                static const int slots = 256 * 2; /* resident workgroups: two per CU */
-                const int ngroups_full = nch / SBR_DW_GROUP_CHUNKS;
-                static const char* max_rounds_env = std::getenv("SBR_DW_FULL_ROUNDS"); /* A/B: cap on the whole-group rounds */
-                int rounds = ngroups_full * tiles / slots;
-                if (max_rounds_env && rounds > std::atoi(max_rounds_env)) rounds = std::atoi(max_rounds_env);
-                gsplit = rounds * slots / tiles;
-                DwPlan plan;
-                plan.gsplit = gsplit;
-                plan.nch = nch;
-                plan.full_blocks = (gsplit + 7) / 8 * 8 * tiles;
-                plan.hbase_rows = b_host;
-                const int rest = nch - gsplit * SBR_DW_GROUP_CHUNKS;
-                const unsigned grid = (unsigned)(plan.full_blocks + (rest + 7) / 8 * 8 * tiles);
-                if (m.ng == 4) {
-                    if constexpr (full4) hipLaunchKernelGGL((lstm_dw_group_kernel<DD, 4, SBR_DW_DEPTH>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, plan);
-                } else {
-                    if constexpr (full3) hipLaunchKernelGGL((lstm_dw_group_kernel<DD, 3, SBR_DW_DEPTH>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, plan);
-                }
-                done = true;
-            }
-        }
-        if (!done) {
-            const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
-            /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */
-            const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
-            if (m.ng == 4) {
-                if constexpr (full4) {
-                    if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
-                    hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
-                } else {
-                    hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
-                }
+        /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */
+        const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
+        if (m.ng == 4) {
+            if constexpr (full4) {
+                if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
+                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
             } else {
-                if constexpr (full3) {
-                    if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
-                    hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
-                } else {
-                    hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
-                }
+                hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            }
+        } else {
+            if constexpr (full3) {
+                if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
+                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+            } else {
+                hipLaunchKernelGGL((lstm_dw_kernel<DD, 3>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
             }
         }
     });
-    hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, gsplit, nch, n, blk.dense);
+    const size_t n = (size_t)(K2 + 1) * NGD;
+    hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
 }
 
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,

@@ -47,6 +47,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_FWD_RT4_MIN_TILES
 #define SBR_FWD_RT4_MIN_TILES 1500
 #endif
+#ifndef SBR_SEQ_RT1_MAX_TILES
+/* Below this many 32-sequence tiles the recurrent kernels take 16-SEQUENCE tiles (96 / 80 registers per wave): with few tiles
+ * the kernel time is the longest tile's chain of dependent steps, and a 16-row step costs half the MFMA time of a 32-row
+ * step on its CU.  M interactions/s of the whole step, 32- vs 16-sequence tiles, bench workload (profiles/r03_batch_sweep_tiles.md):
+ * 256 sequences 3.4 / 5.8, 1 024 12.7 / 21.7, 4 096 43.7 / 66.4, 8 192 74.4 / 96.5, 16 384 (512 tiles) 100.5 / 104.0,
+ * 50 000 122.3 / 114.7. */
+#define SBR_SEQ_RT1_MAX_TILES 640
+#endif
 #ifndef SBR_BWD_RT4_MIN_TILES
 #define SBR_BWD_RT4_MIN_TILES 3000
 #endif
@@ -2520,7 +2528,17 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
                 const char* rt_str = std::getenv("SBR_SEQ_RT"); /* read per call: the tests force either form */
                 const int rt_env = rt_str ? std::atoi(rt_str) : 0;
                 const bool big = rt_env ? rt_env >= 4 : (mb.B + 63) / 64 >= SBR_FWD_RT4_MIN_TILES;
-                if (big && DD >= 64) {
+                /* 16-sequence tiles for small minibatches: below SBR_SEQ_RT1_MAX_TILES 32-sequence tiles the chip is not
+                 * full and the kernel time is the longest tile's chain of dependent steps — half-size tiles halve the step */
+                const bool tiny = rt_env ? rt_env == 1 : (mb.B + 31) / 32 < SBR_SEQ_RT1_MAX_TILES;
+                if (tiny && DD >= 64) {
+                    constexpr int RT = 1;
+                    const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
+                    if (m.ng == 4)
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 4, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
+                    else
+                        hipLaunchKernelGGL((lstm_fwd_seq_kernel<DD, 3, RT, UPW>), dim3(ntiles), dim3((DD / 16 / UPW) * 64), 0, s, m, mb, H, w, ntiles);
+                } else if (big && DD >= 64) {
                     constexpr int RT = 4;
                     const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
                     if (m.ng == 4)
@@ -2620,6 +2638,17 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
                         launched = true;
                     }
                 }
+                if constexpr (DD >= 64 && DD <= 128) {
+                    const bool tiny = rt_env ? rt_env == 1 : (b_host + 31) / 32 < SBR_SEQ_RT1_MAX_TILES;
+                    if (tiny && !launched) { /* 16-sequence tiles (see launch_recurrent_forward) */
+                        const int ntiles = (b_host + 15) / 16;
+                        if (m.ng == 4)
+                            hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 4, 1>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                        else
+                            hipLaunchKernelGGL((lstm_bwd_seq_kernel<DD, 3, 1>), dim3(ntiles), dim3((DD / 16) * 64), 0, s, m, mb, blk, w);
+                        launched = true;
+                    }
+                }
                 if (!launched) {
                     const int ntiles = (b_host + 31) / 32;
                     if (m.ng == 4)
@@ -2666,10 +2695,13 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
         /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */
         const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
+        /* SBR_DW_LDS_PAD: extra dynamic LDS per workgroup = a cap on the kernel's residency (20 KB static: 32 KB more leave
+         * three workgroups per CU instead of four, and room for the sparse update's waves beside them) */
+        static const int lds_pad = std::getenv("SBR_DW_LDS_PAD") ? std::atoi(std::getenv("SBR_DW_LDS_PAD")) : 0;
         if (m.ng == 4) {
             if constexpr (full4) {
                 if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
-                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
+                hipLaunchKernelGGL((lstm_dw_full_kernel<DD, 4>), dim3(grid), dim3(256), lds_pad, s, m, mb, blk, w);
             } else {
                 hipLaunchKernelGGL((lstm_dw_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, mb, blk, w);
             }

@@ -710,8 +710,10 @@ def test_dense_gradient_wide_address_path(monkeypatch):
 
 
 @pytest.mark.parametrize("kind,loss,d,rt", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "1"),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "2"),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "4"),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "1"),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "2"),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "4"),
     (ModelKind.EWMA, LOSS_WARP, 256, None),
@@ -721,7 +723,7 @@ def test_many_tiles_per_minibatch(monkeypatch, kind, loss, d, rt):
     sequence-resident kernels fold their length-sorted tile list (second fold group reversed), 40+ chunks of
     1 024 packed rows in the dense-gradient GEMM, and a sparse update with ~10^5 keys — the regime the
     benchmark runs in, at a size the oracle still finishes in seconds.  Whole-fit parity, bit for bit, in both
-    forms of the sequence-resident kernels (SBR_SEQ_RT: 32- / 64-sequence tiles)."""
+    forms of the sequence-resident kernels (SBR_SEQ_RT: 16- / 32- / 64-sequence tiles)."""
     if rt is not None:
         monkeypatch.setenv("SBR_SEQ_RT", rt)
     users, items, T, B = 9500, 4001, 7, 9000

@@ -10,13 +10,18 @@ BPTT and the Adagrad dense + sparse update (fit_sequence_model's inner loop,
 /root/reference/src/models/sequence_model.rs:111-169).  An *interaction* is one (input, target)
 pair = one loss term (`examples += n-1`, sequence_model.rs:158).
 
-Workload (default): BASELINE.json configs[2] — synthetic 100K users x 1M items, seq_len <= 64,
+Workload (default, N = 1): BASELINE.json configs[2] — synthetic 100K users x 1M items, seq_len <= 64,
 embedding_dim 128, LSTM(Normal) + WARP + Adagrad, the largest single-GPU configuration and the one
 the north-star HBM-roofline target is quoted on.  (configs[1], MovieLens-100K, is 1.3K
 subsequences — a parity/MRR case, run here untimed for the `test_mrr` field and in
-tests/test_parity_gpu.py.)  With N GPUs the user count scales with N (weak scaling): users are
-sharded, every GPU runs its own partition, and per step one all-to-all + one all-gather (RCCL)
-of dense per-owner gradient chunks realise the synchronised optimiser step.
+tests/test_parity_gpu.py.)  With N > 1 GPUs the default is BASELINE.json configs[3]'s per-GPU shape —
+125 000 users per GPU (1M users at N = 8), seq_len <= 128, the same model — users sharded, every GPU
+on its own partition, and per step one all-to-all + one all-gather (RCCL) of dense per-owner gradient
+chunks realise the synchronised optimiser step; `--partition-table --model ewma --loss
+hinge --dim 256 --items 10000000` is configs[4].  `--users` / `--max-len` override either default.
+`--simulate-world N` (one GPU, no process group) runs rank 0's share of an N-GPU step with the real
+scatter / owner-reduce / table-update kernels and device copies in place of the collectives, and
+prints the kernel-side cost of the exchange and the bytes every xGMI link would carry.
 
 Prints ONE JSON line (rank 0, the last line of stdout).  `roofline` describes the gather +
 WARP-score kernel against the HBM roofline (`traffic` = PMC bytes, profiles/score_kernel_pmc.json);
@@ -157,21 +162,129 @@ def cpu_baseline(args, model_kind=0, loss_kind=2):
 
 def movielens_mrr():
     """BASELINE.json configs[1] (untimed): MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad,
-    10 epochs under the reference protocol (lstm.rs:427-448, 498-520)."""
+    10 epochs under the reference protocol (lstm.rs:427-448, 498-520) — at batch_sequences 1, the
+    reference's own schedule (one optimiser step per subsequence), and at 16.  `readme_example` times the
+    configuration of the crate's README / doctest (lib.rs:22-58: max_sequence_length 32), whose fit the
+    README describes as "about 10 seconds" (readme.md:26, unspecified CPU)."""
     from helpers import movielens_protocol
     from sbr_rs_amd._abi import make_hparams
     from sbr_rs_amd.engine import Model
 
-    data, train, test, rng = movielens_protocol()
-    hp = make_hparams(data.num_items(), 128, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, 16)
-    m = Model(hp)
-    t0 = time.perf_counter()
-    loss = m.fit(train.user_pointers, train.item_ids)
-    dt = time.perf_counter() - t0
-    mrr, ranks = m.mrr_score(test.user_pointers, test.item_ids)
-    return {"config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, batch_sequences 16",
-            "test_mrr": mrr, "test_users": int(len(ranks)), "fit_loss": loss, "fit_seconds": dt,
-            "train_interactions_per_s": 10 * (len(train.item_ids)) / dt}
+    def run(max_len, batch):
+        data, train, test, rng = movielens_protocol()
+        hp = make_hparams(data.num_items(), max_len, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, batch)
+        m = Model(hp)
+        t0 = time.perf_counter()
+        loss = m.fit(train.user_pointers, train.item_ids)
+        dt = time.perf_counter() - t0
+        mrr, ranks = m.mrr_score(test.user_pointers, test.item_ids)
+        return {"test_mrr": mrr, "test_users": int(len(ranks)), "fit_loss": loss, "fit_seconds": dt,
+                "train_interactions_per_s": 10 * (len(train.item_ids)) / dt}
+
+    out = {"config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, max_sequence_length 128, batch_sequences 16"}
+    out.update(run(128, 16))
+    out["batch_sequences_1"] = dict(run(128, 1), note="the reference's schedule: one optimiser step per subsequence (sequence_model.rs:111-169)")
+    out["readme_example"] = dict(run(32, 1), config="lib.rs:22-58 / readme.md: max_sequence_length 32, dim 32, WARP, Adagrad, 10 epochs, batch_sequences 1",
+                                 reference_says="about 10 seconds (readme.md:26, src/lib.rs:20; CPU unspecified)")
+    return out
+
+
+def quality_neutral_batch():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "quality_neutral_batch.json")))
+    except Exception:
+        return None
+
+
+def workload_label(args, world):
+    """Which BASELINE.json config the run's shape is (the label the JSON line carries)."""
+    shape = (args.model, args.loss, args.dim, args.items, args.users, args.max_len)
+    if shape == ("lstm", "warp", 128, 1_000_000, 100_000, 64) and world == 1 and not args.partition_table:
+        return "BASELINE.json configs[2]"
+    if shape == ("lstm", "warp", 128, 1_000_000, 125_000, 128) and world > 1 and not args.partition_table:
+        return ("BASELINE.json configs[3]" if world == 8 else
+                f"BASELINE.json configs[3]'s per-GPU shape at {world} GPUs (the config itself is 1M users over 8)")
+    if (args.model, args.loss, args.dim, args.items) == ("ewma", "hinge", 256, 10_000_000) and args.partition_table:
+        return ("BASELINE.json configs[4]" if world == 8 and args.users == 125_000 else
+                "BASELINE.json configs[4]'s shape (EWMA + hinge, d 256, 1e7 items, partitioned item table)")
+    return "custom workload"
+
+
+def simulate_world(args, model_kind, loss_kind):
+    """Rank 0's share of an N-GPU synchronous step on ONE GPU: local compute, then the real exchange kernels —
+    scatter into N per-owner chunks, owner reduce over N inputs, table update from N reduced chunks, dense
+    update from N dense blocks — with device-to-device copies standing in for the all-to-all / all-gather
+    (every "peer" contributes a copy of rank 0's own chunk, so the touched-row density is one device's).  What it
+    measures is the kernel-side term of the exchange; the link term is priced from the bytes."""
+    import torch
+
+    from sbr_rs_amd import engine
+    from sbr_rs_amd.distributed import HipBackend
+
+    n = args.simulate_world
+    engine.set_device(0)
+    ptr, items = synthetic_csr(args.users * n, args.items, args.max_len, zipf=args.item_distribution == "zipf")
+    model = engine.Model(make_hp(args, n, 0, model_kind, loss_kind, args.items))
+    be = HipBackend(model, (ptr, items), n)
+    recv, table, dense_all = be.buffers(n)
+    chunk, db = be.chunk, be.dense_bytes
+    nmb = be.epoch_prepare()
+    phases = {k: 0.0 for k in ("local_compute", "scatter", "all_to_all_stand_in_copies", "owner_reduce", "all_gather_stand_in_copies",
+                               "apply_rows", "dense_join_and_apply")}
+
+    def timed(name, fn):
+        model.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        model.synchronize(); torch.cuda.synchronize()
+        phases[name] += 1e3 * (time.perf_counter() - t0)
+
+    rows = 0
+    steps = 0
+    for i in range(args.warmup + args.steps):
+        mb = i % nmb
+        if i == args.warmup:
+            for k in phases:
+                phases[k] = 0.0
+            rows = steps = 0
+        timed("local_compute", lambda: be.compute_local(mb))
+        timed("scatter", lambda: be.scatter(mb))
+
+        def a2a():  # chunk 0 of every device arrives at device 0: N copies of the own contribution
+            for src in range(n):
+                recv[src * chunk:(src + 1) * chunk].copy_(be.send[:chunk])
+        timed("all_to_all_stand_in_copies", a2a)
+        timed("owner_reduce", lambda: be.owner_reduce(recv))
+
+        def ag():  # the owners' reduced chunks: own slice from the owner reduce, the others from the send buffer (same layout)
+            table[:chunk].copy_(be.own)
+            table[chunk:].copy_(be.send[chunk:])
+        timed("all_gather_stand_in_copies", ag)
+        timed("apply_rows", lambda: be.apply_rows(table))
+
+        def dn():
+            d = be.dense()
+            for q in range(n):
+                dense_all[q * db:(q + 1) * db].copy_(d)
+            be.apply_dense(dense_all)
+        timed("dense_join_and_apply", dn)
+        rows += be.plan.minibatch_rows(mb)
+        steps += 1
+    be.close()
+    per = {k: v / steps for k, v in phases.items()}
+    link_gbs = 153.0  # one xGMI link, per direction (the prompt's figure; 7 links per GPU, full mesh)
+    return {
+        "mode": f"simulate-world {n} on one GPU (kernel-side cost of the exchange; NOT a multi-GPU measurement)",
+        "workload": f"{workload_label(args, n)}: rank 0 of {n}, {args.users} users/GPU x {args.items} items, seq_len<={args.max_len}, "
+                    f"dim {args.dim}, {args.model}+{args.loss}, batch_sequences {args.batch_sequences}",
+        "steps": steps, "interactions_per_step": rows / steps, "ms_per_phase": per,
+        "exchange_kernels_ms": per["scatter"] + per["owner_reduce"] + per["apply_rows"],
+        "single_device_update_ms_for_comparison": "see the N = 1 line's kernels.SPARSE_UPDATE",
+        "chunk_bytes": chunk, "bytes_per_link_per_phase": chunk,
+        "bytes_per_gpu_per_step": 2 * (n - 1) * chunk + (n - 1) * db,
+        "link_time_estimate_ms": {"all_to_all": 1e3 * chunk / (link_gbs * 1e9), "all_gather": 1e3 * chunk / (link_gbs * 1e9),
+                                  "assumption": f"every pair of GPUs exchanges one chunk per phase over its own link at {link_gbs} GB/s, all links concurrently"},
+    }
 
 
 def main():
@@ -179,13 +292,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--users", type=int, default=100_000, help="users per GPU")
+    ap.add_argument("--users", type=int, default=None, help="users per GPU (default: 100 000 at N = 1 = configs[2]; 125 000 at N > 1 = configs[3])")
     ap.add_argument("--items", type=int, default=1_000_000)
-    ap.add_argument("--max-len", type=int, default=64)
+    ap.add_argument("--max-len", type=int, default=None, help="max_sequence_length (default: 64 at N = 1, 128 at N > 1)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--batch-sequences", type=int, default=50000,
-                    help="subsequences per optimiser step and GPU (default: two steps per epoch of the 100K-user workload; "
-                         "DESIGN.md §3 shows test MRR is insensitive to it up to nearly full-batch steps)")
+                    help="subsequences per optimiser step and GPU (default: two steps per epoch of the 100K-user workload — the "
+                         "throughput regime; DESIGN.md §3: EWMA's test MRR does not depend on it, the LSTM's is unchanged up to "
+                         "`value_quality_neutral`'s batch (profiles/quality_neutral_batch.json) and degrades beyond)")
     ap.add_argument("--item-distribution", choices=["uniform", "zipf"], default="uniform",
                     help="uniform = the pure-roofline run (no cache reuse); zipf = Zipf(1.0) over a permuted catalogue")
     ap.add_argument("--model", choices=["lstm", "lstm-coupled", "ewma"], default="lstm")
@@ -202,7 +316,11 @@ def main():
     ap.add_argument("--cold-items", type=int, default=4_000_000,
                     help="catalogue size of the untimed cache-cold pass of the gather + score kernel (table = 8x the 256 MiB "
                          "Infinity Cache at dim 128); 0 = skip")
-    ap.add_argument("--batch-sweep", type=str, default="1024,4096,16384",
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="one GPU: rank 0's share of an N-GPU synchronous step with the real exchange kernels (scatter into N chunks, "
+                         "owner reduce over N inputs, table update) and device copies in place of the collectives; prints kernel ms "
+                         "and bytes per link instead of the throughput line's usual extras")
+    ap.add_argument("--batch-sweep", type=str, default="1024,4096,8192,16384",
                     help="extra batch sizes measured untimed after the main run (reported with the main one as batch_sweep); '' = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
@@ -228,6 +346,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    multi = world > 1 or args.simulate_world > 1
+    if args.users is None:
+        args.users = 125_000 if multi else 100_000   # BASELINE.json configs[3] (1M users over 8 GPUs) / configs[2]
+    if args.max_len is None:
+        args.max_len = 128 if multi else 64
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     if args.backend == "gloo":
@@ -252,6 +375,11 @@ def main():
 
     model_kind = {"lstm": 0, "lstm-coupled": 1, "ewma": 2}[args.model]
     loss_kind = {"bpr": 0, "hinge": 1, "warp": 2}[args.loss]
+    if args.simulate_world > 1:
+        if world != 1:
+            raise SystemExit("--simulate-world runs in one process on one GPU")
+        print(json.dumps(simulate_world(args, model_kind, loss_kind)), flush=True)
+        return
     total_users = args.users * world
     ptr, items = synthetic_csr(total_users, args.items, args.max_len, zipf=args.item_distribution == "zipf")
     hp = make_hp(args, world, rank, model_kind, loss_kind, args.items)
@@ -389,7 +517,9 @@ def main():
         if args.batch_sweep:
             sweep = []
             try:
-                for bsz in [int(x) for x in args.batch_sweep.split(",") if x]:
+                qn = quality_neutral_batch()
+                sizes = sorted({int(x) for x in args.batch_sweep.split(",") if x} | ({int(qn["batch_sequences"])} if qn else set()))
+                for bsz in [b for b in sizes if b != args.batch_sequences]:
                     v, _, rpl, _, ms = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.items, batch=bsz), ptr, items, 8, 3)
                     sweep.append({"batch_sequences": bsz, "interactions_per_s": v, "ms_per_step": ms, "interactions_per_step": rpl})
             except Exception as e:
@@ -474,10 +604,7 @@ def main():
                     tf = flops_per_row * rows_timed / (kernels[fam]["ms_total"] * 1e-3) / 1e12
                     mfma.append({"kernel": fam, "what": what, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
                                  "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF})
-        is_cfg2 = (args.model, args.loss, args.dim, args.items, args.users, args.max_len) == ("lstm", "warp", 128, 1_000_000, 100_000, 64)
-        is_cfg4 = (args.model, args.loss, args.dim) == ("ewma", "hinge", 256) and args.partition_table
-        workload_tag = ("BASELINE.json configs[2]" if is_cfg2 else
-                        "BASELINE.json configs[4] shape (EWMA + hinge, d 256, partitioned item table)" if is_cfg4 else "custom workload")
+        workload_tag = workload_label(args, world)
         out = {
             "metric": "train interactions/sec", "value": rows_total / elapsed, "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
@@ -497,6 +624,12 @@ def main():
             sweep.append({"batch_sequences": args.batch_sequences, "interactions_per_s": rows_total / elapsed,
                           "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "interactions_per_step": rows_per_launch, "note": "the timed run"})
             out["batch_sweep"] = sorted((x for x in sweep if "batch_sequences" in x), key=lambda x: x["batch_sequences"]) + [x for x in sweep if "error" in x]
+            # throughput at the largest batch with evidence of unchanged LSTM quality (tools/planted_batch_sweep.py --json)
+            qn = quality_neutral_batch()
+            hit = qn and [x for x in out["batch_sweep"] if x.get("batch_sequences") == qn["batch_sequences"]]
+            if hit and model_kind != 2:
+                out["value_quality_neutral"] = {"value": hit[0]["interactions_per_s"], "unit": "interactions/s", "ms_per_step": hit[0]["ms_per_step"],
+                                                "batch_sequences_per_gpu": qn["batch_sequences"], "criterion": qn["criterion"], "table": qn["table"]}
         if args.param_crc:
             import zlib
 

@@ -64,7 +64,7 @@ def _worker(rank, world, port, kind, loss, par, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
+        ptr, items = synthetic_interactions(40 if world < 8 else 120, 90, 14, seed=5, zipf=True)
         hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank, par=par)
         m = OracleModel(hp)
         loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world, asynchronous=par == PAR_ASYNC)
@@ -80,26 +80,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind,loss,par", [(int(ModelKind.EWMA), LOSS_WARP, PAR_SYNC), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC),
-                                           (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_ASYNC)])
-def test_two_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss, par):
-    """par = Asynchronous: the driver's pipelined step (compute k+1 before update k lands) must equal
-    the oracle's staleness-one emulation."""
-    world = 2
+@pytest.mark.parametrize("kind,loss,par,world", [(int(ModelKind.EWMA), LOSS_WARP, PAR_SYNC, 2), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC, 2),
+                                                 (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_ASYNC, 2),
+                                                 (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_SYNC, 8), (int(ModelKind.EWMA), LOSS_HINGE, PAR_ASYNC, 8)])
+def test_multi_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss, par, world):
+    """`world` gloo processes through the production driver (world 8 = the node BASELINE configs[3] / [4] name) against one
+    process that emulates all devices.  par = Asynchronous: the driver's pipelined step (compute k+1 before update k lands)
+    must equal the oracle's staleness-one emulation."""
     mp.spawn(_worker, args=(world, _free_port(), kind, loss, par, str(tmp_path)), nprocs=world, join=True)
-    r0 = np.load(tmp_path / "rank0.npz")
-    r1 = np.load(tmp_path / "rank1.npz")
-    # single process, both devices emulated
-    ptr, items = synthetic_interactions(40, 90, 14, seed=5, zipf=True)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    # single process, all devices emulated
+    ptr, items = synthetic_interactions(40 if world < 8 else 120, 90, 14, seed=5, zipf=True)
     hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=0, par=par)
     ref = OracleModel(hp)
     ref_loss = ref.fit(ptr, items)
     for p in PARAMS[kind]:
-        a, b, c = r0[p.name], r1[p.name], ref.get_param(p)
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"replicas diverged on {p.name}"
-        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), f"distributed != single-process on {p.name}"
-    assert float(r0["loss"]) == float(r1["loss"]) == pytest.approx(ref_loss, rel=1e-6)
-    assert int(r0["ex"]) == int(r1["ex"]) > 0
+        c = ref.get_param(p)
+        for r in range(world):
+            assert np.array_equal(ranks[r][p.name].view(np.uint32), c.view(np.uint32)), f"rank {r} of {world} != single-process on {p.name}"
+    assert all(float(r["loss"]) == float(ranks[0]["loss"]) for r in ranks) and float(ranks[0]["loss"]) == pytest.approx(ref_loss, rel=1e-6)
+    assert all(int(r["ex"]) == int(ranks[0]["ex"]) for r in ranks) and int(ranks[0]["ex"]) > 0
 
 
 def test_asynchronous_differs_from_synchronous_only_with_peers(oracle_lib):

@@ -198,6 +198,8 @@ def test_whole_fit_bit_exact(kind, loss, d, items, users, T, B):
     (ModelKind.LSTM_NORMAL, LOSS_HINGE, 64, 3),
     (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 4),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 2),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8),   # the node size of BASELINE configs[3]: eight chunks, eight owner inputs
+    (ModelKind.EWMA, LOSS_HINGE, 256, 8),
 ])
 def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
     """The multi-GPU protocol (scatter / owner_reduce / apply_table through the C-ABI) with `world`
@@ -207,7 +209,7 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
     import torch
 
     items, T, B = 203, 12, 6   # 203 % world != 0 for every world here: ragged last slice
-    ptr, it = synthetic_interactions(90, items, T + 4, seed=17, zipf=True)
+    ptr, it = synthetic_interactions(90 if world < 8 else 240, items, T + 4, seed=17, zipf=True)
     models, plans = [], []
     for q in range(world):
         m = Model(hparams(items, T, d, int(kind), loss, epochs=2, B=B, ndev=world, rank=q))
@@ -255,6 +257,8 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 64, 2, 0, PAR_ASYNC),   # staleness-one pipeline on an exchange stream
     (ModelKind.EWMA, LOSS_WARP, 32, 3, 0, PAR_ASYNC),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 128, 4, OPT_ADAM, PAR_ASYNC),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8, 0, PAR_SYNC),   # world 8 = one xGMI node
+    (ModelKind.EWMA, LOSS_HINGE, 64, 8, 0, PAR_ASYNC),
 ])
 def test_group_fit_single_process(kind, loss, d, world, opt, par):
     """sbr_group_fit: `world` replicas driven from ONE process, the exchange as event-ordered peer
@@ -264,7 +268,7 @@ def test_group_fit_single_process(kind, loss, d, world, opt, par):
     from sbr_rs_amd.engine import group_fit
 
     items, T, B = 211, 12, 5
-    ptr, it = synthetic_interactions(100, items, T + 5, seed=23, zipf=True)
+    ptr, it = synthetic_interactions(100 if world < 8 else 260, items, T + 5, seed=23, zipf=True)
     mk = lambda q: hparams(items, T, d, int(kind), loss, epochs=3, B=B, ndev=world, rank=q, opt=opt,
                            lr=0.02 if opt == OPT_ADAM else 0.16, par=par)
     models = [Model(mk(q)) for q in range(world)]
@@ -283,6 +287,8 @@ def test_group_fit_single_process(kind, loss, d, world, opt, par):
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 64, 4, 0),
     (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 2, OPT_ADAM),
     (ModelKind.EWMA, LOSS_HINGE, 128, 1, 0),          # a group of one: the table is just mapped memory
+    (ModelKind.EWMA, LOSS_HINGE, 256, 8, 0),          # configs[4]'s world: eight owners
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8, 0),
 ])
 def test_partitioned_item_table_group_fit(kind, loss, d, world, opt):
     """sbr_group_create(SBR_GROUP_PARTITION_ITEM_TABLE): the item table exists once (row range r on
@@ -293,7 +299,7 @@ def test_partitioned_item_table_group_fit(kind, loss, d, world, opt):
     from sbr_rs_amd.engine import group_create, group_fit
 
     items, T, B = 1237, 12, 5   # 1237 rows over `world` owners: uneven last slice, several 4 KiB pages
-    ptr, it = synthetic_interactions(110, items, T + 5, seed=29, zipf=True)
+    ptr, it = synthetic_interactions(110 if world < 8 else 280, items, T + 5, seed=29, zipf=True)
     tptr, tit = synthetic_interactions(30, items, T, seed=31)
     hp = hparams(items, T, d, int(kind), loss, epochs=3, B=B, ndev=world, opt=opt, lr=0.02 if opt == OPT_ADAM else 0.16)
     models = group_create(hp, world, partition_item_table=True)

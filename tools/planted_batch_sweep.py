@@ -9,10 +9,14 @@ belong together, and which of them are popular, ranks the held-out last item nea
 nothing ranks it at ~items/2 (MRR ~ 2e-4).  `users` training users, 2 000 held-out
 users (the reference's protocol: unseen users, history = all but the last item, evaluation.rs:12-48).
 
-    tools/planted_batch_sweep.py [--users 200000] [--items 50000] [--batches 16,256,4096,16384,50000]
+    tools/planted_batch_sweep.py [--users 200000] [--items 50000] [--batches 16,256,4096,16384,50000] [--seeds 3]
+                                 [--schedules 50000:0.32:5,50000:0.16:15]   (batch:learning rate:epochs, extra rows)
+                                 [--json profiles/quality_neutral_batch.json]
 
 Runs on the GPU engine (this is a statement about the optimisation regime, not a parity test).  Prints one
-markdown table; the numbers are quoted in DESIGN.md section 3.
+markdown table (mean +- sd over the model seeds); the numbers are quoted in DESIGN.md section 3.  --json writes the
+largest batch whose mean LSTM test MRR is within 3 % of the smallest batch's — what bench.py reports as
+`value_quality_neutral`.
 """
 import argparse
 import os
@@ -59,29 +63,57 @@ def main():
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--p-follow", type=float, default=0.9)
-    ap.add_argument("--batches", type=str, default="16,256,4096,16384,50000")
+    ap.add_argument("--batches", type=str, default="256,1024,4096,8192,16384,32768,50000")
     ap.add_argument("--models", type=str, default="lstm,ewma")
+    ap.add_argument("--seeds", type=int, default=3, help="model seeds per row (initialisation, shuffles, negative draws)")
+    ap.add_argument("--schedules", type=str, default="", help="extra LSTM rows batch:lr:epochs[,...] (large-batch schedules)")
+    ap.add_argument("--json", type=str, default="", help="write the quality-neutral batch (LSTM, within 3 %% of the smallest batch) here")
     a = ap.parse_args()
+    import json
+
     from sbr_rs_amd._abi import make_hparams
     from sbr_rs_amd.engine import Model
 
     ptr, it = planted(a.users, a.items, a.max_len, a.p_follow, 1)
     tptr, tit = planted(2000, a.items, a.max_len, a.p_follow, 2)
     print(f"planted catalogue: {a.users} users, {a.items} items, len 8..{a.max_len}, p_follow {a.p_follow}, "
-          f"{int(ptr[-1]) - a.users} training interactions, dim {a.dim}, {a.epochs} epochs, WARP, Adagrad lr 0.16 l2 4e-4")
-    print("| model | batch_sequences | optimiser steps / epoch | test MRR | fit s |")
-    print("|---|---|---|---|---|")
-    for name in a.models.split(","):
+          f"{int(ptr[-1]) - a.users} training interactions, dim {a.dim}, WARP, Adagrad l2 4e-4, {a.seeds} model seeds per row, "
+          f"2000 held-out users")
+    print("| model | batch_sequences | learning rate | epochs | optimiser steps / epoch | test MRR mean +- sd (min .. max) | fit s |")
+    print("|---|---|---|---|---|---|---|")
+
+    def row(name, b, lr, epochs):
         kind = {"lstm": 0, "ewma": 2}[name]
-        for b in [int(x) for x in a.batches.split(",")]:
-            hp = make_hparams(a.items, a.max_len, a.dim, 0.16, 0.0004, kind, 2, 0, 1, bytes([42] * 16), a.epochs, 1, 0, b)
+        mrrs, dts = [], []
+        for sd in range(a.seeds):
+            hp = make_hparams(a.items, a.max_len, a.dim, lr, 0.0004, kind, 2, 0, 1, bytes([42 + sd] * 16), epochs, 1, 0, b)
             m = Model(hp)
             t0 = time.perf_counter()
             m.fit(ptr, it)
-            dt = time.perf_counter() - t0
-            mrr, _ = m.mrr_score(tptr, tit)
-            print(f"| {name} | {b} | {-(-a.users // b)} | {mrr:.4f} | {dt:.1f} |", flush=True)
+            dts.append(time.perf_counter() - t0)
+            mrrs.append(float(m.mrr_score(tptr, tit)[0]))
             m.close() if hasattr(m, "close") else None
+        mean, sdv = float(np.mean(mrrs)), float(np.std(mrrs, ddof=1)) if len(mrrs) > 1 else 0.0
+        print(f"| {name} | {b} | {lr} | {epochs} | {-(-a.users // b)} | {mean:.4f} +- {sdv:.4f} ({min(mrrs):.4f} .. {max(mrrs):.4f}) | {np.mean(dts):.1f} |", flush=True)
+        return mean, sdv
+
+    results = {}
+    for name in a.models.split(","):
+        for b in [int(x) for x in a.batches.split(",")]:
+            results[name, b] = row(name, b, 0.16, a.epochs)
+    for spec in [x for x in a.schedules.split(",") if x]:
+        b, lr, ep = spec.split(":")
+        row("lstm", int(b), float(lr), int(ep))
+    if a.json and any(k[0] == "lstm" for k in results):
+        bs = sorted(b for (n, b) in results if n == "lstm")
+        base = results["lstm", bs[0]][0]
+        ok = [b for b in bs if results["lstm", b][0] >= 0.97 * base]
+        neutral = max(b for b in ok if all(results["lstm", x][0] >= 0.97 * base for x in bs if x <= b))
+        json.dump({"batch_sequences": neutral, "criterion": f"largest batch whose mean LSTM test MRR over {a.seeds} seeds stays within 3 % of "
+                   f"batch {bs[0]}'s on the planted-structure catalogue (and every smaller batch does too)",
+                   "reference_batch": bs[0], "reference_mrr": base,
+                   "rows": [{"batch_sequences": b, "mrr_mean": results["lstm", b][0], "mrr_sd": results["lstm", b][1]} for b in bs],
+                   "table": "profiles/r03_planted_batch_sweep.md", "tool": "tools/planted_batch_sweep.py"}, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

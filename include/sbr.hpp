@@ -137,7 +137,9 @@ class XorShiftRng {
     }
     /// `Rng::gen_range(low, high)` (rand 0.5 `UniformInt::sample_single`): zone = range << leading_zeros(range),
     /// accept when the low half of next_u64() * range is <= zone, result = low + high half.
+    /// Panics in the crate when low >= high (`assert!(low < high)`); here: std::invalid_argument.
     std::uint64_t gen_range(std::uint64_t low, std::uint64_t high) {
+        if (low >= high) throw std::invalid_argument("gen_range: low must be below high");
         const std::uint64_t range = high - low;
         const std::uint64_t zone = range << __builtin_clzll(range);
         for (;;) {
@@ -147,6 +149,7 @@ class XorShiftRng {
     }
     /// `Uniform::new(low, high).sample(rng)`: zone = MAX - (MAX - range + 1) % range (data.rs:77-78).
     std::uint64_t uniform(std::uint64_t low, std::uint64_t high) {
+        if (low >= high) throw std::invalid_argument("Uniform::new: low must be below high");
         const std::uint64_t range = high - low, max = std::numeric_limits<std::uint64_t>::max();
         const std::uint64_t zone = max - (max - range + 1) % range;
         for (;;) {

@@ -198,7 +198,9 @@ sbr_status sbr_device_count(int32_t* out_count);
  * sbr_group_fit each row is then updated by its owner only, from the devices' gradient lists merged in
  * device order: bitwise the same result as the replicated Synchronous exchange, with per-step traffic
  * proportional to the batch instead of to the table.  Prediction / mrr_score / get_param work on any
- * replica.  Parallelism::Asynchronous is not available for a partitioned table. */
+ * replica.  Parallelism::Asynchronous over a partitioned table runs the synchronous step (the owners update in
+ * place after a rendezvous; there is no staleness-one pipeline to run) — in sbr_group_fit, under one process per GPU
+ * and with the peer transport alike, so that a hyper-parameter draw never decides whether a configuration can run. */
 #define SBR_GROUP_PARTITION_ITEM_TABLE 1u
 sbr_status sbr_group_create(const sbr_hparams* hp, uint32_t n, uint32_t flags, sbr_model** out_models);
 sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out);

@@ -69,6 +69,9 @@ def lib():
         L.orc_fit_end.argtypes = [vp, fp, u64p]
         L.orc_fit_end_lagged.argtypes = [vp, fp]
         L.orc_model_padding_is_zero.argtypes = [vp]
+        L.orc_model_set_reference_order.argtypes = [vp, C.c_int]
+        L.orc_model_get_rng.argtypes = [vp, vp]
+        L.orc_model_get_rng.restype = None
         L.orc_fit_debug_fetch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_uint64]
         L.orc_model_fit.argtypes = [vp, vp, vp, C.c_uint64, fp]
         L.orc_user_representation.argtypes = [vp, vp, C.c_uint64, vp]
@@ -259,6 +262,19 @@ class OracleModel:
 
     def optimizer_steps(self) -> int:
         return lib().orc_model_get_opt_steps(self._h)
+
+    def get_rng(self) -> bytes:
+        """The model RNG's state as the 16 bytes that re-create it through XorShiftRng::from_seed."""
+        out = (C.c_uint8 * 16)()
+        lib().orc_model_get_rng(self._h, out)
+        return bytes(out)
+
+    def set_reference_order(self, on: bool = True) -> None:
+        """Checker-only mode (batch_sequences = 1): negatives from the partition's sequential xorshift stream
+        (sequence_model.rs:58-65, 137) and, with num_devices > 1, one optimiser application per device in device order
+        (wyrm's SynchronizedOptimizer as recalled) — the reference's order of work in the two places where the
+        engine's contract substitutes its own (counter-keyed draws; one update from the summed gradients)."""
+        _check(lib().orc_model_set_reference_order(self._h, 1 if on else 0))
 
     def fit(self, user_ptr, item_ids) -> float:
         up = np.ascontiguousarray(user_ptr, dtype=np.uint64)

@@ -44,6 +44,18 @@ typedef struct orc_model {
     uint64_t opt_steps;
     orc_rng rng;
     uint64_t global_epoch;
+    /* Reference-order mode (orc_model_set_reference_order; checker only, no engine counterpart): the two places where
+     * the engine's contract departs from the reference's ORDER of work are replaced by the reference's own —
+     *  (i)  negatives are drawn from the partition's sequential xorshift stream with rand 0.5's Uniform, one draw per try,
+     *       exactly as sequence_model.rs:58-65 / :137 do (the contract keys every draw by a counter instead, so that
+     *       draws can be evaluated in parallel);
+     *  (ii) with num_devices > 1 every device's gradient is applied as its OWN optimiser step, one after the other in
+     *       device order (wyrm's SynchronizedOptimizer as recalled, sequence_model.rs:163-166: the workers rendezvous,
+     *       then each update goes in under exclusion — N Adagrad applications, G += g_q^2 each), where the contract adds
+     *       the devices' gradients and applies one update.
+     * batch_sequences must be 1 (the reference's schedule).  Used to measure whether the substitutions move test MRR
+     * (tools/mrr_stream_sweep.py --reference-order). */
+    int reference_order;
 } orc_model;
 
 typedef struct orc_local { /* one device's view of one minibatch */
@@ -244,7 +256,18 @@ int orc_model_padding_is_zero(orc_model* m) {
     return 1;
 }
 uint64_t orc_model_get_epoch(orc_model* m) { return m->global_epoch; }
+int orc_model_set_reference_order(orc_model* m, int on) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    m->reference_order = on ? 1 : 0;
+    return SBR_OK;
+}
 uint64_t orc_model_get_opt_steps(orc_model* m) { return m->opt_steps; }
+/* state of the model RNG as the 16 seed bytes that re-create it (x, y, z, w little-endian): what the reference's
+ * Hyperparameters.rng holds after build_params (lstm.rs:174-194) */
+void orc_model_get_rng(orc_model* m, uint8_t out[16]) {
+    const uint32_t v[4] = { m->rng.x, m->rng.y, m->rng.z, m->rng.w };
+    memcpy(out, v, 16);
+}
 
 /* optimiser element update (≙ wyrm optim::{Adagrad, Adam} as recalled) */
 static void orc_opt(orc_model* m, float* w, float* acc, float* mom, float g) {
@@ -345,6 +368,8 @@ int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
         }
     }
     if (nseq == 0) return SBR_ERR_NO_INTERACTIONS;
+    if (m->reference_order && (m->hp.batch_sequences != 1 || (m->hp.num_devices > 1 && m->hp.parallelism != SBR_PAR_SYNCHRONOUS)))
+        return SBR_ERR_INVALID_ARGUMENT; /* the reference's schedule; Hogwild has no order to restate */
     uint64_t* start = (uint64_t*)malloc(nseq * 8);
     uint32_t* len = (uint32_t*)malloc(nseq * 4);
     uint64_t k = 0;
@@ -369,7 +394,8 @@ int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
         uint8_t seed[16];
         orc_rng_gen_seed(&m->rng, seed);
         orc_rng_from_seed(&p->part_rng[q], seed);
-        p->fit_seed[q] = orc_rng_u64(&p->part_rng[q]);
+        /* contract: the key of the counter-based negative draws; the reference's thread_rng serves shuffles and draws only */
+        if (!m->reference_order) p->fit_seed[q] = orc_rng_u64(&p->part_rng[q]);
     }
     p->nnz = user_ptr[num_users];
     p->items = (uint32_t*)malloc((p->nnz ? p->nnz : 1) * 4);
@@ -527,7 +553,7 @@ static float orc_score_tree(const orc_model* m, const float* h, uint32_t item) {
 /* Negative sampling + loss + dloss/dh for every packed row.
  * ≙ sequence_model.rs:125-141 (negative choice), sample_warp_negative (:47-68), the loss nodes
  * (lstm.rs:300-320) and the dot-node backward into h. */
-static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
+static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key, orc_rng* thread_rng) {
     int d = m->d;
     uint32_t I = m->hp.num_items;
     L->loss_sum = 0.0;
@@ -540,7 +566,9 @@ static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key) {
         uint32_t tries = 0;
         int max_tries = m->hp.loss == SBR_LOSS_WARP ? ORC_WARP_TRIES : 1;
         for (int k = 0; k < max_tries; ++k) {
-            nj = orc_negative_draw(epoch_key, L->ctr[r], (uint32_t)k, I);
+            /* reference order (batch_sequences = 1: packed row r is step r of the one sequence): `uniform.sample(rng)`,
+             * Uniform::new(0, num_items) over the worker's own stream, sequence_model.rs:59 / :137 */
+            nj = m->reference_order ? (uint32_t)orc_rng_uniform(thread_rng, 0, I) : orc_negative_draw(epoch_key, L->ctr[r], (uint32_t)k, I);
             neg = orc_score_tree(m, h, nj);
             ++tries;
             if (orc_warp_accepts(pos, neg)) break;
@@ -703,7 +731,7 @@ int orc_fit_step_local(orc_plan* p, int q, uint64_t mb) {
     orc_local* L = &p->loc[q];
     orc_pack(p, q, mb, L);
     orc_forward(p->m, L);
-    orc_score(p->m, L, orc_epoch_key_of(p->fit_seed[q], p->epoch_key_epoch));
+    orc_score(p->m, L, orc_epoch_key_of(p->fit_seed[q], p->epoch_key_epoch), &p->part_rng[q]);
     orc_lagged_loss_update(p, q);
     orc_backward(p->m, L);
     return SBR_OK;
@@ -784,47 +812,36 @@ static void orc_reduce_row(const orc_entry* ent, uint64_t i, uint64_t j, int d, 
  *  with +g*h — sorted by (row, device, packed row, kind); duplicates added in that order; one
  *  Adagrad update (with L2) per touched row, also for rows whose summed data-gradient is zero
  *  (SURVEY App. A-14); biases likewise for target/negative rows. */
-int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
+static int orc_apply_own_block(orc_plan* p, const void* block, int q) {
+    /* one optimiser step from ONE device's block: its dense gradient, then its sparse entries per row */
     orc_model* m = p->m;
-    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: owner-reduce protocol below */
-    int d = m->d, ndev = p->ndev;
-    uint64_t Rmax = (uint64_t)p->Rmax, bytes = orc_fit_exchange_bytes(p), nd = orc_ndense(m);
+    int d = m->d;
+    uint64_t Rmax = (uint64_t)p->Rmax, nd = orc_ndense(m);
     orc_begin_optimizer_step(m);
-    /* dense */
+    const uint32_t* w = (const uint32_t*)block;
+    const float* dense = (const float*)(w + 8 + 4 * Rmax + 2 * Rmax * (uint64_t)d);
     float* dg = (float*)malloc(nd * 4);
-    uint64_t total_entries = 0;
-    for (int q = 0; q < ndev; ++q) {
-        const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
-        const float* dense = (const float*)(w + 8 + 4 * Rmax + 2 * Rmax * (uint64_t)d);
-        if (q == 0) memcpy(dg, dense, nd * 4); else for (uint64_t i = 0; i < nd; ++i) dg[i] = dg[i] + dense[i];
-        total_entries += 3ull * w[0];
-        double ls; uint64_t ex;
-        memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
-        p->loss_sum += ls; p->examples += ex;
-        p->loss_dev[q] += ls; p->examples_dev[q] += ex;
-    }
+    memcpy(dg, dense, nd * 4);
+    double ls; uint64_t ex;
+    memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
+    p->loss_sum += ls; p->examples += ex;
+    p->loss_dev[q] += ls; p->examples_dev[q] += ex;
     orc_dense_update(m, dg);
     free(dg);
-    /* sparse */
-    orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (total_entries ? total_entries : 1));
-    uint64_t ne = 0;
-    for (int q = 0; q < ndev; ++q) {
-        const uint32_t* w = (const uint32_t*)((const char*)all_blocks + (size_t)q * bytes);
-        uint32_t R = w[0];
-        const uint32_t* in_idx = w + 8; const uint32_t* out_idx = in_idx + Rmax; const uint32_t* neg = out_idx + Rmax;
-        for (uint32_t r = 0; r < R; ++r) {
-            uint32_t base = (uint32_t)((uint64_t)q * 3 * Rmax + 3ull * r);
-            ent[ne].row = in_idx[r]; ent[ne].src = base; ++ne;
-            ent[ne].row = out_idx[r]; ent[ne].src = base + 1; ++ne;
-            ent[ne].row = neg[r]; ent[ne].src = base + 2; ++ne;
-        }
+    uint32_t R = w[0];
+    uint64_t ne = 3ull * R;
+    orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (ne ? ne : 1));
+    const uint32_t* in_idx = w + 8; const uint32_t* out_idx = in_idx + Rmax; const uint32_t* neg = out_idx + Rmax;
+    for (uint32_t r = 0; r < R; ++r) {
+        ent[3 * r].row = in_idx[r]; ent[3 * r].src = 3u * r;
+        ent[3 * r + 1].row = out_idx[r]; ent[3 * r + 1].src = 3u * r + 1;
+        ent[3 * r + 2].row = neg[r]; ent[3 * r + 2].src = 3u * r + 2;
     }
     qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
     float* gsum = (float*)malloc(sizeof(float) * d);
     float* part = (float*)malloc(sizeof(float) * d);
-    const uint32_t* w0 = (const uint32_t*)all_blocks; /* ndev == 1: the device's own block */
-    orc_entry_src es = { (const float*)(w0 + 8 + 4 * Rmax), (const float*)(w0 + 8 + 4 * Rmax) + Rmax * (uint64_t)d,
-                         (const float*)(w0 + 8 + 3 * Rmax) };
+    orc_entry_src es = { (const float*)(w + 8 + 4 * Rmax), (const float*)(w + 8 + 4 * Rmax) + Rmax * (uint64_t)d,
+                         (const float*)(w + 8 + 3 * Rmax) };
     uint64_t i = 0;
     while (i < ne) {
         uint32_t row = ent[i].row;
@@ -835,9 +852,13 @@ int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
         orc_row_update(m, row, gsum, 1, has_b, gb);
         i = j;
     }
-    free(part);
-    free(gsum); free(ent);
+    free(part); free(gsum); free(ent);
     return SBR_OK;
+}
+
+int orc_fit_step_apply(orc_plan* p, const void* all_blocks) {
+    if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: owner-reduce protocol below */
+    return orc_apply_own_block(p, all_blocks, 0);
 }
 
 /* ---- multi-device optimiser step: owner-reduce protocol ---------------------------------------
@@ -970,6 +991,20 @@ int orc_fit_step(orc_plan* p, uint64_t mb) {
         return st;
     }
     int n = p->ndev;
+    if (p->m->reference_order) {
+        /* every worker's forward / backward against the parameters as they stand at the rendezvous, then the updates one
+         * worker at a time (device order stands in for the reference's arrival order) */
+        uint64_t bytes = orc_fit_exchange_bytes(p);
+        char* blk = (char*)malloc((size_t)n * bytes);
+        for (int q = 0; q < n; ++q) {
+            orc_fit_step_local(p, q, mb);
+            orc_fit_export_local(p, q, blk + (size_t)q * bytes);
+        }
+        int st = SBR_OK;
+        for (int q = 0; q < n && st == SBR_OK; ++q) st = orc_apply_own_block(p, blk + (size_t)q * bytes, q);
+        free(blk);
+        return st;
+    }
     uint64_t cb = orc_fit_chunk_bytes(p), db = orc_fit_dense_bytes(p);
     char* send = (char*)malloc((size_t)n * n * cb); /* [device][chunk] */
     char* recv = (char*)malloc((size_t)n * cb);

@@ -32,7 +32,10 @@
 /* numerator and denominator of the rational tanh; the caller divides (or multiplies by a
  * reciprocal it obtained elsewhere) */
 SBR_APPROX_HD void sbr_tanh_pq(float x, float* p, float* q) {
-    x = __builtin_fminf(__builtin_fmaxf(x, -SBR_TANH_CLAMP), SBR_TANH_CLAMP);
+    /* comparison + select, not fmin / fmax: a NaN argument fails both comparisons and stays NaN, as the reference's
+     * activations propagate it (fmax(NaN, -C) would be -C: diverged weights would give finite-looking states and scores) */
+    x = x > SBR_TANH_CLAMP ? SBR_TANH_CLAMP : x;
+    x = x < -SBR_TANH_CLAMP ? -SBR_TANH_CLAMP : x;
     const float x2 = x * x;
     float n = -2.76076847742355e-16f;
     n = __builtin_fmaf(n, x2, 2.00018790482477e-13f);

@@ -1639,8 +1639,8 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
  * blocks [apply]; the next step's scatter is safe because every rank passed the following barrier. */
 sbr_status sbr_fit_exchange_export(sbr_fit_plan* p, int32_t out_fds[2], uint64_t out_bytes[2]) {
     if (!p || !out_fds || !out_bytes || p->ndev < 1 || p->m->shared) return SBR_ERR_INVALID_ARGUMENT;
-    /* the peer transport runs the synchronous step only (Asynchronous = the collective transport's pipeline) */
-    if (p->ndev > 1 && p->m->hp.parallelism == SBR_PAR_ASYNCHRONOUS) return SBR_ERR_UNSUPPORTED;
+    /* the peer transport runs the synchronous step whatever hp.parallelism says (the staleness-one pipeline belongs to the
+     * collective transport): Asynchronous here IS Synchronous — deterministic, and a valid outcome of Hogwild */
     SBRCHK(ensure_device(p->m));
     const uint64_t chunk = slice_rows(p) * ((uint64_t)p->m->d + 2) * 4;
     if (!p->xchg_own[0].ptr) {
@@ -1803,11 +1803,12 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
         hipEvent_t scattered = nullptr, reduced = nullptr, applied = nullptr, gathered = nullptr;
         hipStream_t xs = nullptr; /* exchange stream (Asynchronous) */
     };
-    const bool async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS;
     const bool partitioned = models[0]->shared != nullptr;
+    /* a partitioned table is updated in place by its owners after a rendezvous, so there is no staleness-one pipeline for
+     * it: Parallelism::Asynchronous runs the synchronous step there (same everywhere a partitioned table is driven) */
+    const bool async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS && !partitioned;
     for (uint32_t r = 0; r < n; ++r)
         if (models[r]->shared != models[0]->shared) return SBR_ERR_INVALID_ARGUMENT;
-    if (partitioned && async) return SBR_ERR_UNSUPPORTED;
     std::vector<Dev> dev(n);
     uint64_t chunk = 0, db = 0;
     auto cleanup = [&]() {
@@ -2050,8 +2051,8 @@ sbr_status sbr_model_create_partitioned(const sbr_hparams* hp, sbr_model** out) 
     if (!storage_dim(hp->embedding_dim) || hp->num_items == 0 || hp->num_devices == 0 || hp->num_devices > 16 ||
         hp->device_rank >= hp->num_devices)
         return SBR_ERR_INVALID_ARGUMENT;
-    /* a partitioned table is updated in place by its owners after a rendezvous: no staleness-one pipeline */
-    if (hp->num_devices > 1 && hp->parallelism == SBR_PAR_ASYNCHRONOUS) return SBR_ERR_UNSUPPORTED;
+    /* a partitioned table is updated in place by its owners after a rendezvous: Parallelism::Asynchronous runs the
+     * synchronous step (no staleness-one pipeline), here as in sbr_group_fit */
     int ndevices = 0, device = 0;
     if (hipGetDeviceCount(&ndevices) != hipSuccess || ndevices == 0) return SBR_ERR_NO_DEVICE;
     HIPCHK(hipGetDevice(&device));

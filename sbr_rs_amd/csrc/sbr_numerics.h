@@ -230,8 +230,9 @@ static inline uint64_t sbr_xs_u64(sbr_xorshift* r) {
 static inline void sbr_rand_gen_seed16(sbr_xorshift* r, uint8_t out[16]) {
     for (int i = 0; i < 16; ++i) out[i] = (uint8_t)sbr_xs_u32(r);
 }
-/* gen_range(0, n), n >= 1 */
+/* gen_range(0, n), n >= 1 (the crate asserts low < high; n = 0 returns 0 here without drawing instead of shifting by 64) */
 static inline uint64_t sbr_rand_gen_range(sbr_xorshift* r, uint64_t n) {
+    if (n == 0) return 0;
     const uint64_t zone = n << __builtin_clzll(n);
     for (;;) {
         const __uint128_t m = (__uint128_t)sbr_xs_u64(r) * (__uint128_t)n;

@@ -273,8 +273,10 @@ def fit_distributed(model, interactions, group=None, transport: str = None) -> f
         from .partitioned import PeerExchangeStepper
 
         if int(model.hp.parallelism) == 0:  # Parallelism::Asynchronous: only the collective transport has the pipelined order
-            raise ValueError("Parallelism.Asynchronous is implemented for the collective transport only; the peer transport "
-                             "runs the synchronous step (set parallelism(Synchronous) or SBR_EXCHANGE_TRANSPORT=collective)")
+            import warnings
+
+            warnings.warn("Parallelism.Asynchronous with the peer transport runs the synchronous step (the staleness-one "
+                          "pipeline belongs to the collective transport); the result equals Parallelism.Synchronous", stacklevel=2)
 
         stepper = PeerExchangeStepper(model, interactions, group)
         try:

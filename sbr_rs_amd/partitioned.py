@@ -190,8 +190,10 @@ class PartitionedStepper:
 def fit_partitioned(model: Model, interactions, group=None) -> float:
     """``fit`` over a partitioned table, one process per GPU (≙ fit with num_threads = world size)."""
     if int(model.hp.parallelism) == 0:
-        raise ValueError("Parallelism.Asynchronous is not implemented for a partitioned item table (its owners update in "
-                         "place after a rendezvous); use Parallelism.Synchronous")
+        import warnings
+
+        warnings.warn("Parallelism.Asynchronous over a partitioned item table runs the synchronous step (its owners update in "
+                      "place after a rendezvous; the result equals Parallelism.Synchronous, bit for bit)", stacklevel=2)
     stepper = PartitionedStepper(model, interactions, group)
     try:
         epochs = int(model.hp.num_epochs)

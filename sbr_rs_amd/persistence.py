@@ -35,6 +35,7 @@ def save_model(model, path: str) -> None:
     out["hp_seed"] = np.frombuffer(bytes(hp.seed), dtype=np.uint8).copy()
     epoch, steps = eng.counters()
     out["counters"] = np.asarray([epoch, steps], dtype=np.uint64)
+    out["partitioned"] = np.asarray(1 if eng.is_partitioned() else 0)  # the item table stored once across the replicas
     out["rng_state"] = np.frombuffer(eng.get_rng(), dtype=np.uint8).copy()
     for p in Param:
         if eng.param_count(p):
@@ -42,19 +43,25 @@ def save_model(model, path: str) -> None:
     np.savez(_npz_path(path), **out)
 
 
-def load_engine(path: str, device_rank: int = None) -> Model:
-    z = np.load(_npz_path(path))
+_TABLE_PARAMS = ("ITEM_EMBEDDING", "ITEM_BIAS", "ITEM_EMBEDDING_ACC", "ITEM_BIAS_ACC", "ITEM_EMBEDDING_M", "ITEM_BIAS_M")
+
+
+def _hparams_of(z, device_rank=None) -> SbrHparams:
     kw = {f: z[f"hp_{f}"].item() for f in _HP_FIELDS}
     if device_rank is not None:
         kw["device_rank"] = device_rank
-    hp: SbrHparams = make_hparams(kw["num_items"], kw["max_sequence_length"], kw["embedding_dim"], kw["learning_rate"],
-                                  kw["l2_penalty"], kw["model"], kw["loss"], kw["optimizer"], kw["parallelism"],
-                                  bytes(z["hp_seed"].tobytes()), kw["num_epochs"], kw["num_devices"], kw["device_rank"],
-                                  kw["batch_sequences"])
-    eng = Model(hp)
+    return make_hparams(kw["num_items"], kw["max_sequence_length"], kw["embedding_dim"], kw["learning_rate"],
+                        kw["l2_penalty"], kw["model"], kw["loss"], kw["optimizer"], kw["parallelism"],
+                        bytes(z["hp_seed"].tobytes()), kw["num_epochs"], kw["num_devices"], kw["device_rank"],
+                        kw["batch_sequences"])
+
+
+def _restore_into(eng: Model, z, table: bool = True) -> Model:
+    """Parameters, optimiser state, counters and RNG of a saved model into `eng`; table = False skips the item-table
+    blocks (a partitioned group stores them once: one replica writes them)."""
     for p in Param:
         key = f"param_{p.name}"
-        if key in z.files:
+        if key in z.files and (table or p.name not in _TABLE_PARAMS):
             eng.set_param(p, z[key])
     eng.set_counters(int(z["counters"][0]), int(z["counters"][1]))
     if "rng_state" in z.files:
@@ -62,26 +69,54 @@ def load_engine(path: str, device_rank: int = None) -> Model:
     return eng
 
 
+def load_engine(path: str, device_rank: int = None) -> Model:
+    z = np.load(_npz_path(path))
+    return _restore_into(Model(_hparams_of(z, device_rank)), z)
+
+
 def load_model(path: str):
     """Returns an ImplicitLSTMModel or ImplicitEWMAModel: parameters, optimiser state, counters and the
     model RNG are restored exactly, so the next ``fit`` is the one the saved model would have run.  A model
     saved with ``num_threads(n)`` in one process comes back as its n replicas (replica r on HIP device
-    r mod device count); under one process per GPU every rank loads its own replica
-    (``load_engine(path, device_rank=rank)``)."""
+    r mod device count); under one process per GPU (torch.distributed initialised, world = n) every rank gets ITS
+    replica (device_rank = its rank).  A model whose item table was partitioned is rebuilt partitioned — one copy of
+    the table across the replicas / ranks, never n full tables."""
     from .engine import device_count, set_device
     from .ewma import ImplicitEWMAModel
     from .lstm import ImplicitLSTMModel
 
-    eng = load_engine(path, device_rank=0)
-    cls = ImplicitEWMAModel if int(eng.hp.model) == 2 else ImplicitLSTMModel
-    world = int(eng.hp.num_devices)
     try:
         import torch.distributed as dist
 
         launched = dist.is_available() and dist.is_initialized()
     except ImportError:
         launched = False
-    if world == 1 or launched:
+    z = np.load(_npz_path(path))
+    world = int(z["hp_num_devices"].item())
+    partitioned = "partitioned" in z.files and int(z["partitioned"].item()) == 1
+    if launched and world > 1:
+        if dist.get_world_size() != world:
+            raise ValueError(f"the model was saved with num_threads = {world}; the process group has {dist.get_world_size()} ranks")
+        rank = dist.get_rank()  # one process per GPU: every rank restores ITS replica
+        if partitioned:
+            from .partitioned import create_partitioned_model
+
+            eng = _restore_into(create_partitioned_model(_hparams_of(z, rank)), z, table=True)
+        else:
+            eng = load_engine(path, device_rank=rank)
+        return (ImplicitEWMAModel if int(eng.hp.model) == 2 else ImplicitLSTMModel)(eng)
+    if partitioned and world > 1:
+        # one process, n replicas over ONE copy of the table: rebuild the group, not n full tables
+        from .engine import group_create
+
+        group = group_create(_hparams_of(z, 0), world, partition_item_table=True)
+        for r, g in enumerate(group):
+            _restore_into(g, z, table=r == 0)  # the table arrays are shared: written once
+        cls = ImplicitEWMAModel if int(group[0].hp.model) == 2 else ImplicitLSTMModel
+        return cls(group[0], group=group)
+    eng = load_engine(path, device_rank=0)
+    cls = ImplicitEWMAModel if int(eng.hp.model) == 2 else ImplicitLSTMModel
+    if world == 1:
         return cls(eng)
     ndev = device_count()
     group = [eng]

@@ -50,7 +50,10 @@ class XorShiftRng:
 
     def gen_range(self, low: int, high: int) -> int:
         """``Rng::gen_range(low, high)`` = ``UniformInt::sample_single``: zone = range << leading_zeros(range);
-        draw v = next_u64, accept when the low half of v * range is <= zone; result = low + high half."""
+        draw v = next_u64, accept when the low half of v * range is <= zone; result = low + high half.  The crate
+        asserts low < high; here: ValueError."""
+        if low >= high:
+            raise ValueError("gen_range: low must be below high")
         rng = high - low
         zone = (rng << (64 - rng.bit_length())) & _M64
         while True:
@@ -60,6 +63,8 @@ class XorShiftRng:
 
     def uniform(self, low: int, high: int) -> int:
         """``Uniform::new(low, high).sample(rng)``: zone = MAX - (MAX - range + 1) % range (data.rs:77-78)."""
+        if low >= high:
+            raise ValueError("Uniform::new: low must be below high")
         rng = high - low
         zone = _M64 - (_M64 - rng + 1) % rng
         while True:

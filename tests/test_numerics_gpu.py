@@ -38,6 +38,12 @@ def test_math_bitwise(L, oracle_lib):
     assert np.array_equal(e.view(np.uint32), ce.view(np.uint32))
     assert np.array_equal(s.view(np.uint32), cs.view(np.uint32))
     assert np.array_equal(t.view(np.uint32), ct.view(np.uint32))
+    # a NaN pre-activation stays NaN through the clamp (diverged weights must not yield finite-looking states)
+    bad = np.array([np.nan, 1.0, -np.nan, np.inf], dtype=np.float32)
+    e2, s2, t2 = (np.zeros(4, np.float32) for _ in range(3))
+    assert L.sbr_selftest_math(_p(bad), 4, _p(e2), _p(s2), _p(t2)) == 0
+    assert np.isnan(t2[0]) and np.isnan(s2[0]) and np.isnan(e2[0]) and np.isnan(t2[2]) and not np.isnan(t2[1])
+    assert t2[3] == np.float32(oracle_lib.orc_tanhf(float("inf"))) and np.isnan(np.float32(oracle_lib.orc_tanhf(float("nan"))))
     # and the device values themselves against float64 libm (the oracle shares the polynomial, so this
     # is the check that the polynomial is a tanh): 3e-7 for tanh / sigmoid
     x64 = x.astype(np.float64)

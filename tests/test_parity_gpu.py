@@ -508,6 +508,47 @@ def test_save_load_multi_replica_model_continues(tmp_path):
             assert_same_bits(ra.get_param(p), rb.get_param(p), f"resumed replica {p.name}")
 
 
+def test_save_load_partitioned_model_stays_partitioned(tmp_path):
+    """A model whose item table is partitioned over its replicas comes back with ONE copy of the table (not n full
+    tables) and continues training exactly like the original."""
+    import sbr_rs_amd as sbr
+
+    ptr, it = synthetic_interactions(60, 1300, 14, seed=18, zipf=True)
+    comp = sbr.data.CompressedInteractions(60, 1300, ptr, it, np.zeros(len(it), dtype=np.uint64))
+
+    def build():
+        return (sbr.ewma.Hyperparameters.new(1300, 12).from_seed(bytes([9] * 16)).embedding_dim(64).learning_rate(0.16)
+                .l2_penalty(0.0004).loss(sbr.Loss.Hinge).optimizer(sbr.Optimizer.Adagrad).num_epochs(2).num_threads(2)
+                .partition_item_table(True).batch_sequences(6).build())
+
+    a = build()
+    a.fit(comp)
+    sbr.persistence.save_model(a, str(tmp_path / "part"))
+    b = sbr.persistence.load_model(str(tmp_path / "part"))
+    assert len(b._replicas()) == 2 and all(r.is_partitioned() for r in b._replicas())
+    for p in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.EWMA_ALPHA):
+        assert_same_bits(a.params.get_param(p), b.params.get_param(p), f"reloaded {p.name}")
+    assert a.fit(comp) == b.fit(comp)
+    for ra, rb in zip(a._replicas(), b._replicas()):
+        for p in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC):
+            assert_same_bits(ra.get_param(p), rb.get_param(p), f"resumed partitioned replica {p.name}")
+
+
+def test_asynchronous_over_a_partitioned_table_is_the_synchronous_step():
+    """Parallelism::Asynchronous has no staleness-one pipeline over a partitioned table (owners update in place after a
+    rendezvous): it runs — never refuses — and equals the Synchronous oracle bit for bit."""
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    items, T, world = 1237, 12, 3
+    ptr, it = synthetic_interactions(110, items, T + 5, seed=33, zipf=True)
+    mk = lambda par: hparams(items, T, 32, int(ModelKind.EWMA), LOSS_WARP, epochs=2, B=5, ndev=world, par=par)
+    models = group_create(mk(PAR_ASYNC), world, partition_item_table=True)
+    o = OracleModel(mk(PAR_SYNC))
+    assert group_fit(models, ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+    for q in range(world):
+        assert_params_equal(models[q], o, ModelKind.EWMA, f"partitioned + Asynchronous, rank {q}")
+
+
 def test_batch_of_one_is_per_sequence_sgd():
     ptr, it = synthetic_interactions(20, 80, 12, seed=4)
     hp = hparams(80, 10, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, B=1, epochs=1)

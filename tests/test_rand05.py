@@ -122,3 +122,19 @@ def test_standard_normal_moments_and_tail(oracle_lib):
     assert abs(np.mean(z ** 3)) < 0.03 and abs(np.mean(z ** 4) - 3.0) < 0.06
     assert 0.0020 < np.mean(np.abs(z) > 3.0) < 0.0034  # 0.0027
     assert np.abs(z).max() > 3.66  # the tail beyond R = 3.654 is reached
+
+
+def test_empty_range_is_rejected_like_the_crate():
+    """rand 0.5 asserts low < high in gen_range / Uniform::new; the mirrors raise instead of shifting by 64."""
+    import pytest
+
+    r = XorShiftRng.from_seed(_seed(3))
+    before = r.state_seed()
+    for bad in ((0, 0), (5, 5), (7, 3)):
+        with pytest.raises(ValueError):
+            r.gen_range(*bad)
+        with pytest.raises(ValueError):
+            r.uniform(*bad)
+    with pytest.raises(ValueError):
+        r.below(0)
+    assert r.state_seed() == before  # nothing was drawn

@@ -4,7 +4,11 @@
 seed, and test MRR over the 188 test users moves by about +-0.01 with anything that changes the order of the
 updates — which is why the reference itself carries two thresholds per case (default / MKL_CBWR=AVX).
 
-    tools/mrr_stream_sweep.py [--streams 24] [--split fixed|varying] [--jobs 8]
+    tools/mrr_stream_sweep.py [--streams 24] [--split fixed|varying] [--jobs 8] [--reference-order]
+
+--reference-order  the oracle's checker-only mode: negatives from the worker's sequential xorshift stream and, for the
+                 2-thread case, one Adagrad application per worker — the reference's order of work instead of the
+                 contract's counter-keyed draws / summed-gradient update (oracle/sbr_oracle.c, `reference_order`).
 
 --split fixed    the reference's split (XorShiftRng::from_seed([42; 16]) -> user_based_split 0.2); stream k > 0
                  advances the already-advanced RNG by 7k draws before it is moved into the model, so only the
@@ -27,7 +31,7 @@ CASES = {"lstm hinge 1 thread": (0, 1, 1, (0.081, 0.091)), "lstm hinge 2 threads
          "lstm warp": (0, 2, 1, (0.10, 0.089)), "ewma hinge": (2, 1, 1, (0.11, 0.091)), "ewma warp": (2, 2, 1, (0.14, 0.089))}
 
 
-def one(case, k, split):
+def one(case, k, split, reference_order=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import hparams, load_movielens
@@ -44,18 +48,21 @@ def one(case, k, split):
             rng.next_u32()
     train, test = train.to_compressed(), test.to_compressed()
     m = OracleModel(hparams(data.num_items(), 128, 32, kind, loss, epochs=10, B=1, seed=rng.state_seed(), ndev=threads))
+    if reference_order:
+        m.set_reference_order(True)
     m.fit(train.user_pointers, train.item_ids)
     return float(m.mrr_score(test.user_pointers, test.item_ids)[0])
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--one":
-        print(one(sys.argv[2], int(sys.argv[3]), sys.argv[4]))
+        print(one(sys.argv[2], int(sys.argv[3]), sys.argv[4], len(sys.argv) > 5 and sys.argv[5] == "ref"))
         sys.exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=24)
     ap.add_argument("--split", choices=["fixed", "varying"], default="fixed")
     ap.add_argument("--jobs", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--reference-order", action="store_true")
     a = ap.parse_args()
     jobs = [(c, k) for c in CASES for k in range(a.streams)]
     res, running = {c: {} for c in CASES}, []
@@ -70,10 +77,12 @@ if __name__ == "__main__":
         while len(running) >= a.jobs:
             drain()
             time.sleep(0.05)
-        running.append((c, k, subprocess.Popen([sys.executable, __file__, "--one", c, str(k), a.split], stdout=subprocess.PIPE, text=True)))
+        running.append((c, k, subprocess.Popen([sys.executable, __file__, "--one", c, str(k), a.split] + (["ref"] if a.reference_order else []),
+                                               stdout=subprocess.PIPE, text=True)))
     while running:
         drain()
         time.sleep(0.05)
+    print(f"mode: {'reference order (sequential negative stream; one update per worker)' if a.reference_order else 'contract (counter-keyed negatives; one update from the summed gradients)'}, split {a.split}")
     print(f"| case | reference bound (default / CI) | protocol run (stream 0) | mean of {a.streams} | sd | min | max |")
     print("|---|---|---|---|---|---|---|")
     for c, (_, _, _, b) in CASES.items():

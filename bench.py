@@ -24,7 +24,8 @@ scatter / owner-reduce / table-update kernels and device copies in place of the 
 prints the kernel-side cost of the exchange and the bytes every xGMI link would carry.
 
 Prints ONE JSON line (rank 0, the last line of stdout).  `roofline` describes the gather +
-WARP-score kernel against the HBM roofline (`traffic` = PMC bytes, profiles/score_kernel_pmc.json);
+WARP-score kernel against the HBM roofline (`traffic` = PMC bytes measured at this operating point,
+profiles/score_kernel_traffic.json + profiles/r03_counter_calibration.md, else null);
 `kernels` lists every kernel family's time inside the timed region (HIP events on the engine's
 streams; concurrent families include each other's contention); `kernels_standalone` comes from a
 second, UNTIMED pass with stream overlap off (N = 1): every family alone, with the sparse update's
@@ -95,6 +96,18 @@ def measured_ceiling(row_bytes: int, cached_table: bool):
     except Exception:
         return None
     return best
+
+
+def measured_traffic(which, rows_per_launch, k_mean, d):
+    """(upper, lower) HBM bytes per launch of the score kernel from profiles/score_kernel_traffic.json if that profile was taken
+    at this run's operating point (rows per launch and negatives per row within 5 %), else (None, None)."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "score_kernel_traffic.json")))[which]
+    except Exception:
+        return None, None
+    if d != 128 or abs(prof["rows_per_launch"] / max(rows_per_launch, 1) - 1) > 0.05 or abs(prof["mean_negatives_scored"] / max(k_mean, 1e-9) - 1) > 0.05:
+        return None, None
+    return prof["hbm_bytes_per_launch"], prof["hbm_bytes_per_launch_lower"]
 
 
 def cpu_baseline(args, model_kind=0, loss_kind=2):
@@ -187,6 +200,27 @@ def movielens_mrr():
     out["readme_example"] = dict(run(32, 1), config="lib.rs:22-58 / readme.md: max_sequence_length 32, dim 32, WARP, Adagrad, 10 epochs, batch_sequences 1",
                                  reference_says="about 10 seconds (readme.md:26, src/lib.rs:20; CPU unspecified)")
     return out
+
+
+def mrr_gemm(model, args, users=8192):
+    """`mrr_score` of the trained bench model over `users` synthetic test users against the whole catalogue (untimed
+    extra): the rank kernels' time from the engine's HIP events, priced at 2 * users * items * dim flop."""
+    tptr, titems = synthetic_csr(users, args.items, args.max_len, seed=7)
+    model.mrr_score(tptr[:257], titems[: int(tptr[256])])  # warm-up (first launch, allocations)
+    model.timing_enable(True)
+    model.timing_read()
+    t0 = time.perf_counter()
+    mrr, ranks = model.mrr_score(tptr, titems)
+    wall = time.perf_counter() - t0
+    tm = model.timing_read()
+    model.timing_enable(False)
+    ms = tm["RANK"][0]
+    flops = 2.0 * len(ranks) * args.items * args.dim
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "rank_test_score + rank_gemm (v_mfma_f32_32x32x2_f32, rank-count epilogue) + rank_history", "bound": "mfma",
+            "users": int(len(ranks)), "items": args.items, "dim": args.dim, "rank_kernels_ms": ms, "launches": int(tm["RANK"][1]),
+            "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+            "mrr_score_wall_ms": 1e3 * wall, "mrr": float(mrr), "note": "untimed extra; the U x I score matrix is never materialised"}
 
 
 def quality_neutral_batch():
@@ -507,8 +541,9 @@ def main():
                 cptr, citems = synthetic_csr(args.users, args.cold_items, args.max_len)
                 _, sc_ms, rpl, kc, _ = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.cold_items), cptr, citems, 3, 1)
                 cb = ((2 + kc) * 4 * args.dim + (1 + kc) * 4) * rpl
+                ct, ctl = measured_traffic("cold", rpl, kc, args.dim) if args.cold_items == 4_000_000 else (None, None)
                 cold = {"items": args.cold_items, "table_bytes": args.cold_items * args.dim * 4, "avg_launch_ms": sc_ms,
-                        "mean_negatives_scored": kc, "algorithmic_bytes_per_launch": cb,
+                        "mean_negatives_scored": kc, "algorithmic_bytes_per_launch": cb, "traffic": ct, "traffic_lower": ctl,
                         "achieved": cb / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": cb / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 del cptr, citems
@@ -542,20 +577,15 @@ def main():
             bytes_per_row = (2 + k_mean) * 4 * d + (1 + k_mean) * 4
             bytes_per_launch = bytes_per_row * rows_per_launch
             achieved = bytes_per_launch / (score["ms_per_launch"] * 1e-3) / 1e9
-            # HBM bytes per launch from the rocprofv3 PMC passes of the default bench command (FETCH_SIZE and
-            # WRITE_SIZE in separate runs, gfx950 half-count correction applied; profiles/score_kernel_pmc.json);
-            # for a different batch or k it is scaled by this run's algorithmic bytes over the profiled run's
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "score_kernel_pmc.json")
-            if os.path.exists(pmc) and d == 128:
-                try:
-                    prof = json.load(open(pmc))
-                    traffic = prof["hbm_bytes_per_launch"] * bytes_per_launch / prof["profiled_run"]["algorithmic_bytes_per_launch"]
-                except Exception:
-                    traffic = None
+            # HBM bytes per launch MEASURED for this very configuration: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+            # runs) around the default bench command, the timed dispatches only, corrected per profiles/r03_counter_calibration.md;
+            # printed only when this run's rows per launch and mean k are within 5 % of the profiled run's, else null
+            traffic, traffic_lower = measured_traffic("warm", rows_per_launch, k_mean, d)
             roofline = {"kernel": "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)", "bound": "hbm",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "traffic": traffic, "traffic_lower": traffic_lower,
+                        "traffic_source": "profiles/score_kernel_traffic.json (PMC, same command; interval: profiles/r03_counter_calibration.md)" if traffic else None,
+                        "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
                         "avg_launch_ms": score["ms_per_launch"]}
             ceil = measured_ceiling(4 * d, cached_table=args.items * d * 4 < (1 << 30))
@@ -642,6 +672,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, model_kind, loss_kind)
             except Exception as e:  # the throughput line must survive a host-side problem (e.g. memory limits)
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_mrr and not args.partition_table:
+            try:  # evaluation.rs:27-41 at catalogue scale: [users x d] . [d x items] on f32 MFMA with the rank count in the epilogue
+                out["mrr_gemm"] = mrr_gemm(model, args)
+            except Exception as e:
+                out["mrr_gemm"] = {"error": repr(e)}
         if world == 1 and not args.no_mrr:
             try:
                 out["test_mrr"] = movielens_mrr()

@@ -2308,38 +2308,48 @@ __global__ void rank_test_score_kernel(ModelView m, const float* reps, const int
     ranks[u] = 0;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void rank_gemm_kernel(ModelView m, const float* reps, const int* rep_row, uint32_t num_users,
-                                                        const float* ts, uint32_t items_per_group, uint32_t* ranks,
-                                                        uint32_t* nonfinite_flag) {
+template <int D, int UW>
+__global__ __launch_bounds__(256, UW == 1 ? (D <= 128 ? 4 : 2) : (D * UW <= 64 ? 4 : (D * UW <= 128 ? 3 : 2))) void rank_gemm_kernel(ModelView m, const float* reps, const int* rep_row, uint32_t num_users,
+                                                                            const float* ts, uint32_t items_per_group, uint32_t* ranks,
+                                                                            uint32_t* nonfinite_flag) {
+    // UW = 32-user tiles per wave (a workgroup owns 128 * UW users): every staged 32-item tile of E feeds UW x 64 MFMAs per
+    // wave between two barriers — UW = 2 halves the barriers, the LDS fills and the L2 traffic per flop at half the waves
     constexpr int LDE = D + 1;
     constexpr int KS = D / 2;  // MFMA k-steps
+    constexpr int WGU = 128 * UW;  // users per workgroup
     __shared__ float Es[2][32 * LDE];
     __shared__ float Bs[2][32];
+    // thresholds of the workgroup's users in the order the accumulator registers want them: Ts[wave][tile][hh][q] = threshold
+    // of user (wave * UW + tile) * 32 + (q & 3) + 8 (q >> 2) + 4 hh — read back per item tile as 16-byte broadcasts instead of
+    // living in 16 registers per user tile
+    __shared__ float Ts[4][UW][2][16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l31 = lane & 31;
     const int hh = lane >> 5;
-    const uint32_t u0 = blockIdx.x * 128 + wave * 32;
-    // A fragments of this wave's 32 users: a[s] = h[u0 + l31][2 s + hh], held for the whole item range
-    float a[KS];
-    {
-        const uint32_t u = u0 + l31;
+    const uint32_t u0 = blockIdx.x * WGU + wave * 32 * UW;
+    // A fragments of this wave's users: a[t][s] = h[u0 + 32 t + l31][2 s + hh], held for the whole item range
+    float a[UW][KS];
+#pragma unroll
+    for (int t = 0; t < UW; ++t) {
+        const uint32_t u = u0 + 32 * t + l31;
         const float* h = reps + (size_t)rep_row[u < num_users ? u : num_users - 1] * D;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) a[s] = u < num_users ? h[2 * s + hh] : 0.0f;
+        for (int s = 0; s < KS; ++s) a[t][s] = u < num_users ? h[2 * s + hh] : 0.0f;
     }
-    // thresholds of the 16 users this lane's accumulator registers belong to
-    float tsr[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const uint32_t u = u0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-        tsr[q] = u < num_users ? ts[u] : 0.0f;
+    for (int e = tid; e < 4 * UW * 32; e += 256) {
+        const int w2 = e / (UW * 32), t2 = (e / 32) % UW, h2 = (e >> 4) & 1, q = e & 15;
+        const uint32_t u = blockIdx.x * WGU + (w2 * UW + t2) * 32 + (q & 3) + 8 * (q >> 2) + 4 * h2;
+        Ts[w2][t2][h2][q] = u < num_users ? ts[u] : 0.0f;
     }
-    int cnt[16];
+    // per-lane counters of "score >= threshold", two 16-bit counters per register (a lane adds at most one per tile and
+    // register: the launcher keeps an item range below 65 536 tiles)
+    uint32_t cnt2[UW][8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) cnt[q] = 0;
+    for (int t = 0; t < UW; ++t)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cnt2[t][q] = 0;
     bool bad = false;
     const uint32_t i_begin = blockIdx.y * items_per_group;
     uint32_t i_end = i_begin + items_per_group;
@@ -2382,34 +2392,50 @@ __global__ __launch_bounds__(256) void rank_gemm_kernel(ModelView m, const float
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
         if (tile + 1 < ntiles) fetch(tile + 1);
-        f32x16 acc;
+        f32x16 acc[UW];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        for (int t = 0; t < UW; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
         const float* eb = &Es[buf][l31 * LDE + hh];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], eb[2 * s], acc, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) {
+            const float bvs = eb[2 * s];
+#pragma unroll
+            for (int t = 0; t < UW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], bvs, acc[t], 0, 0, 0);
+        }
         const float bias = Bs[buf][l31];
         const bool item_ok = i_begin + (uint32_t)tile * 32 + l31 < i_end;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float sc = bias + acc[q];
-            if (item_ok) {
-                if (!(sc - sc == 0.0f)) bad = true;
-                if (sc >= tsr[q]) ++cnt[q];
+        for (int t = 0; t < UW; ++t)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 t4 = ld4(&Ts[wave][t][hh][4 * q4]);
+                const float tq[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 4 * q4 + j;
+                    const float sc = bias + acc[t][q];
+                    if (item_ok) {
+                        if (!(sc - sc == 0.0f)) bad = true;
+                        if (sc >= tq[j]) cnt2[t][q >> 1] += (q & 1) ? 0x10000u : 1u;
+                    }
+                }
             }
-        }
         if (tile + 1 < ntiles) stage(buf ^ 1);
         __syncthreads();
     }
     // per-user totals: sum over the 32 item lanes of each half-wave
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        int c = cnt[q];
+    for (int t = 0; t < UW; ++t)
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
-        const uint32_t u = u0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-        if (l31 == 0 && u < num_users && c) atomicAdd(&ranks[u], (uint32_t)c);
-    }
+        for (int q = 0; q < 16; ++q) {
+            int c = (int)((cnt2[t][q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+            const uint32_t u = u0 + 32 * t + (q & 3) + 8 * (q >> 2) + 4 * hh;
+            if (l31 == 0 && u < num_users && c) atomicAdd(&ranks[u], (uint32_t)c);
+        }
     if (__any(bad) && lane == 0) atomicOr(nonfinite_flag, 1u);
 }
 
@@ -2812,18 +2838,31 @@ void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint
                  const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, float* ts_scratch,
                  uint32_t* ranks, uint32_t* nonfinite_flag, hipStream_t s) {
     if (num_users == 0) return;
-    const uint32_t utiles = (num_users + 127) / 128;
-    // item groups: enough workgroups to fill the chip, at least one 32-item tile each
-    uint32_t groups = (1024 + utiles - 1) / utiles;
+    // 32 users per wave (128 per workgroup, four waves per SIMD); SBR_RANK_UW = 2 selects the 64-users-per-wave form (half the
+    // barriers and LDS fills per flop at half the waves), which measured 5 % slower — kept as the A/B and test switch
+    static const int uw_env = std::getenv("SBR_RANK_UW") ? std::atoi(std::getenv("SBR_RANK_UW")) : 0;
+    const int uw = m.d > 128 ? 1 : uw_env ? uw_env : 1; /* measured at 8 192 users x 1e6 items, d = 128: 105 TFLOP/s with 32 users per wave, 100 with 64 */
+    const uint32_t wgu = 128u * (uint32_t)uw;
+    const uint32_t utiles = (num_users + wgu - 1) / wgu;
+    // item groups: at least one 32-item tile each, and MANY more workgroups than the chip holds at once (a launch of
+    // 1 024 workgroups on 768 resident slots ran one full round and a third of a second one)
+    static const uint32_t target_wgs = std::getenv("SBR_RANK_WGS") ? (uint32_t)std::atoi(std::getenv("SBR_RANK_WGS")) : 768u * 6u;
+    uint32_t groups = (target_wgs + utiles - 1) / utiles;
     const uint32_t max_groups = (m.num_items + 31) / 32;
     if (groups > max_groups) groups = max_groups;
     if (groups < 1) groups = 1;
     uint32_t per = (m.num_items + groups - 1) / groups;
     per = ((per + 31) / 32) * 32;
+    if (per > 65535u * 32u) per = 65535u * 32u; /* the kernel's per-lane counters are 16 bits wide: fewer than 65 536 tiles per range */
     groups = (m.num_items + per - 1) / per;
     DISPATCH_D(m.d, {
         hipLaunchKernelGGL((rank_test_score_kernel<DD>), dim3((num_users + 255) / 256), dim3(256), 0, s, m, reps, rep_row, num_users, test_item, test_in_hist, ts_scratch, ranks);
-        hipLaunchKernelGGL((rank_gemm_kernel<DD>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
+        if constexpr (DD <= 128) {
+            if (uw == 2) hipLaunchKernelGGL((rank_gemm_kernel<DD, 2>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
+            else hipLaunchKernelGGL((rank_gemm_kernel<DD, 1>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
+        } else {
+            hipLaunchKernelGGL((rank_gemm_kernel<DD, 1>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
+        }
         hipLaunchKernelGGL((rank_history_kernel<DD>), dim3(num_users), dim3(64), 0, s, m, reps, rep_row, ts_scratch, hist_ptr, hist_items, ranks);
     });
 }

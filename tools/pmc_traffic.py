@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d A -o run -- python bench.py --no-cpu-baseline --no-mrr
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d B -o run -- python bench.py --no-cpu-baseline --no-mrr
-    tools/pmc_traffic.py A/run_results.db B/run_results.db score_kernel 3 > profiles/score_kernel_pmc.json
+    tools/pmc_traffic.py A/run_results.db B/run_results.db score_kernel 3 > profiles/r02_score_kernel_pmc.json   (round 2; round 3: tools/pmc_dispatches.py + profiles/score_kernel_traffic.json)
 
 Counters are per dispatch; argument 4 = number of leading (warm-up) dispatches to skip.  Corrections
 per MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KiB; on gfx950 FETCH_SIZE

@@ -2268,7 +2268,10 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         if (user_ptr[u + 1] - user_ptr[u] >= 2) users.push_back(u);
     if (out_num_ranked) *out_num_ranked = users.size();
     std::vector<uint32_t> ranks(users.size(), 0);
-    const size_t EVAL_B = 2048;
+    /* users per scoring launch: the rank GEMM streams the item table once per 128 users whatever the launch size, but every
+     * launch has its ramp and tail — 8 192 users x 1e6 items at d = 128: 104 / 108 / 109 / 112 TFLOP/s at 1 024 / 2 048 /
+     * 4 096 / 8 192 users per launch (SBR_EVAL_USERS overrides: the A/B switch) */
+    static const size_t EVAL_B = std::getenv("SBR_EVAL_USERS") ? (size_t)std::atoi(std::getenv("SBR_EVAL_USERS")) : 8192;
     for (size_t c0 = 0; c0 < users.size(); c0 += EVAL_B) {
         const size_t c1 = std::min(c0 + EVAL_B, users.size());
         const size_t nu = c1 - c0;

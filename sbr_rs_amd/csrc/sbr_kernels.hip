@@ -2559,7 +2559,7 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
                 /* 16-sequence tiles for small minibatches: below SBR_SEQ_RT1_MAX_TILES 32-sequence tiles the chip is not
                  * full and the kernel time is the longest tile's chain of dependent steps — half-size tiles halve the step */
                 const bool tiny = rt_env ? rt_env == 1 : (mb.B + 31) / 32 < SBR_SEQ_RT1_MAX_TILES;
-                if (tiny && DD >= 64) {
+                if (tiny) {  /* every d <= 128: at d = 32 a 16-row step is 64 MFMAs per wave instead of 128 */
                     constexpr int RT = 1;
                     const int ntiles = (mb.B + 16 * RT - 1) / (16 * RT);
                     if (m.ng == 4)
@@ -2666,7 +2666,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
                         launched = true;
                     }
                 }
-                if constexpr (DD >= 64 && DD <= 128) {
+                if constexpr (DD <= 128) {
                     const bool tiny = rt_env ? rt_env == 1 : (b_host + 31) / 32 < SBR_SEQ_RT1_MAX_TILES;
                     if (tiny && !launched) { /* 16-sequence tiles (see launch_recurrent_forward) */
                         const int ntiles = (b_host + 15) / 16;

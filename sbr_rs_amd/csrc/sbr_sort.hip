@@ -23,6 +23,8 @@
 
 #include "sbr_kernels.h"
 
+#include <cstdlib>
+
 #include "../../include/sbr_hip.h"
 #include "sbr_numerics.h"
 
@@ -263,6 +265,78 @@ __global__ __launch_bounds__(1024) void head_scan_kernel(uint32_t* __restrict__ 
     }
 }
 
+// ---- small inputs: everything in ONE launch -------------------------------------------------------
+// Up to SMALL_N keys (a minibatch of one or a few sequences — the reference's own schedule is one subsequence per
+// optimiser step, sequence_model.rs:111-169, i.e. ~10^2 keys) fit the LDS of one workgroup twice over: one wave generates
+// the keys into LDS, runs every radix pass there (histogram, 64-lane scan of the bins, the same ballot-ranked stable
+// scatter as radix_scatter_kernel, ping-pong between two LDS arrays), writes the ordered keys out and lists the segment
+// heads — nine launches of the general path become one, which is what a step of ~10^2 rows is made of.
+constexpr int SMALL_N = 4096;
+template <class Src>
+__global__ __launch_bounds__(64) void small_sort_kernel(Src src, uint32_t n, int passes, int digit_bits, uint64_t* __restrict__ out,
+                                                        uint32_t* __restrict__ head_pos, uint32_t* __restrict__ nheads) {
+    __shared__ uint64_t ka[SMALL_N], kb[SMALL_N];
+    __shared__ uint32_t h[1 << SORT_MAX_DIGIT_BITS];
+    const int lane = threadIdx.x;
+    const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (uint32_t e = lane; e < n; e += 64) ka[e] = src(e);
+    uint64_t* from = ka;
+    uint64_t* to = kb;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * digit_bits;
+        for (uint32_t b = lane; b < nb; b += 64) h[b] = 0u;
+        __syncthreads();
+        for (uint32_t e = lane; e < n; e += 64) atomicAdd(&h[((uint32_t)(from[e] >> 32) >> shift) & mask], 1u);
+        __syncthreads();
+        {   // exclusive scan of the bins: lane l owns bins l*per .. l*per + per - 1
+            const uint32_t per = nb >> 6;
+            uint32_t sum = 0;
+            for (uint32_t j = 0; j < per; ++j) sum += h[lane * per + j];
+            uint32_t run = wave_inclusive_scan(sum, lane) - sum;
+            for (uint32_t j = 0; j < per; ++j) {
+                const uint32_t c = h[lane * per + j];
+                h[lane * per + j] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            const bool valid = e < n;
+            const uint64_t k = valid ? from[e] : 0ull;
+            const uint32_t d = ((uint32_t)(k >> 32) >> shift) & mask;
+            uint64_t same = __ballot(valid);
+            for (int b = 0; b < digit_bits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t vote = __ballot(bit);
+                same &= bit ? vote : ~vote;
+            }
+            if (valid) {
+                to[h[d] + (uint32_t)__popcll(same & lt)] = k;
+                if ((same >> lane) == 1ull) h[d] += (uint32_t)__popcll(same);
+            }
+        }
+        __syncthreads();
+        uint64_t* t = from; from = to; to = t;
+    }
+    uint32_t heads = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool valid = e < n;
+        const uint64_t k = valid ? from[e] : 0ull;
+        const bool head = valid && (e == 0 || (uint32_t)(k >> 32) != (uint32_t)(from[e - 1] >> 32));
+        if (valid) out[e] = k;
+        const uint64_t m = __ballot(head);
+        if (head) head_pos[heads + (uint32_t)__popcll(m & lt)] = e;
+        heads += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) {
+        *nheads = heads;
+        head_pos[heads] = n;
+    }
+}
+
 struct Scratch {
     uint32_t *counts, *bintotal, *tile_heads;
 };
@@ -309,12 +383,31 @@ void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint6
     }
 }
 
+// keys in (row, entry) order + segment heads: one launch for small inputs, the tiled passes otherwise
+template <class Src>
+void sort_and_list(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, uint32_t* head_pos,
+                   uint32_t* nheads, hipStream_t s);
+
 void list_heads(const uint64_t* keys_sorted, uint32_t n, const Scratch& sc, uint32_t* head_pos, uint32_t* nheads, hipStream_t s) {
     const uint32_t ntiles = tiles_of(n);
     const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
     hipLaunchKernelGGL((head_tiles_kernel<false>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
     hipLaunchKernelGGL(head_scan_kernel, dim3(1), dim3(1024), 0, s, sc.tile_heads, ntiles, n, nheads, head_pos);
     hipLaunchKernelGGL((head_tiles_kernel<true>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+}
+
+template <class Src>
+void sort_and_list(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, uint32_t* head_pos,
+                   uint32_t* nheads, hipStream_t s) {
+    const char* small_env = std::getenv("SBR_SORT_SMALL"); /* read per call: the tests run the tiled path on small inputs too */
+    const bool small_on = !(small_env && small_env[0] == '0');
+    if (n <= (uint32_t)SMALL_N && small_on) {
+        const PassPlan pp = plan_passes(row_bits);
+        hipLaunchKernelGGL((small_sort_kernel<Src>), dim3(1), dim3(64), 0, s, first, n, pp.passes, pp.digit_bits, out, head_pos, nheads);
+        return;
+    }
+    radix_sort(first, n, row_bits, tmp, out, sc, s);
+    list_heads(out, n, sc, head_pos, nheads, s);
 }
 
 }  // namespace
@@ -335,10 +428,10 @@ void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, u
     const int row_bits = key_bits - 32;
     const Scratch scr = carve(sort_temp, total, row_bits);
     if (early_mb)
-        radix_sort(SrcEarly{early_mb->in_idx, early_mb->out_idx, early_mb->ctr, epoch_key, num_items}, total, row_bits, keys, keys_sorted, scr, s);
+        sort_and_list(SrcEarly{early_mb->in_idx, early_mb->out_idx, early_mb->ctr, epoch_key, num_items}, total, row_bits, keys, keys_sorted, scr,
+                      sc.head_pos, sc.nheads, s);
     else
-        radix_sort(SrcBlock{blk.in_idx, blk.out_idx, blk.neg}, total, row_bits, keys, keys_sorted, scr, s);
-    list_heads(keys_sorted, total, scr, sc.head_pos, sc.nheads, s);
+        sort_and_list(SrcBlock{blk.in_idx, blk.out_idx, blk.neg}, total, row_bits, keys, keys_sorted, scr, sc.head_pos, sc.nheads, s);
 }
 
 void launch_merge_sort(const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp,
@@ -352,8 +445,7 @@ void launch_selftest_sort(const uint32_t* rows, uint32_t n, int row_bits, uint64
                           uint32_t* nheads, hipStream_t s) {
     if (n == 0) return;
     const Scratch scr = carve(temp, n, row_bits);
-    radix_sort(SrcRows{rows}, n, row_bits, tmp, out, scr, s);
-    list_heads(out, n, scr, head_pos, nheads, s);
+    sort_and_list(SrcRows{rows}, n, row_bits, tmp, out, scr, head_pos, nheads, s);
 }
 
 }  // namespace sbr

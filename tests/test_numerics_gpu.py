@@ -85,9 +85,12 @@ def test_mfma_is_fma_chain(L, k):
     (100_000, 11, "zipf"), (300_001, 20, "uniform"), (1_500_000, 20, "zipf"), (700_000, 24, "uniform"),
     (50_000, 32, "uniform"), (20_000, 3, "uniform"), (123_457, 17, "one_row"),
 ])
-def test_key_ordering_is_a_stable_sort_by_row(L, n, row_bits, dist):
+@pytest.mark.parametrize("small", ["1", "0"])
+def test_key_ordering_is_a_stable_sort_by_row(L, monkeypatch, n, row_bits, dist, small):
     """sbr_sort.hip against numpy's stable argsort: keys (row << 32 | e) in (row, e) order — one, two and three radix passes,
-    ragged last tiles, hot rows, a single row — and the ascending list of segment heads with its sentinel."""
+    ragged last tiles, hot rows, a single row — and the ascending list of segment heads with its sentinel.  Inputs of up to
+    4 096 keys take the single-launch LDS-resident form unless SBR_SORT_SMALL=0 sends them through the tiled passes."""
+    monkeypatch.setenv("SBR_SORT_SMALL", small)
     rs = np.random.RandomState(n % 9973 + row_bits)
     hi = (1 << row_bits) if row_bits < 32 else (1 << 32) - 1
     if dist == "uniform":

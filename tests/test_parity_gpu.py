@@ -761,6 +761,8 @@ def test_dense_gradient_wide_address_path(monkeypatch):
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "2"),
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, "4"),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "1"),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, "1"),
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, "1"),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "2"),
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "4"),
     (ModelKind.EWMA, LOSS_WARP, 256, None),

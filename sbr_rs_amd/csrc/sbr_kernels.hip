@@ -904,10 +904,12 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 if (t + 2 < nsteps) prefetch_idx(t + 2);
             }
         };
-        // 256-register form: x_{t+1} is gathered here and lands under the epilogue.  128-register form: after the epilogue
-        // (its registers would otherwise be spilled across it, and a spill of a just-requested row is a wait for the
-        // gather); the other resident workgroup covers the latency.
-        if constexpr (RT >= 4) request_next_x();
+        // 256-register form: x_{t+1} is gathered here and lands under the epilogue.  128-register form (32-sequence tiles):
+        // after the epilogue (its registers would otherwise be spilled across it, and a spill of a just-requested row is a
+        // wait for the gather); the other resident workgroup covers the latency.  16-sequence tiles hold ONE 16-byte piece
+        // of x per thread and run where a CU has one or two workgroups and nobody to cover a gather: requested here too.
+        constexpr bool EARLY_X = RT >= 4 || RT == 1;
+        if constexpr (EARLY_X) request_next_x();
         PROF_MARK(3)
         __syncthreads();  // every wave is done reading As
         PROF_MARK(4)
@@ -969,7 +971,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 }
         }
         PROF_MARK(5)
-        if constexpr (RT < 4) request_next_x();
+        if constexpr (!EARLY_X) request_next_x();
         row_begin = row_begin_next;
         nrows = nrows_next;
         if (more) stage();  // the x region of As is free since the barrier above

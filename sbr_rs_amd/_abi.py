@@ -65,7 +65,7 @@ class KernelFamily(enum.IntEnum):
 
 
 NUM_KERNEL_FAMILIES = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SbrHparams(C.Structure):

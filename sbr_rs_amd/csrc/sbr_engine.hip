@@ -564,7 +564,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 5; }
+uint32_t sbr_abi_version(void) { return 6; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {

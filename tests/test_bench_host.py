@@ -1,0 +1,52 @@
+"""CPU: the host-side bookkeeping of bench.py — which BASELINE.json config a run's shape is labelled as, when the measured
+HBM traffic of the score kernel may be printed, and the committed quality-neutral batch."""
+import json
+import os
+import types
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**kw):
+    base = dict(model="lstm", loss="warp", dim=128, items=1_000_000, users=100_000, max_len=64, partition_table=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_workload_labels_follow_baseline_configs():
+    assert bench.workload_label(_args(), 1) == "BASELINE.json configs[2]"
+    assert bench.workload_label(_args(users=125_000, max_len=128), 8) == "BASELINE.json configs[3]"
+    assert "configs[3]'s per-GPU shape at 4 GPUs" in bench.workload_label(_args(users=125_000, max_len=128), 4)
+    # configs[2]'s shape on several GPUs is not a BASELINE config, and neither is configs[3]'s shape on one
+    assert bench.workload_label(_args(), 8) == "custom workload"
+    assert bench.workload_label(_args(users=125_000, max_len=128), 1) == "custom workload"
+    c4 = _args(model="ewma", loss="hinge", dim=256, items=10_000_000, users=125_000, max_len=128, partition_table=True)
+    assert bench.workload_label(c4, 8) == "BASELINE.json configs[4]"
+    assert "configs[4]'s shape" in bench.workload_label(c4, 2)
+    assert bench.workload_label(_args(dim=64), 1) == "custom workload"
+
+
+def test_measured_traffic_is_printed_only_at_the_profiled_operating_point():
+    prof = json.load(open(os.path.join(ROOT, "profiles", "score_kernel_traffic.json")))
+    for which in ("warm", "cold"):
+        e = prof[which]
+        up, lo = bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], 128)
+        assert up == e["hbm_bytes_per_launch"] and lo == e["hbm_bytes_per_launch_lower"] and lo < up
+        assert 1.1 < lo / e["algorithmic_bytes_per_launch"] < up / e["algorithmic_bytes_per_launch"] < 1.4
+        assert bench.measured_traffic(which, e["rows_per_launch"] * 1.04, e["mean_negatives_scored"] * 0.97, 128)[0] == up
+        assert bench.measured_traffic(which, e["rows_per_launch"] * 1.08, e["mean_negatives_scored"], 128) == (None, None)
+        assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"] * 0.9, 128) == (None, None)
+        assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], 256) == (None, None)
+    assert bench.measured_traffic("absent", 1.0, 1.0, 128) == (None, None)
+
+
+def test_quality_neutral_batch_is_committed_with_its_evidence():
+    qn = bench.quality_neutral_batch()
+    assert qn and qn["batch_sequences"] == 8192
+    rows = {r["batch_sequences"]: r["mrr_mean"] for r in qn["rows"]}
+    base = rows[qn["reference_batch"]]
+    assert all(rows[b] >= 0.97 * base for b in rows if b <= qn["batch_sequences"])
+    assert rows[16384] < 0.97 * base and rows[50000] < 0.8 * base  # what the bench's default batch costs the LSTM
+    assert os.path.exists(os.path.join(ROOT, qn["table"]))

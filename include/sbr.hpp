@@ -432,7 +432,7 @@ inline std::vector<std::uint32_t> narrow(const std::vector<ItemId>& ids) {
 /// (sbr_group_create).
 class Replicas {
   public:
-    Replicas(sbr_hparams hp, bool partition_item_table) : hp_(hp) {
+    Replicas(sbr_hparams hp, bool partition_item_table) : hp_(hp), partitioned_(partition_item_table) {
         handles_.assign(hp.num_devices, nullptr);
         const sbr_status st = sbr_group_create(&hp, hp.num_devices, partition_item_table ? SBR_GROUP_PARTITION_ITEM_TABLE : 0u,
                                                handles_.data());
@@ -447,6 +447,8 @@ class Replicas {
 
     sbr_model* primary() const { return handles_[0]; }
     const sbr_hparams& hparams() const { return hp_; }
+    const std::vector<sbr_model*>& handles() const { return handles_; }
+    bool partitioned() const { return partitioned_; }
 
     Result<float, FittingError> fit(const data::CompressedInteractions& interactions) {
         float loss = 0.0f;
@@ -465,6 +467,7 @@ class Replicas {
         handles_.clear();
     }
     sbr_hparams hp_;
+    bool partitioned_ = false;
     std::vector<sbr_model*> handles_;
 };
 
@@ -513,6 +516,88 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
         std::vector<float> out(count);
         if (count) check(sbr_model_get_param(handle(), which, out.data(), count), "sbr_model_get_param");
         return out;
+    }
+
+    /// ≙ the serde derives on Hyperparameters / Parameters / the models (lstm.rs:38,204,386; ewma.rs:44,208,401; `bincode`
+    /// in Cargo.toml:18): hyper-parameters, every parameter and optimiser-state block, the two counters and the state of
+    /// the model RNG — everything the next `fit` depends on — in one little-endian file:
+    ///   "SBRM" u32 version  u32 sizeof(sbr_hparams)  sbr_hparams  u8 partitioned  u64 epoch  u64 optimiser steps
+    ///   u8 rng[16]  u32 blocks  { i32 which  u64 count  f32[count] } ...
+    /// A model built with num_threads(n) stores ONE copy (replicas are bit-identical by construction).
+    void save(const std::string& path) const {
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("save: cannot open " + path);
+        auto put = [&](const void* p, std::size_t n) { f.write(reinterpret_cast<const char*>(p), (std::streamsize)n); };
+        const std::uint32_t version = 1, hp_bytes = (std::uint32_t)sizeof(sbr_hparams);
+        put("SBRM", 4); put(&version, 4); put(&hp_bytes, 4);
+        const sbr_hparams hp = replicas_->hparams();
+        put(&hp, sizeof hp);
+        const std::uint8_t part = replicas_->partitioned() ? 1 : 0;
+        put(&part, 1);
+        std::uint64_t epoch = 0, steps = 0;
+        check(sbr_model_get_counters(handle(), &epoch, &steps), "sbr_model_get_counters");
+        put(&epoch, 8); put(&steps, 8);
+        std::uint8_t rng[16];
+        check(sbr_model_get_rng(handle(), rng), "sbr_model_get_rng");
+        put(rng, 16);
+        std::vector<std::pair<std::int32_t, std::vector<float>>> blocks;
+        for (int w = SBR_PARAM_ITEM_EMBEDDING; w <= SBR_PARAM_EWMA_ALPHA_M; ++w) {
+            std::vector<float> v = parameter((sbr_param)w);
+            if (!v.empty()) blocks.emplace_back((std::int32_t)w, std::move(v));
+        }
+        const std::uint32_t nb = (std::uint32_t)blocks.size();
+        put(&nb, 4);
+        for (const auto& b : blocks) {
+            const std::uint64_t count = b.second.size();
+            put(&b.first, 4); put(&count, 8); put(b.second.data(), count * sizeof(float));
+        }
+        if (!f) throw std::runtime_error("save: write failed: " + path);
+    }
+
+  protected:
+    /// Rebuilds the replicas of a saved model (one copy of a partitioned table, never n full tables) and restores the
+    /// saved state into every one of them: the next `fit` is the one the saved model would have run.
+    explicit ImplicitSequenceModel(const std::string& path, int expect_ewma) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("load: cannot open " + path);
+        auto get = [&](void* p, std::size_t n) {
+            f.read(reinterpret_cast<char*>(p), (std::streamsize)n);
+            if (!f) throw std::runtime_error("load: truncated file: " + path);
+        };
+        char magic[4];
+        std::uint32_t version = 0, hp_bytes = 0;
+        get(magic, 4); get(&version, 4); get(&hp_bytes, 4);
+        if (std::string(magic, 4) != "SBRM" || version != 1 || hp_bytes != sizeof(sbr_hparams))
+            throw std::runtime_error("load: not a model file of this library version: " + path);
+        sbr_hparams hp;
+        get(&hp, sizeof hp);
+        if ((hp.model == SBR_MODEL_EWMA) != (expect_ewma != 0)) throw std::runtime_error("load: the file holds the other model type: " + path);
+        std::uint8_t part = 0;
+        get(&part, 1);
+        std::uint64_t epoch = 0, steps = 0;
+        get(&epoch, 8); get(&steps, 8);
+        std::uint8_t rng[16];
+        get(rng, 16);
+        replicas_ = std::make_unique<Replicas>(hp, part != 0);
+        std::uint32_t nb = 0;
+        get(&nb, 4);
+        for (std::uint32_t i = 0; i < nb; ++i) {
+            std::int32_t which = 0;
+            std::uint64_t count = 0;
+            get(&which, 4); get(&count, 8);
+            std::vector<float> v(count);
+            get(v.data(), count * sizeof(float));
+            const bool table = which == SBR_PARAM_ITEM_EMBEDDING || which == SBR_PARAM_ITEM_EMBEDDING_ACC || which == SBR_PARAM_ITEM_BIAS ||
+                               which == SBR_PARAM_ITEM_BIAS_ACC || which == SBR_PARAM_ITEM_EMBEDDING_M || which == SBR_PARAM_ITEM_BIAS_M;
+            for (std::size_t r = 0; r < replicas_->handles().size(); ++r) {
+                if (part && table && r > 0) continue;  // a partitioned table exists once: written through replica 0
+                check(sbr_model_set_param(replicas_->handles()[r], (sbr_param)which, v.data(), count), "sbr_model_set_param");
+            }
+        }
+        for (sbr_model* h : replicas_->handles()) {
+            check(sbr_model_set_counters(h, epoch, steps), "sbr_model_set_counters");
+            check(sbr_model_set_rng(h, rng), "sbr_model_set_rng");
+        }
     }
 
   private:
@@ -616,6 +701,10 @@ enum class LSTMVariant { Normal, Coupled };
 /// An LSTM-based sequence model for implicit feedback (lstm.rs:386-416).
 class ImplicitLSTMModel : public detail::ImplicitSequenceModel {
     using detail::ImplicitSequenceModel::ImplicitSequenceModel;
+
+  public:
+    /// A model written by `save` (≙ deserialising the serde-derived ImplicitLSTMModel, lstm.rs:386).
+    static ImplicitLSTMModel load(const std::string& path) { return ImplicitLSTMModel(path, 0); }
 };
 
 /// Hyperparameters for the ImplicitLSTMModel (lstm.rs:39-202).
@@ -658,6 +747,10 @@ namespace ewma {
 /// Implicit EWMA model (ewma.rs:401-429).  State recurrence as coded at ewma.rs:302-313.
 class ImplicitEWMAModel : public detail::ImplicitSequenceModel {
     using detail::ImplicitSequenceModel::ImplicitSequenceModel;
+
+  public:
+    /// A model written by `save` (≙ deserialising the serde-derived ImplicitEWMAModel, ewma.rs:401).
+    static ImplicitEWMAModel load(const std::string& path) { return ImplicitEWMAModel(path, 1); }
 };
 
 /// Hyperparameters describing the EWMA model (ewma.rs:45-206).

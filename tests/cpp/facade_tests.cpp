@@ -334,6 +334,50 @@ static void partitioned_equals_replicated() {
     std::printf("partitioned=ok loss=%.9g\n", l1);
 }
 
+// ≙ the serde derives (lstm.rs:38,204,386; ewma.rs:44,208,401): a saved model comes back with its parameters,
+// optimiser state, counters and RNG, continues training exactly like the original — also with several replicas and
+// with the item table stored once
+static void save_load_roundtrip(const std::string& dir) {
+    const std::size_t num_users = 90, num_items = 1500;
+    XorShiftRng rng = XorShiftRng::from_seed(seed42());
+    Interactions all(num_users, num_items);
+    for (std::size_t u = 0; u < num_users; ++u) {
+        const std::size_t n = 3 + rng.below(20);
+        for (std::size_t t = 0; t < n; ++t) all.push(Interaction(u, rng.below(num_items), t));
+    }
+    const CompressedInteractions train = all.to_compressed();
+    {   // LSTM, Adam (first and second moments travel too), one replica
+        auto a = models::lstm::Hyperparameters::new_(num_items, 16).from_seed(seed42()).embedding_dim(32).num_epochs(2).batch_sequences(5).build();
+        a.fit(train).unwrap();
+        a.save(dir + "/lstm.sbrm");
+        auto b = models::lstm::ImplicitLSTMModel::load(dir + "/lstm.sbrm");
+        for (int w = SBR_PARAM_ITEM_EMBEDDING; w <= SBR_PARAM_EWMA_ALPHA_M; ++w) CHECK(a.parameter((sbr_param)w) == b.parameter((sbr_param)w));
+        const float la = a.fit(train).unwrap(), lb = b.fit(train).unwrap();
+        CHECK(bits(la) == bits(lb));
+        CHECK(a.parameter(SBR_PARAM_ITEM_EMBEDDING) == b.parameter(SBR_PARAM_ITEM_EMBEDDING));
+        CHECK(a.parameter(SBR_PARAM_LSTM_W_M) == b.parameter(SBR_PARAM_LSTM_W_M));
+        bool refused = false;
+        try { (void)models::ewma::ImplicitEWMAModel::load(dir + "/lstm.sbrm"); } catch (const std::runtime_error&) { refused = true; }
+        CHECK(refused);
+    }
+    {   // EWMA, three replicas over ONE copy of the table
+        auto a = models::ewma::Hyperparameters::new_(num_items, 16).from_seed(seed42()).embedding_dim(64).loss(Loss::Hinge)
+                     .optimizer(Optimizer::Adagrad).learning_rate(0.16f).num_epochs(2).num_threads(3).batch_sequences(7)
+                     .partition_item_table(true).build();
+        a.fit(train).unwrap();
+        a.save(dir + "/ewma.sbrm");
+        auto b = models::ewma::ImplicitEWMAModel::load(dir + "/ewma.sbrm");
+        std::int32_t part = 0;
+        CHECK(sbr_model_is_partitioned(b.handle(), &part) == SBR_OK && part == 1);
+        const float la = a.fit(train).unwrap(), lb = b.fit(train).unwrap();
+        CHECK(bits(la) == bits(lb));
+        CHECK(a.parameter(SBR_PARAM_ITEM_EMBEDDING) == b.parameter(SBR_PARAM_ITEM_EMBEDDING));
+        CHECK(a.parameter(SBR_PARAM_EWMA_ALPHA_ACC) == b.parameter(SBR_PARAM_EWMA_ALPHA_ACC));
+        CHECK(bits(mrr_score(a, train).unwrap()) == bits(mrr_score(b, train).unwrap()));
+    }
+    std::printf("save_load=ok\n");
+}
+
 static void no_device() {
     // without a GPU the engine must refuse, not fall back
     try {
@@ -356,6 +400,7 @@ int main(int argc, char** argv) {
         else if (which == "empty_interactions") empty_interactions();
         else if (which == "defaults_and_predict") defaults_and_predict();
         else if (which == "partitioned_equals_replicated") partitioned_equals_replicated();
+        else if (which == "save_load_roundtrip") save_load_roundtrip(arg);
         else if (which == "mrr_test_single_thread") mrr_test_single_thread(arg);
         else if (which == "mrr_test_two_threads") mrr_test_two_threads(arg);
         else if (which == "mrr_test_warp") mrr_test_warp(arg);

@@ -109,6 +109,13 @@ def test_empty_interactions_and_defaults(facade):
 
 
 @pytest.mark.gpu
+def test_save_load_roundtrip_in_cpp(facade, tmp_path):
+    """≙ the serde derives: `model.save(path)` / `Implicit*Model::load(path)` of the C++ host layer — parameters,
+    optimiser state (Adam moments included), counters and RNG; one replica and three replicas over a partitioned table."""
+    assert run(facade, "save_load_roundtrip", str(tmp_path))[1].get("save_load") == "ok"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case,kind,loss,threads,T,B", [
     ("mrr_test_single_thread", ModelKind.LSTM_NORMAL, LOSS_HINGE, 1, 128, 8),  # lstm.rs:451-473
     ("mrr_test_two_threads", ModelKind.LSTM_NORMAL, LOSS_HINGE, 2, 128, 8),    # lstm.rs:475-497

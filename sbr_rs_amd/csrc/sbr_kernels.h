@@ -98,6 +98,11 @@ struct PeerLists {
 /* recurrent forward over all steps of the minibatch (LSTM d <= 128: one sequence-resident launch; d = 256: one launch per step) */
 void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
                               const int* off_host, hipStream_t s);
+/* sbr_wave.hip: the wave-per-sequence form of the recurrent pass for small minibatches at d <= 32 (false: not taken, the
+ * caller launches the tile kernels; same outputs bit for bit) */
+bool launch_wave_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host, hipStream_t s);
+bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int tm_host, int b_host,
+                          hipStream_t s);
 /* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s);

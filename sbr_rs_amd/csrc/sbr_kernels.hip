@@ -2547,6 +2547,7 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
         });
         return;
     }
+    if (launch_wave_forward(m, mb, H, w, tm_host, s)) return; /* small minibatch at d <= 32: one wave per sequence (sbr_wave.hip) */
     /* d = 256 keeps the per-step launches here: 16 unit tiles x 32-row tiles fill the chip at every step, and the
      * resident form would stream the 2 MiB of weights per 32 rows (measured 8.3 vs 7.9 ms at 20 000 sequences); the
      * BPTT kernel below does take the resident form at d = 256 (7.3 vs 9.3 ms) */
@@ -2643,6 +2644,7 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
         });
         return; /* dalpha: launch_dense_gradient (the side stream, beside the sparse update) */
     }
+    if (launch_wave_backward(m, mb, blk, w, tm_host, b_host, s)) return; /* small minibatch at d <= 32 (sbr_wave.hip) */
     bool stepwise = true;
     /* d = 256: 16 waves per workgroup leave 128 registers per wave, i.e. only the 32-sequence form, one workgroup per CU;
      * its time has a floor of ~4.8 ms (the longest tile's 63 dependent steps), so below ~320 tiles the per-step launches

@@ -784,6 +784,41 @@ def test_many_tiles_per_minibatch(monkeypatch, kind, loss, d, rt):
     assert_params_equal(g, o, kind, "many tiles")
 
 
+@pytest.mark.parametrize("kind,loss,d,B,T", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 1, 40),    # the reference's own schedule: one subsequence per optimiser step
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 32, 1, 17),
+    (ModelKind.LSTM_NORMAL, LOSS_BPR, 16, 1, 23),
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 3, 9),
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 32, 7, 12),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 64, 30),
+])
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_wave_per_sequence_form(monkeypatch, kind, loss, d, B, T, wave):
+    """Small minibatches at d <= 32 run the recurrent pass with one wave per sequence on the vector ALU (sbr_wave.hip);
+    SBR_WAVE = 0 forces the MFMA tile kernels instead.  Whole-fit parity with the oracle, bit for bit, in both forms
+    (so the two forms agree with each other too), over ragged lengths including length-2 subsequences."""
+    monkeypatch.setenv("SBR_WAVE", wave)
+    users, items = 60, 301
+    ptr, it = synthetic_interactions(users, items, T, seed=91 + d + B, min_len=2)
+    hp = hparams(items, T, d, int(kind), loss, epochs=2, B=B)
+    g, o = make_pair(hp)
+    lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    assert_params_equal(g, o, kind, f"wave={wave}")
+
+
+def test_wave_form_falls_back_for_long_sequences(monkeypatch):
+    """The wave form stages every step of a sequence in LDS; a max_sequence_length that does not fit (here 300 steps at
+    d = 32) takes the tile kernels even when SBR_WAVE = 1 asks for the wave form."""
+    monkeypatch.setenv("SBR_WAVE", "1")
+    users, items, T = 12, 101, 300
+    ptr, it = synthetic_interactions(users, items, T, seed=5, min_len=250)
+    hp = hparams(items, T, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, epochs=1, B=2)
+    g, o = make_pair(hp)
+    assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+    assert_params_equal(g, o, ModelKind.LSTM_NORMAL, "long sequences")
+
+
 def test_full_size_properties():
     """BASELINE.json configs[2] at full size (100 000 users x 1 000 000 items, len <= 64, d = 128, LSTM +
     WARP, 50 000 sequences per step) is far beyond what the oracle can run, so the checks are

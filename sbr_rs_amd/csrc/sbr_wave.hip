@@ -35,6 +35,31 @@ constexpr size_t WAVE_LDS_LIMIT = 150 * 1024;
 
 __device__ __forceinline__ float4 ld4w(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4w(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float x) { return (v2f){x, x}; }
+// sbr_tanh_pq (sbr_approx.h) on two arguments at once: packed f32 arithmetic, the same operations per element
+__device__ __forceinline__ void tanh_pq2(v2f x, v2f* p, v2f* q) {
+    x.x = x.x > SBR_TANH_CLAMP ? SBR_TANH_CLAMP : x.x;  // comparison + select: NaN stays NaN
+    x.x = x.x < -SBR_TANH_CLAMP ? -SBR_TANH_CLAMP : x.x;
+    x.y = x.y > SBR_TANH_CLAMP ? SBR_TANH_CLAMP : x.y;
+    x.y = x.y < -SBR_TANH_CLAMP ? -SBR_TANH_CLAMP : x.y;
+    const v2f x2 = x * x;
+    v2f n = pk_splat(-2.76076847742355e-16f);
+    n = pk_fma(n, x2, pk_splat(2.00018790482477e-13f));
+    n = pk_fma(n, x2, pk_splat(-8.60467152213735e-11f));
+    n = pk_fma(n, x2, pk_splat(5.12229709037114e-08f));
+    n = pk_fma(n, x2, pk_splat(1.48572235717979e-05f));
+    n = pk_fma(n, x2, pk_splat(6.37261928875436e-04f));
+    n = pk_fma(n, x2, pk_splat(4.89352455891786e-03f));
+    *p = n * x;
+    v2f dq = pk_splat(1.19825839466702e-06f);
+    dq = pk_fma(dq, x2, pk_splat(1.18534705686654e-04f));
+    dq = pk_fma(dq, x2, pk_splat(2.26843463243900e-03f));
+    dq = pk_fma(dq, x2, pk_splat(4.89352518554385e-03f));
+    *q = dq;
+}
 // LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order, so a write followed
 // by another lane's read needs no barrier — only the compiler must keep the program order
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -92,6 +117,75 @@ __global__ __launch_bounds__(256) void lstm_fwd_wave_kernel(ModelView m, MbView 
     // ---- the recurrence: wave 0 alone, no barriers
     const int lane = tid;
     const int u = lane % D, grp = lane / D;
+    if constexpr (D == 32 && NG == 4) {
+        // d = 32, four gates: lane l owns gate columns l and 64 + l — (i_u, g_u) in lanes u < 32, (f_u, o_u) in lanes 32 + u.
+        // Both chains advance in one packed fma per k; every lane evaluates the rational tanh of ITS two pre-activations
+        // (two, not four, per lane), and the numerators / denominators cross the wave halves with v_permlane32_swap —
+        // no LDS round trip between the chain and the cell.
+        v2f w2[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) w2[k] = (v2f){m.W[(size_t)(D + k) * NGD + lane], m.W[(size_t)(D + k) * NGD + 64 + lane]};
+        const bool low = lane < 32;
+        float c_prev = 0.0f, h_prev = 0.0f;
+#ifdef SBR_PROF_WAVE
+        const long long pc0 = clock64(), pw0 = wall_clock64();
+        long long pacc[4] = {0, 0, 0, 0}, pt = pc0;
+#define WPROF(k_) { const long long n_ = clock64(); pacc[k_] += n_ - pt; pt = n_; }
+#else
+#define WPROF(k_)
+#endif
+        for (int t = 0; t < nsteps; ++t) {
+            WPROF(3)
+            v2f z2 = (v2f){Ps[t * NGD + lane], Ps[t * NGD + 64 + lane]};
+            // h_{t-1}[k] lives in lane k: a v_readlane per k puts it into a scalar register (no LDS round trip between the
+            // cell and the chain; the reads do not depend on the chain and fill its dependent-issue gaps)
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float hk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h_prev), k));
+                z2 = pk_fma(pk_splat(hk), w2[k], z2);
+            }
+            WPROF(0)
+            // arguments of the rational tanh: i, f, o are sigmoids (tanh of half the pre-activation), g is a tanh
+            const float half1 = 0.5f * z2.y;
+            v2f p2, q2;
+            tanh_pq2((v2f){0.5f * z2.x, low ? z2.y : half1}, &p2, &q2);
+            const v2u sp0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p2.x), __float_as_uint(p2.x), false, false);
+            const v2u sq0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2.x), __float_as_uint(q2.x), false, false);
+            const v2u sp1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p2.y), __float_as_uint(p2.y), false, false);
+            const v2u sq1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(q2.y), __float_as_uint(q2.y), false, false);
+            // .x = the value of lane u (lower half), .y = the value of lane 32 + u, in both halves
+            const float pi = __uint_as_float(sp0.x), pf = __uint_as_float(sp0.y), qi = __uint_as_float(sq0.x), qf = __uint_as_float(sq0.y);
+            const float pg = __uint_as_float(sp1.x), po = __uint_as_float(sp1.y), qg = __uint_as_float(sq1.x), qo = __uint_as_float(sq1.y);
+            // sbr_lstm_cell_fwd from here on, operation for operation
+            const float q_if = qi * qf, q_go = qg * qo;
+            const float r = 1.0f / (q_if * q_go);
+            const float r_if = r * q_go, r_go = r * q_if;
+            const float gf = sbr_fma(0.5f, pf * (r_if * qi), 0.5f);
+            const float gi = sbr_fma(0.5f, pi * (r_if * qf), 0.5f);
+            const float gg = pg * (r_go * qo);
+            const float go = sbr_fma(0.5f, po * (r_go * qg), 0.5f);
+            const float cc = sbr_fma(gf, c_prev, gi * gg);
+            c_prev = cc;
+            WPROF(1)
+            const int r_ = __builtin_amdgcn_readfirstlane(Rs[t]);
+            float* Grow = w.G + (size_t)r_ * 4 * D;
+            Grow[lane] = low ? gi : gf;
+            Grow[64 + lane] = low ? gg : go;
+            h_prev = go * sbr_tanhf(cc);
+            if (low) {
+                w.C[(size_t)r_ * D + u] = cc;
+                H[(size_t)r_ * D + u] = h_prev;
+            }
+            WPROF(2)
+        }
+#ifdef SBR_PROF_WAVE
+        if (lane == 0 && b == 0 && nsteps > 100)
+            printf("WAVEPROF fwd steps %d: cycles/step %lld (chain %lld, cell %lld, tanh(c)+stores %lld, loop %lld); shader clock %.0f MHz\n", nsteps,
+                   (clock64() - pc0) / nsteps, pacc[0] / nsteps, pacc[1] / nsteps, pacc[2] / nsteps, pacc[3] / nsteps,
+                   (double)(clock64() - pc0) / (double)(wall_clock64() - pw0) * 100.0);
+#endif
+        return;
+    }
     float wh[SLOTS][D];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
@@ -155,11 +249,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
     float* Gs = lds;               // [Tm][4D] gate values
     float* Cs = Gs + Tm * 4 * D;   // [Tm][D]  cell states
     float* DHs = Cs + Tm * D;      // [Tm][D]  dloss/dh
-    float* Zs = DHs + Tm * D;      // [NGD]    dz of the current step
-    float* DHr = Zs + NGD;         // [D]      recurrent dh from step t+1
-    int* Rs = reinterpret_cast<int*>(DHr + D);
+    float* TCs = DHs + Tm * D;     // [Tm][D]  tanh(c_t)
+    float* Zs = TCs + Tm * D;      // [NGD]    dz of the current step
+    int* Rs = reinterpret_cast<int*>(Zs + NGD);  // [Tm] packed row of step t
     for (int t = tid; t < nsteps; t += 256) Rs[t] = mb.off[t] + b;
-    if (tid < D) DHr[tid] = 0.0f;
     __syncthreads();
     for (int idx = tid; idx < nsteps * Q; idx += 256) {
         const int t = idx / Q, c4 = (idx % Q) * 4;
@@ -173,7 +266,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
         dh.z = g * en.z - g * ep.z;
         dh.w = g * en.w - g * ep.w;
         st4w(&DHs[t * D + c4], dh);
-        st4w(&Cs[t * D + c4], ld4w(w.C + r * D + c4));
+        const float4 cv = ld4w(w.C + r * D + c4);
+        st4w(&Cs[t * D + c4], cv);
+        // tanh(c_t): the one transcendental of the cell backward does not depend on the gradient coming down the sequence,
+        // so all 256 threads evaluate it here instead of the lone recurrence wave (which pays ~7 cycles per instruction)
+        st4w(&TCs[t * D + c4], make_float4(sbr_tanhf(cv.x), sbr_tanhf(cv.y), sbr_tanhf(cv.z), sbr_tanhf(cv.w)));
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) st4w(&Gs[t * 4 * D + g4 * D + c4], ld4w(w.G + r * 4 * D + g4 * D + c4));
     }
@@ -188,17 +285,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
         const float4 v = ld4w(m.W + (size_t)col * NGD + j);
         wt[j] = v.x; wt[j + 1] = v.y; wt[j + 2] = v.z; wt[j + 3] = v.w;
     }
-    float dc = 0.0f;
+    float dc = 0.0f, rec = 0.0f;  // carry of the cell state gradient, recurrent dh of unit u (every lane group holds both)
     for (int t = nsteps - 1; t >= 0; --t) {
         const bool carried = t + 1 < nsteps;  // the sequence has a step t+1: recurrent dh and dc exist
-        const float recv = carried ? DHr[u] : 0.0f;
-        const float dh = DHs[t * D + u] + recv;
+        const float dh = DHs[t * D + u] + (carried ? rec : 0.0f);
         const float gi = Gs[t * 4 * D + u], gf = Gs[t * 4 * D + D + u], gg = Gs[t * 4 * D + 2 * D + u], go = Gs[t * 4 * D + 3 * D + u];
-        const float cc = Cs[t * D + u];
+        const float tc = TCs[t * D + u];
         const float cp = t > 0 ? Cs[(t - 1) * D + u] : 0.0f;
-        float dz[4], dco;
-        sbr_lstm_cell_bwd(dh, carried ? dc : 0.0f, gi, gf, gg, go, cc, cp, NG == 3, &dz[0], &dz[1], &dz[2], &dz[3], &dco);
-        dc = dco;
+        // sbr_lstm_cell_bwd, operation for operation (tanh(c_t) was formed in the staging phase)
+        const float d_o = dh * tc;
+        const float dcv = sbr_fma(dh * go, 1.0f - tc * tc, carried ? dc : 0.0f);
+        const float di = dcv * gg, dg = dcv * gi;
+        float df = dcv * cp;
+        dc = dcv * gf;
+        float dz[4];
+        if (NG == 3) { df = df - di; dz[0] = 0.0f; } else { dz[0] = di * (gi * (1.0f - gi)); }
+        dz[1] = df * (gf * (1.0f - gf));
+        dz[2] = dg * (1.0f - gg * gg);
+        dz[3] = d_o * (go * (1.0f - go));
         const int r = __builtin_amdgcn_readfirstlane(Rs[t]);
         float* dZrow = w.dZ + (size_t)r * NGD;
 #pragma unroll
@@ -214,7 +318,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
             }
         }
         wave_lds_fence();
-        float acc = 0.0f;
+        float acc = 0.0f;  // column `col` of dz W^T, j ascending from 0; dz read back as broadcast 16-byte pieces
 #pragma unroll
         for (int j = 0; j < NGD; j += 4) {
             const float4 zv = ld4w(&Zs[j]);
@@ -224,8 +328,18 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
             acc = sbr_fma(zv.w, wt[j + 3], acc);
         }
         if (lane < D) blk.dX[(size_t)r * D + lane] = acc;
-        else if (lane < 2 * D) DHr[lane - D] = acc;
-        wave_lds_fence();
+        // recurrent dh of unit u = column d + u, held by lane d + u: into every lane group, inside the vector ALU
+        if constexpr (D == 32) {
+            const v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+            rec = __uint_as_float(sw.y);  // .y = the value of the upper half-wave's lane 32 + u
+        } else {
+            const v2u sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+            // .y = the value of the odd 16-lane row of each pair: lane 16 + u for lanes 0..31; then the lower half-wave's value
+            // into the upper one (lanes >= 32 own no column)
+            const v2u lo = __builtin_amdgcn_permlane32_swap(sw.y, sw.y, false, false);
+            rec = __uint_as_float(lo.x);
+        }
+        wave_lds_fence();  // the next step's dz must not overwrite Zs before every lane has read it
     }
 }
 
@@ -265,7 +379,7 @@ bool launch_wave_forward(const ModelView& m, const MbView& mb, float* H, const W
 bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int tm_host, int b_host,
                           hipStream_t s) {
     const int d = m.d, ngd = m.ng * m.d;
-    const size_t lds = ((size_t)tm_host * 6 * d + ngd + d + tm_host) * 4;
+    const size_t lds = ((size_t)tm_host * 7 * d + ngd + tm_host) * 4;
     if (!wave_shape_ok(d, m.ng, b_host, lds)) return false;
 #define SBR_WAVE_BWD(DD, NN)                                                                                   \
     {                                                                                                          \

@@ -13,7 +13,7 @@ def main():
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
     rows = db.execute(f"select name, start, end{', ' + qcol if qcol else ''} from kernels order by start").fetchall()
-    fwd = [i for i, r in enumerate(rows) if "lstm_fwd_seq_kernel" in r[0]]
+    fwd = [i for i, r in enumerate(rows) if "lstm_fwd_seq_kernel" in r[0] or "lstm_fwd_wave_kernel" in r[0]]
     a, b = fwd[which], fwd[which + 1]
     t0 = rows[a][1]
     print(f"step {which}: {(rows[b][1] - t0) / 1e6:.3f} ms from forward launch to forward launch; columns: start ms, duration ms, queue, kernel")

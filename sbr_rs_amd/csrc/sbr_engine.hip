@@ -502,6 +502,8 @@ struct sbr_fit_plan {
     unsigned long long* ex_acc = nullptr;
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
+    bool sort_off_stream = false; /* the step's key ordering ran on another stream than the main one: ev_sorted joins it */
+    bool header_accumulated = false; /* single device: block_header_kernel already added this step to loss_acc / ex_acc */
     /* partitioned item table: this device's gradient list (addressed by sorted-key position), the owner
      * bounds, and the owner-side merge buffers */
     float *glist = nullptr, *gblist = nullptr;
@@ -1280,7 +1282,13 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* The sort of the sparse-update keys needs only the index arrays and the negatives: it runs on its own stream,
      * underneath the backward pass (WARP: the negatives come out of the score kernel) or, for the single-negative losses
      * whose negatives are a hash of the row counter, from the very start of the step (joined by step_apply / step_scatter). */
-    hipStream_t side = m->overlap ? m->side : m->stream;
+    /* A small step (its sparse update is the single-launch form: <= 4 096 keys) is a chain of launches of a few microseconds
+     * each; the event hand-offs between three streams then cost more than the overlap buys (MovieLens-100K at one sequence per
+     * step: 1.67 s with the side streams, 1.57 s on one), so everything is queued on the main stream. */
+    static const char* small_env = std::getenv("SBR_SMALL_STEP_ROWS");
+    const int small_rows = small_env ? std::atoi(small_env) : 1365;
+    const bool overlap = m->overlap && mb.R > small_rows;
+    hipStream_t side = overlap ? m->side : m->stream;
     /* Where the key ordering of a WARP step runs (its negatives come out of the score kernel).  SBR_SORT_PLACE:
      *   stream  its own stream from the end of the score kernel on: it takes whatever slots the backward pass's retiring
      *           workgroups free, and is finished by the time the update needs the keys
@@ -1288,7 +1296,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      *   post    the main stream right after the backward pass, beside the start of the dense-gradient GEMM */
     static const char* place_env = std::getenv("SBR_SORT_PLACE");
     enum { SORT_OWN_STREAM, SORT_PRE, SORT_POST };
-    const int place = !m->overlap ? SORT_PRE : !place_env ? SORT_OWN_STREAM : !std::strcmp(place_env, "pre") ? SORT_PRE : !std::strcmp(place_env, "post") ? SORT_POST : SORT_OWN_STREAM;
+    const int place = !overlap ? SORT_PRE : !place_env ? SORT_OWN_STREAM : !std::strcmp(place_env, "pre") ? SORT_PRE : !std::strcmp(place_env, "post") ? SORT_POST : SORT_OWN_STREAM;
     hipStream_t sorter = place == SORT_OWN_STREAM ? m->sorter : m->stream;
     const bool early_sort = m->hp.loss != SBR_LOSS_WARP && !std::getenv("SBR_NO_EARLY_SORT"); /* the variable is the A/B switch */
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
@@ -1302,10 +1310,11 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
             sbr::launch_own_sort(bv, (uint32_t)mb.R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, on,
                                  early_sort ? &mv : nullptr, epoch_key, m->hp.num_items);
         }
-        HIPCHK(hipEventRecord(m->ev_sorted, on));
+        p->sort_off_stream = on != m->stream; /* on the main stream the update is ordered behind the sort anyway: no event */
+        if (p->sort_off_stream) HIPCHK(hipEventRecord(m->ev_sorted, on));
         return SBR_OK;
     };
-    if (early_sort) SBRCHK(launch_sort(m->overlap ? m->sorter : m->stream));
+    if (early_sort) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
         sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
@@ -1314,7 +1323,10 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
         sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
     }
-    sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, m->stream);
+    /* single device: the loss accumulators take the block's header in the header kernel itself (one launch fewer per step) */
+    p->header_accumulated = p->ndev == 1;
+    sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
+                             p->header_accumulated ? p->ex_acc : nullptr, m->stream);
     if (!early_sort && place != SORT_POST) SBRCHK(launch_sort(sorter));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
@@ -1323,15 +1335,17 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* the dense-gradient GEMM (MFMA-bound, reads dZ / X / H only) goes to the side stream so that the
      * HBM-bound sparse update that follows on the main stream overlaps it; joined in step_apply /
      * step_dense before anything reads blk.dense */
-    HIPCHK(hipEventRecord(m->ev_fork, m->stream));
-    HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+    if (side != m->stream) {
+        HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+        HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
+    }
     {
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
         sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side);
     }
     if (!early_sort && place == SORT_POST) SBRCHK(launch_sort(m->stream));
-    HIPCHK(hipEventRecord(m->ev_join, side));
-    p->dense_pending = true;
+    if (side != m->stream) HIPCHK(hipEventRecord(m->ev_join, side));
+    p->dense_pending = side != m->stream;
     p->last_R = mb.R;
     p->last_block = block;
     HIPCHK(hipGetLastError());
@@ -1345,10 +1359,11 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     SBRCHK(ensure_device(m));
     const uint8_t* all = p->block;
     begin_optimizer_step(m);
-    sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
+    if (!p->header_accumulated) sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
+    p->header_accumulated = false;
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
         sbr::launch_seg_apply(m->mv, block_view(m, p->block, p->rmax), p->ep[p->cur].rows_of_dev[minibatch], p->keys_sorted, p->seg,
                               m->stream);
     }
@@ -1391,7 +1406,7 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
         sbr::launch_seg_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys_sorted, p->seg, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -1546,7 +1561,7 @@ static sbr_status partition_reduce_own(sbr_fit_plan* p, uint64_t minibatch) {
     SBRCHK(partition_buffers(p));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
-    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+    if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         sbr::launch_seg_list(m->mv, bv, R, p->ndev, slice_rows(p), p->keys_sorted, p->glist, p->gblist, p->gfl, p->bounds_dev, p->seg,

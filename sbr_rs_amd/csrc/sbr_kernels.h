@@ -108,7 +108,10 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                   int rows_host, hipStream_t s);
 /* debug only: dloss/dh of every packed row (the training path never materialises it) */
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
-void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s);
+/* header of the exchange block (rows, loss sum, examples); loss_acc / ex_acc non-null (single device): the plan's accumulators
+ * take the header in the same launch */
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, double* loss_acc,
+                         unsigned long long* ex_acc, hipStream_t s);
 /* BPTT (dX, dZ) and, separately, the dense gradient into blk.dense (may run on a second stream:
  * it reads only dZ, X, H) */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

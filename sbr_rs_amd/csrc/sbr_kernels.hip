@@ -141,7 +141,8 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction,
 // compared with a tolerance) and example count
 __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
-                                                          const unsigned int* part_tries, int nparts) {
+                                                          const unsigned int* part_tries, int nparts, double* loss_acc,
+                                                          unsigned long long* ex_acc) {
     __shared__ double part[4];
     __shared__ unsigned int tpart[4];
     double acc = 0.0;
@@ -164,8 +165,16 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
         header[0] = (uint32_t)R;
         header[1] = tpart[0] + tpart[1] + tpart[2] + tpart[3]; /* negatives scored in this minibatch (reporting only) */
         header[2] = header[3] = 0;
-        *reinterpret_cast<double*>(header + 4) = part[0] + part[1] + part[2] + part[3];
+        const double loss = part[0] + part[1] + part[2] + part[3];
+        *reinterpret_cast<double*>(header + 4) = loss;
         *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
+        if (loss_acc) { /* single device: the plan's accumulators take the header here (accumulate_loss_kernel with one block) */
+            loss_acc[0] += loss;
+            loss_acc[1] += loss;
+            ex_acc[0] += (unsigned long long)R;
+            ex_acc[1] += header[1];
+            ex_acc[2] += (unsigned long long)R;
+        }
     }
 }
 
@@ -1938,7 +1947,10 @@ __device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, u
 // rows) instead of three, and no lane group spends a round trip finding out that its position is not a head.
 // Positions are requested two segments ahead and key windows one segment ahead, so that in steady state only
 // the row round trip is exposed.
-template <int D, class Emit>
+// INLINE_LONG (small key counts: launch_seg_reduce): a segment of more than SBR_SEG_CHUNK entries is reduced right here by
+// its lane group, chunk partial by chunk partial in the contract's order, instead of being registered for the three
+// kernels of the chunked path — four launches fewer per step where a step is a handful of microseconds.
+template <int D, class Emit, bool INLINE_LONG = false>
 __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
@@ -1973,6 +1985,26 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
         p_end = p_next_end;
         p_next = p_nn;
         p_next_end = p_nn_end;
+        if (INLINE_LONG && len > SBR_SEG_CHUNK) { /* chunk partials in order: the first initialises (seg_chunk / seg_finish) */
+            const RowPrefetch pre = emit.template pre<D>(row, lg);
+            float4 g;
+            float gb;
+            bool has_b;
+            seg_accumulate<D>(blk, keys, p, p + SBR_SEG_CHUNK, lg, &g, &gb, &has_b);
+            for (uint64_t q = p + SBR_SEG_CHUNK; q < p + len; q += SBR_SEG_CHUNK) {
+                float4 v;
+                float vb;
+                bool vh;
+                seg_accumulate<D>(blk, keys, q, q + SBR_SEG_CHUNK < p + len ? q + SBR_SEG_CHUNK : p + len, lg, &v, &vb, &vh);
+                g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w;
+                if (vh) {
+                    gb = has_b ? gb + vb : vb;
+                    has_b = true;
+                }
+            }
+            emit.template row<D>(row, p, lg, g, has_b, gb, pre);
+            continue;
+        }
         if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
             if (lg == 0) {
                 const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
@@ -2625,9 +2657,10 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
     });
 }
 
-void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, hipStream_t s) {
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, double* loss_acc,
+                         unsigned long long* ex_acc, hipStream_t s) {
     hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, blk.header, rows_host, w.part_loss, w.part_tries,
-                       rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0);
+                       rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0, loss_acc, ex_acc);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
@@ -2710,18 +2743,21 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
     }
 }
 
-void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w_in, int rows_host,
                            int b_host, hipStream_t s) {
     if (rows_host == 0) return; /* the empty case is handled by launch_recurrent_backward */
     if (m.ng == 0) { /* EWMA: dalpha from the per-sequence partials the backward scan left in w.dab */
         const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
-        hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w.dab, b_host, m.d, w.partials);
-        hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w.partials, nch, m.d, m.alpha, blk.dense);
+        hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.dab, b_host, m.d, w_in.partials);
+        hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.partials, nch, m.d, m.alpha, blk.dense);
         return;
     }
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
     const int tiles = ((K2 + 127) / 128) * ((NGD + 127) / 128);
+    /* a single chunk: its partial IS the gradient — the GEMM writes it straight into the block and the reduction launch is skipped */
+    WorkView w = w_in;
+    if (nch == 1) w.partials = blk.dense;
     DISPATCH_D(m.d, {
         const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
@@ -2746,6 +2782,7 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
             }
         }
     });
+    if (nch == 1) return;
     const size_t n = (size_t)(K2 + 1) * NGD;
     hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
 }
@@ -2762,12 +2799,23 @@ void launch_repack_lstm(const ModelView& m, hipStream_t s) {
     hipLaunchKernelGGL(repack_lstm_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, m);
 }
 
+#ifndef SBR_SEG_INLINE_MAX_KEYS
+#define SBR_SEG_INLINE_MAX_KEYS 4096 /* up to this many keys the sparse reduction is the single launch of seg_short_kernel<.., true> */
+#endif
 // sorted keys -> per-row reduction (chunked order) -> Emit: short segments, then the long ones
 template <class Emit>
 static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, const uint64_t* keys_sorted, const SegScratch& sc,
                               const Emit& emit, hipStream_t s) {
     if (rows_host == 0) return;
     const uint64_t total = 3ull * rows_host;
+    if (total <= SBR_SEG_INLINE_MAX_KEYS) { /* small step: one launch, long segments reduced in place */
+        DISPATCH_D(d, {
+            const int gpb = 4 * (64 / (DD / 4));
+            hipLaunchKernelGGL((seg_short_kernel<DD, Emit, true>), dim3(grid_for_groups((long long)total / 2 + 1, gpb)), dim3(256), 0, s, blk,
+                               keys_sorted, total, sc, emit);
+        });
+        return;
+    }
     (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
     DISPATCH_D(d, {
         const int gpb = 4 * (64 / (DD / 4));

@@ -807,6 +807,19 @@ def test_wave_per_sequence_form(monkeypatch, kind, loss, d, B, T, wave):
     assert_params_equal(g, o, kind, f"wave={wave}")
 
 
+def test_small_step_with_a_hot_row():
+    """Up to 4 096 keys the sparse reduction is ONE launch: a row with more than SBR_SEG_CHUNK = 256 entries is reduced in
+    place, chunk partial by chunk partial, instead of going through the three kernels of the chunked path.  A catalogue of
+    three items and 140-step sequences gives every step rows with hundreds of entries."""
+    users, items, T = 6, 3, 140
+    ptr, it = synthetic_interactions(users, items, T, seed=17, min_len=120)
+    for kind, loss, d, B in ((ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 1), (ModelKind.EWMA, LOSS_HINGE, 64, 2), (ModelKind.LSTM_COUPLED, LOSS_BPR, 128, 3)):
+        hp = hparams(items, T, d, int(kind), loss, epochs=2, B=B)
+        g, o = make_pair(hp)
+        assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+        assert_params_equal(g, o, kind, "hot row in a small step")
+
+
 def test_wave_form_falls_back_for_long_sequences(monkeypatch):
     """The wave form stages every step of a sequence in LDS; a max_sequence_length that does not fit (here 300 steps at
     d = 32) takes the tile kernels even when SBR_WAVE = 1 asks for the wave form."""

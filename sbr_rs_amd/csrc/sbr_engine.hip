@@ -1302,7 +1302,9 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
-            HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* everything before: the previous step's readers of the keys, this step's score */
+            /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
+             * itself, before it queues the backward pass) */
+            if (early_sort) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
             HIPCHK(hipStreamWaitEvent(on, m->ev_scored, 0));
         }
         {
@@ -1327,11 +1329,17 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     p->header_accumulated = p->ndev == 1;
     sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
                              p->header_accumulated ? p->ex_acc : nullptr, m->stream);
-    if (!early_sort && place != SORT_POST) SBRCHK(launch_sort(sorter));
+    /* host order: with the ordering on its own stream the backward pass is queued FIRST — the ordering's up to nine short
+     * launches would otherwise sit in the host's queue ahead of it (50 us at a few hundred sequences per step, as long as
+     * the pass itself); ev_scored, recorded here, is what the ordering waits for either way */
+    const bool sort_first = place == SORT_PRE;
+    if (!early_sort && sort_first) SBRCHK(launch_sort(sorter));
+    if (!early_sort && place == SORT_OWN_STREAM) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
     {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }
+    if (!early_sort && place == SORT_OWN_STREAM) SBRCHK(launch_sort(sorter));
     /* the dense-gradient GEMM (MFMA-bound, reads dZ / X / H only) goes to the side stream so that the
      * HBM-bound sparse update that follows on the main stream overlaps it; joined in step_apply /
      * step_dense before anything reads blk.dense */

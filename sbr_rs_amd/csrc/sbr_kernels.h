@@ -103,6 +103,9 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
 bool launch_wave_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host, hipStream_t s);
 bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int tm_host, int b_host,
                           hipStream_t s);
+/* dense-gradient chunk partials of a small step at d <= 32: one wave per 32 x 32 output block (w.partials as the tile kernels') */
+bool launch_wave_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+                                hipStream_t s);
 /* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s);

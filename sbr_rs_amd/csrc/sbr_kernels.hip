@@ -2758,7 +2758,8 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     /* a single chunk: its partial IS the gradient — the GEMM writes it straight into the block and the reduction launch is skipped */
     WorkView w = w_in;
     if (nch == 1) w.partials = blk.dense;
-    DISPATCH_D(m.d, {
+    const bool block_form = launch_wave_dense_gradient(m, mb, blk, w, rows_host, s); /* small step at d <= 32 (sbr_wave.hip) */
+    if (!block_form) DISPATCH_D(m.d, {
         const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
         /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */

@@ -32,8 +32,11 @@ namespace sbr {
 
 namespace {
 
-constexpr int SORT_ITEMS = 64;                 // keys per lane of a wave-tile
-constexpr int SORT_TILE = 64 * SORT_ITEMS;     // keys per wave-tile
+constexpr int SORT_ITEMS = 64;                 // keys per lane of a wave-tile: 4 096-key tiles ...
+constexpr int SORT_ITEMS_FINE = 8;             // ... or 512-key tiles while the input is small (SORT_FINE_MAX_N): a step of a few
+                                               // hundred sequences is 10^4-10^5 keys — six 4 096-key tiles would leave the
+                                               // ordering to six waves (150 us per step at 25 000 keys, under a 100 us BPTT)
+constexpr uint32_t SORT_FINE_MAX_N = 1u << 18;
 constexpr int SORT_BATCH = 8;                  // keys per lane requested together
 constexpr int SORT_MAX_DIGIT_BITS = 11;
 constexpr int SORT_WAVES = 4;                  // wave-tiles per workgroup
@@ -51,7 +54,13 @@ inline PassPlan plan_passes(int row_bits) {
     if (p.digit_bits < 6) p.digit_bits = 6;
     return p;
 }
-inline uint32_t tiles_of(uint64_t n) { return (uint32_t)((n + SORT_TILE - 1) / SORT_TILE); }
+inline int items_of(uint64_t n) {  // keys per lane of a tile for an input of n keys (SBR_SORT_ITEMS = 64 / 8 forces one: tests)
+    const char* e = std::getenv("SBR_SORT_ITEMS");
+    if (e && std::atoi(e) == SORT_ITEMS) return SORT_ITEMS;
+    if (e && std::atoi(e) == SORT_ITEMS_FINE) return n <= SORT_FINE_MAX_N ? SORT_ITEMS_FINE : SORT_ITEMS;  // (the scratch is sized for that)
+    return n <= SORT_FINE_MAX_N ? SORT_ITEMS_FINE : SORT_ITEMS;
+}
+inline uint32_t tiles_of(uint64_t n, int items) { return (uint32_t)((n + 64 * (uint64_t)items - 1) / (64 * (uint64_t)items)); }
 
 // ---- key sources -------------------------------------------------------------------------------
 struct SrcBlock {  // a device's own entries after the score kernel has chosen the negatives
@@ -101,7 +110,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 }
 
 // ---- one radix pass ----------------------------------------------------------------------------
-template <class Src>
+template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
                                                                      uint32_t* __restrict__ counts) {
     extern __shared__ uint32_t lds[];
@@ -111,8 +120,8 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, ui
     for (uint32_t b = lane; b < nb; b += 64) h[b] = 0u;
     __syncthreads();
     const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
-    const uint64_t base = (uint64_t)tile * SORT_TILE;
-    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+    const uint64_t base = (uint64_t)tile * (64 * ITEMS);
+    for (int i0 = 0; i0 < ITEMS; i0 += SORT_BATCH) {
         uint64_t k[SORT_BATCH];
 #pragma unroll
         for (int j = 0; j < SORT_BATCH; ++j) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void radix_binscan_kernel(uint32_t* __restrict
     if (lane == 0) bintotal[bin] = running;
 }
 
-template <class Src>
+template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
                                                                         const uint32_t* __restrict__ counts,
                                                                         const uint32_t* __restrict__ bintotal, uint64_t* __restrict__ out) {
@@ -179,9 +188,9 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src,
         }
     }
     __syncthreads();
-    const uint64_t base = (uint64_t)tile * SORT_TILE;
+    const uint64_t base = (uint64_t)tile * (64 * ITEMS);
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+    for (int i0 = 0; i0 < ITEMS; i0 += SORT_BATCH) {
         uint64_t k[SORT_BATCH];
 #pragma unroll
         for (int j = 0; j < SORT_BATCH; ++j) {
@@ -209,16 +218,16 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src,
 }
 
 // ---- segment heads -----------------------------------------------------------------------------
-template <bool WRITE>
+template <bool WRITE, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void head_tiles_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t ntiles,
                                                                      uint32_t* __restrict__ tile_heads, uint32_t* __restrict__ head_pos) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
     if (tile >= ntiles) return;
-    const uint64_t base = (uint64_t)tile * SORT_TILE;
+    const uint64_t base = (uint64_t)tile * (64 * ITEMS);
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t off = WRITE ? tile_heads[tile] : 0u;
-    for (int i0 = 0; i0 < SORT_ITEMS; i0 += SORT_BATCH) {
+    for (int i0 = 0; i0 < ITEMS; i0 += SORT_BATCH) {
         uint32_t row[SORT_BATCH], prev[SORT_BATCH];
 #pragma unroll
         for (int j = 0; j < SORT_BATCH; ++j) {
@@ -343,7 +352,7 @@ struct Scratch {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline Scratch carve(void* temp, size_t max_entries, int row_bits) {
     const PassPlan pp = plan_passes(row_bits);
-    const size_t nb = (size_t)1 << pp.digit_bits, nt = tiles_of(max_entries) + 1;
+    const size_t nb = (size_t)1 << pp.digit_bits, nt = tiles_of(max_entries, items_of(max_entries)) + 1;
     uint8_t* p = reinterpret_cast<uint8_t*>(temp);
     Scratch s;
     s.counts = reinterpret_cast<uint32_t*>(p);
@@ -356,10 +365,10 @@ inline Scratch carve(void* temp, size_t max_entries, int row_bits) {
 
 // stable sort of n generated keys by their row bits: first pass from `first`, later passes between the two buffers,
 // the last pass always writes `out`
-template <class Src>
-void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
+template <class Src, int ITEMS>
+void radix_sort_tiles(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
     const PassPlan pp = plan_passes(row_bits);
-    const uint32_t ntiles = tiles_of(n), nb = 1u << pp.digit_bits;
+    const uint32_t ntiles = tiles_of(n, ITEMS), nb = 1u << pp.digit_bits;
     const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
     const size_t lds = (size_t)SORT_WAVES * nb * 4;
     for (int p = 0; p < pp.passes; ++p) {
@@ -367,20 +376,27 @@ void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint6
         uint64_t* dst = ((pp.passes - 1 - p) & 1) ? tmp : out;
         const uint64_t* from = dst == out ? tmp : out;
         if (p == 0) {
-            hipLaunchKernelGGL((radix_hist_kernel<Src>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts);
+            hipLaunchKernelGGL((radix_hist_kernel<Src, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts);
         } else {
-            hipLaunchKernelGGL((radix_hist_kernel<SrcKeys>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
+            hipLaunchKernelGGL((radix_hist_kernel<SrcKeys, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
                                sc.counts);
         }
         hipLaunchKernelGGL(radix_binscan_kernel, dim3((nb * 64 + 255) / 256), dim3(256), 0, s, sc.counts, ntiles, nb, sc.bintotal);
         if (p == 0) {
-            hipLaunchKernelGGL((radix_scatter_kernel<Src>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts,
+            hipLaunchKernelGGL((radix_scatter_kernel<Src, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts,
                                sc.bintotal, dst);
         } else {
-            hipLaunchKernelGGL((radix_scatter_kernel<SrcKeys>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
+            hipLaunchKernelGGL((radix_scatter_kernel<SrcKeys, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
                                sc.counts, sc.bintotal, dst);
         }
     }
+}
+// stable sort of n generated keys by their row bits: first pass from `first`, later passes between the two buffers,
+// the last pass always writes `out`
+template <class Src>
+void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
+    if (items_of(n) == SORT_ITEMS_FINE) radix_sort_tiles<Src, SORT_ITEMS_FINE>(first, n, row_bits, tmp, out, sc, s);
+    else radix_sort_tiles<Src, SORT_ITEMS>(first, n, row_bits, tmp, out, sc, s);
 }
 
 // keys in (row, entry) order + segment heads: one launch for small inputs, the tiled passes otherwise
@@ -388,12 +404,17 @@ template <class Src>
 void sort_and_list(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, uint32_t* head_pos,
                    uint32_t* nheads, hipStream_t s);
 
-void list_heads(const uint64_t* keys_sorted, uint32_t n, const Scratch& sc, uint32_t* head_pos, uint32_t* nheads, hipStream_t s) {
-    const uint32_t ntiles = tiles_of(n);
+template <int ITEMS>
+void list_heads_tiles(const uint64_t* keys_sorted, uint32_t n, const Scratch& sc, uint32_t* head_pos, uint32_t* nheads, hipStream_t s) {
+    const uint32_t ntiles = tiles_of(n, ITEMS);
     const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
-    hipLaunchKernelGGL((head_tiles_kernel<false>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+    hipLaunchKernelGGL((head_tiles_kernel<false, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
     hipLaunchKernelGGL(head_scan_kernel, dim3(1), dim3(1024), 0, s, sc.tile_heads, ntiles, n, nheads, head_pos);
-    hipLaunchKernelGGL((head_tiles_kernel<true>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+    hipLaunchKernelGGL((head_tiles_kernel<true, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), 0, s, keys_sorted, n, ntiles, sc.tile_heads, head_pos);
+}
+void list_heads(const uint64_t* keys_sorted, uint32_t n, const Scratch& sc, uint32_t* head_pos, uint32_t* nheads, hipStream_t s) {
+    if (items_of(n) == SORT_ITEMS_FINE) list_heads_tiles<SORT_ITEMS_FINE>(keys_sorted, n, sc, head_pos, nheads, s);
+    else list_heads_tiles<SORT_ITEMS>(keys_sorted, n, sc, head_pos, nheads, s);
 }
 
 template <class Src>
@@ -415,7 +436,11 @@ void sort_and_list(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, ui
 size_t sparse_sort_temp_bytes(size_t max_entries, int key_bits) {
     const int row_bits = key_bits - 32;
     const PassPlan pp = plan_passes(row_bits);
-    const size_t nb = (size_t)1 << pp.digit_bits, nt = tiles_of(max_entries) + 1;
+    const size_t nb = (size_t)1 << pp.digit_bits;
+    /* the larger of the two tile granularities: 4 096-key tiles for max_entries, 512-key tiles for what of it is ordered that way */
+    const size_t fine_n = max_entries < SORT_FINE_MAX_N ? max_entries : SORT_FINE_MAX_N;
+    const size_t nt_c = tiles_of(max_entries, SORT_ITEMS) + 1, nt_f = tiles_of(fine_n, SORT_ITEMS_FINE) + 1;
+    const size_t nt = nt_c > nt_f ? nt_c : nt_f;
     return align256(nb * nt * 4) + align256(nb * 4) + align256((nt + 1) * 4);
 }
 

@@ -29,9 +29,13 @@ namespace sbr {
 namespace {
 
 #ifndef SBR_WAVE_MAX_SEQ
-#define SBR_WAVE_MAX_SEQ 64
+#define SBR_WAVE_MAX_SEQ 2048 /* ms per step at d = 32, len <= 64, wave / tile form: 256 sequences 0.32 / 0.53, 2 048 0.43 / 0.55, 4 096 0.66 / 0.72, 8 192 0.93 / 0.68 */
 #endif
 constexpr size_t WAVE_LDS_LIMIT = 150 * 1024;
+#define SBR_WAVE_RSRC_FLAGS 0x00020000 /* word 3 of a raw buffer resource on gfx9-class targets (32-bit data format, no swizzle) */
+#ifndef SBR_DW_BLOCK_MAX_CHUNKS
+#define SBR_DW_BLOCK_MAX_CHUNKS 128 /* x 1-2 block rows = workgroups: the chip's CUs once */
+#endif
 
 __device__ __forceinline__ float4 ld4w(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4w(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -343,6 +347,178 @@ __global__ __launch_bounds__(256) void lstm_bwd_wave_kernel(ModelView m, MbView 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense gradient of a SMALL step: dW[k][j] = sum_r xh[r][k] dz[r][j] per 1 024-row chunk, one WAVE per 32 x 32 block of
+// the output.  The chunk's chain (rows ascending, from 0: SBR_DW_CHUNK_ROWS) is 512 dependent v_mfma_f32_32x32x2_f32 for
+// every accumulator, whoever computes it; the tile kernel of sbr_kernels.hip gives a wave four accumulators (and at
+// d = 32 half of its 128 x 128 tile lies outside the matrix), so a chunk costs it 4 x 512 MFMAs back to back — 55-130 us
+// — which is what a step of a few hundred sequences then waits for.  Here a chunk is 512 MFMAs deep (14 us): one
+// workgroup per chunk and block ROW, one wave per block — the waves of a workgroup sit on different SIMDs, each with an
+// MFMA pipe to itself (two dependent chains on one SIMD take turns: measured 141 cycles per MFMA and wave) — 64-row slabs of
+// [32 columns of xh | dz] staged through LDS (double-buffered in LDS, two slabs ahead in registers), operands read back
+// one float per lane and MFMA, eight MFMAs' reads ahead.  Rows past the chunk's end, first-step rows'
+// h_{t-1} and padding columns are zeros (requests beyond the buffer resources), i.e. +0 on every chain.  The bias row
+// (column sums of dz, a plain add chain over the rows) is formed by the waves of the first block row from the staged dz.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+typedef unsigned v4uw __attribute__((ext_vector_type(4)));
+template <int D, int NG>
+struct DwBlockCfg {
+    static constexpr int K2 = 2 * D, NGD = NG * D;
+    static constexpr int KB = (K2 + 31) / 32, JB = (NGD + 31) / 32;  // blocks; a workgroup = one block ROW of one chunk
+    static constexpr int NL = 4;                                     // loader waves (one per SIMD, beside the MFMA waves)
+    static constexpr int NT = (JB + NL + 1) * 64;                    // + the wave that forms the bias row
+    static constexpr int KP = 32, JP = JB * 32, LD = KP + JP;        // floats per staged row: the block row's 32 columns of xh, all of dz
+    static constexpr int S = 64;                                     // rows per slab
+    static constexpr size_t lds_bytes = (size_t)2 * S * LD * 4 + SBR_DW_CHUNK_ROWS * 4;
+};
+template <int D, int NG>
+__global__ __launch_bounds__((DwBlockCfg<D, NG>::NT)) void lstm_dw_block_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
+    using Cfg = DwBlockCfg<D, NG>;
+    constexpr int K2 = Cfg::K2, NGD = Cfg::NGD, JB = Cfg::JB, NT = Cfg::NT, KP = Cfg::KP, LD = Cfg::LD, S = Cfg::S;
+    constexpr int NLT = Cfg::NL * 64;                         // loader threads
+    constexpr int QX = 32 / 4, QZ = NGD / 4;                  // 16-byte pieces per row of the xh block row and of dZ
+    constexpr int IX = (S * QX + NLT - 1) / NLT, IZ = (S * QZ + NLT - 1) / NLT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* buf0 = lds;
+    float* buf1 = lds + S * LD;
+    int* s_prev = reinterpret_cast<int*>(lds + 2 * S * LD);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = blockIdx.x % Cfg::KB;
+    const int c = blockIdx.x / Cfg::KB;
+    const int r0 = c * SBR_DW_CHUNK_ROWS;
+    const int nr = mb.R - r0 < SBR_DW_CHUNK_ROWS ? mb.R - r0 : SBR_DW_CHUNK_ROWS;
+    const int nslabs = (nr + S - 1) / S;
+    for (int i = tid; i < SBR_DW_CHUNK_ROWS; i += NT) s_prev[i] = i < nr ? mb.prev_row[r0 + i] : -1;
+    // padding columns of both buffers (d = 16 with three gates: dz columns 48..63) stay zero: cleared once
+    for (int i = tid; i < 2 * S * LD; i += NT) lds[i] = 0.0f;
+    __syncthreads();
+    float* part = w.partials + (size_t)c * (K2 + 1) * NGD;
+    if (wave < JB) {
+        // ---- MFMA wave: block (kb, jb = wave); per slab 32 dependent MFMAs, operands from LDS, eight MFMAs' reads ahead
+        const int jb = wave, l31 = lane & 31, par = lane >> 5;
+        f32x16w acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        __syncthreads();  // slab 0 staged
+        for (int slab = 0; slab < nslabs; ++slab) {
+            const float* cur = (slab & 1) ? buf1 : buf0;
+            const float* ap = cur + par * LD + l31;
+            const float* bp = cur + par * LD + KP + jb * 32 + l31;
+            constexpr int G = 8;
+            float av[2][G], bv[2][G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) { av[0][q] = ap[2 * q * LD]; bv[0][q] = bp[2 * q * LD]; }
+#pragma unroll
+            for (int g = 0; g < S / 2 / G; ++g) {
+                if (g + 1 < S / 2 / G) {
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        av[(g + 1) & 1][q] = ap[2 * ((g + 1) * G + q) * LD];
+                        bv[(g + 1) & 1][q] = bp[2 * ((g + 1) * G + q) * LD];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < G; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][q], bv[g & 1][q], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        const int j = jb * 32 + l31;
+        if (j < NGD) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int kk = kb * 32 + (q & 3) + 8 * (q >> 2) + 4 * par;
+                if (kk < K2) part[(size_t)kk * NGD + j] = acc[q];
+            }
+        }
+        return;
+    }
+    if (wave == JB + Cfg::NL) {
+        // ---- bias wave: row k = 2d of the gradient = column sums of dz, a plain add chain over the rows of the chunk (rows past
+        // its end add +0), read from the staged slabs; lane l owns columns l and 64 + l.  (A lone wave pays ~7 cycles per
+        // instruction: folded into the MFMA waves these adds cost a third of the MFMA rate, folded into a loader wave they made
+        // it the slowest wave of the workgroup.)  Only the first block row's workgroup has work here.
+        float bias0 = 0.0f, bias1 = 0.0f;
+        __syncthreads();  // slab 0 staged
+        for (int slab = 0; slab < nslabs; ++slab) {
+            if (kb == 0) {
+                const float* cur = (slab & 1) ? buf1 : buf0;
+                const float* z0 = cur + KP + (lane < NGD ? lane : 0);
+                const float* z1 = cur + KP + (64 + lane < NGD ? 64 + lane : 0);
+#pragma unroll 16
+                for (int i = 0; i < S; ++i) {
+                    bias0 = bias0 + z0[i * LD];
+                    bias1 = bias1 + z1[i * LD];
+                }
+            }
+            __syncthreads();
+        }
+        if (kb == 0) {
+            if (lane < NGD) part[(size_t)K2 * NGD + lane] = bias0;
+            if (64 + lane < NGD) part[(size_t)K2 * NGD + 64 + lane] = bias1;
+        }
+        return;
+    }
+    // ---- loader waves: stage the slabs (rows past the chunk, h_{t-1} of first steps, columns outside the matrix: requests beyond
+    // the buffer resources, i.e. zeros)
+    const int lt = tid - JB * 64;  // loader thread id
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)w.X, (short)0, mb.R * D * 4, SBR_WAVE_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)blk.H, (short)0, mb.R * D * 4, SBR_WAVE_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)w.dZ, (short)0, mb.R * NGD * 4, SBR_WAVE_RSRC_FLAGS);
+    struct Regs { v4uw xr[IX], hr[IX], zr[IZ]; };
+    Regs ra, rb;  // two slabs in flight towards LDS (a request has two slabs' MFMAs to land under)
+    auto fetch = [&](Regs& rg, int slab) {
+#pragma unroll
+        for (int it = 0; it < IX; ++it) {
+            const int p = lt + it * NLT, lr = slab * S + p / QX, k4 = kb * 32 + (p % QX) * 4;  // column of xh = [x | h]
+            const bool ok = p < S * QX && lr < nr;
+            const int pr = s_prev[lr < SBR_DW_CHUNK_ROWS ? lr : 0];
+            // one of the two requests of a piece falls outside its resource and returns zeros: the piece is their OR
+            rg.xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok && k4 < D ? (unsigned)((r0 + lr) * D + k4) * 4u : OOB, 0, 0);
+            rg.hr[it] = __builtin_amdgcn_raw_buffer_load_b128(rsH, ok && k4 >= D && k4 < K2 && pr >= 0 ? (unsigned)(pr * D + k4 - D) * 4u : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < IZ; ++it) {
+            const int p = lt + it * NLT, lr = slab * S + p / QZ, c4 = (p % QZ) * 4;
+            const bool ok = p < S * QZ && lr < nr;
+            rg.zr[it] = __builtin_amdgcn_raw_buffer_load_b128(rsZ, ok ? (unsigned)((r0 + lr) * NGD + c4) * 4u : OOB, 0, 0);
+        }
+    };
+    auto stage = [&](const Regs& rg, float* buf) {
+#pragma unroll
+        for (int it = 0; it < IX; ++it) {
+            const int p = lt + it * NLT, row = p / QX, c4 = (p % QX) * 4;
+            if (p < S * QX) *reinterpret_cast<v4uw*>(&buf[row * LD + c4]) = rg.xr[it] | rg.hr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IZ; ++it) {
+            const int p = lt + it * NLT, row = p / QZ, c4 = (p % QZ) * 4;
+            if (p < S * QZ) *reinterpret_cast<v4uw*>(&buf[row * LD + KP + c4]) = rg.zr[it];
+        }
+    };
+    // slab s is computed from LDS buffer s & 1 while slab s + 1 goes from registers into the other buffer (its readers passed
+    // the barrier at the end of slab s - 1) and slab s + 3 is requested into the registers that have just been emptied;
+    // requests past the last slab fall outside the chunk and return zeros, which nobody reads
+    fetch(ra, 0);
+    stage(ra, buf0);
+    fetch(ra, 1);
+    fetch(rb, 2);
+    __syncthreads();  // slab 0 staged
+    for (int slab = 0; slab < nslabs; slab += 2) {
+        stage(ra, buf1);
+        fetch(ra, slab + 3);
+        __syncthreads();
+        if (slab + 1 < nslabs) {
+            stage(rb, buf0);
+            fetch(rb, slab + 4);
+            __syncthreads();
+        }
+    }
+}
+
 int wave_mode() {  // SBR_WAVE: 0 never, 1 whenever the shape allows, unset: up to SBR_WAVE_MAX_SEQ sequences per step
     const char* e = std::getenv("SBR_WAVE");  // read per call: the tests force either form
     return e ? (std::atoi(e) ? 1 : 0) : -1;
@@ -391,6 +567,28 @@ bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView&
     else if (m.ng == 4) SBR_WAVE_BWD(16, 4)
     else SBR_WAVE_BWD(16, 3)
 #undef SBR_WAVE_BWD
+    return true;
+}
+
+bool launch_wave_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+                                hipStream_t s) {
+    const int d = m.d;
+    if ((d != 16 && d != 32) || (m.ng != 3 && m.ng != 4) || rows_host <= 0) return false;
+    const char* e = std::getenv("SBR_DW_BLOCK");  // 0 never, 1 always (tests), unset: while the waves fit the SIMDs about once
+    const int mode = e ? (std::atoi(e) ? 1 : 0) : -1;
+    const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
+    if (mode == 0 || (mode < 0 && nch > SBR_DW_BLOCK_MAX_CHUNKS)) return false;
+#define SBR_DW_BLOCK_LAUNCH(DD, NN)                                                                                          \
+    {                                                                                                                        \
+        using Cfg = DwBlockCfg<DD, NN>;                                                                                      \
+        allow_lds(lstm_dw_block_kernel<DD, NN>, Cfg::lds_bytes);                                                             \
+        hipLaunchKernelGGL((lstm_dw_block_kernel<DD, NN>), dim3(nch * Cfg::KB), dim3(Cfg::NT), Cfg::lds_bytes, s, m, mb, blk, w); \
+    }
+    if (d == 32 && m.ng == 4) SBR_DW_BLOCK_LAUNCH(32, 4)
+    else if (d == 32) SBR_DW_BLOCK_LAUNCH(32, 3)
+    else if (m.ng == 4) SBR_DW_BLOCK_LAUNCH(16, 4)
+    else SBR_DW_BLOCK_LAUNCH(16, 3)
+#undef SBR_DW_BLOCK_LAUNCH
     return true;
 }
 

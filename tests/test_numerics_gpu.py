@@ -85,12 +85,15 @@ def test_mfma_is_fma_chain(L, k):
     (100_000, 11, "zipf"), (300_001, 20, "uniform"), (1_500_000, 20, "zipf"), (700_000, 24, "uniform"),
     (50_000, 32, "uniform"), (20_000, 3, "uniform"), (123_457, 17, "one_row"),
 ])
-@pytest.mark.parametrize("small", ["1", "0"])
-def test_key_ordering_is_a_stable_sort_by_row(L, monkeypatch, n, row_bits, dist, small):
+@pytest.mark.parametrize("small,items", [("1", None), ("0", None), ("0", "64")])
+def test_key_ordering_is_a_stable_sort_by_row(L, monkeypatch, n, row_bits, dist, small, items):
     """sbr_sort.hip against numpy's stable argsort: keys (row << 32 | e) in (row, e) order — one, two and three radix passes,
     ragged last tiles, hot rows, a single row — and the ascending list of segment heads with its sentinel.  Inputs of up to
-    4 096 keys take the single-launch LDS-resident form unless SBR_SORT_SMALL=0 sends them through the tiled passes."""
+    4 096 keys take the single-launch LDS-resident form unless SBR_SORT_SMALL=0 sends them through the tiled passes; the
+    tiled passes cut up to 2^18 keys into 512-key tiles and more into 4 096-key tiles (SBR_SORT_ITEMS=64: always)."""
     monkeypatch.setenv("SBR_SORT_SMALL", small)
+    if items:
+        monkeypatch.setenv("SBR_SORT_ITEMS", items)
     rs = np.random.RandomState(n % 9973 + row_bits)
     hi = (1 << row_bits) if row_bits < 32 else (1 << 32) - 1
     if dist == "uniform":

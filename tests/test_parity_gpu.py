@@ -807,6 +807,26 @@ def test_wave_per_sequence_form(monkeypatch, kind, loss, d, B, T, wave):
     assert_params_equal(g, o, kind, f"wave={wave}")
 
 
+@pytest.mark.parametrize("kind,loss,d,B", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 300),
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 32, 64),
+    (ModelKind.LSTM_NORMAL, LOSS_BPR, 16, 150),
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 301),
+])
+@pytest.mark.parametrize("form", ["1", "0"])
+def test_dense_gradient_block_form(monkeypatch, kind, loss, d, B, form):
+    """Small steps at d <= 32 form the dense gradient with one wave per 32 x 32 output block (sbr_wave.hip:
+    lstm_dw_block_kernel); SBR_DW_BLOCK = 0 forces the 128 x 128 tile kernel.  Several 1 024-row chunks per step, a ragged
+    last chunk with an odd row count, first-step rows (h_{-1} = 0) everywhere: whole-fit parity, bit for bit, in both forms."""
+    monkeypatch.setenv("SBR_DW_BLOCK", form)
+    users, items, T = 700, 401, 14
+    ptr, it = synthetic_interactions(users, items, T, seed=33 + d, min_len=2)
+    hp = hparams(items, T, d, int(kind), loss, epochs=1, B=B)
+    g, o = make_pair(hp)
+    assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
+    assert_params_equal(g, o, kind, f"dense gradient block form={form}")
+
+
 def test_small_step_with_a_hot_row():
     """Up to 4 096 keys the sparse reduction is ONE launch: a row with more than SBR_SEG_CHUNK = 256 entries is reduced in
     place, chunk partial by chunk partial, instead of going through the three kernels of the chunked path.  A catalogue of

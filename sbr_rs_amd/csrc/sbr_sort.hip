@@ -276,43 +276,62 @@ __global__ __launch_bounds__(1024) void head_scan_kernel(uint32_t* __restrict__ 
 
 // ---- small inputs: everything in ONE launch -------------------------------------------------------
 // Up to SMALL_N keys (a minibatch of one or a few sequences — the reference's own schedule is one subsequence per
-// optimiser step, sequence_model.rs:111-169, i.e. ~10^2 keys) fit the LDS of one workgroup twice over: one wave generates
-// the keys into LDS, runs every radix pass there (histogram, 64-lane scan of the bins, the same ballot-ranked stable
-// scatter as radix_scatter_kernel, ping-pong between two LDS arrays), writes the ordered keys out and lists the segment
-// heads — nine launches of the general path become one, which is what a step of ~10^2 rows is made of.
+// optimiser step, sequence_model.rs:111-169, i.e. ~10^2 keys) fit the LDS of one workgroup twice over: the workgroup
+// generates the keys into LDS and runs every radix pass there — each of its eight waves owns a contiguous eighth of the
+// keys (its own histogram, then, after a scan over (bin, wave), the same ballot-ranked stable scatter as
+// radix_scatter_kernel over its slice; ping-pong between two LDS arrays) — writes the ordered keys out and lists the
+// segment heads: nine launches of the general path become one, which is what a step of ~10^2 rows is made of.  (As ONE
+// wave the 1 620 keys of a 16-sequence step took 48 us, as long as the step's backward pass.)
 constexpr int SMALL_N = 4096;
+constexpr int SMALL_WAVES = 8;  // wave w orders the w-th eighth of the keys; the bins' offsets are exchanged through LDS
 template <class Src>
-__global__ __launch_bounds__(64) void small_sort_kernel(Src src, uint32_t n, int passes, int digit_bits, uint64_t* __restrict__ out,
-                                                        uint32_t* __restrict__ head_pos, uint32_t* __restrict__ nheads) {
+__global__ __launch_bounds__(SMALL_WAVES * 64) void small_sort_kernel(Src src, uint32_t n, int passes, int digit_bits, uint64_t* __restrict__ out,
+                                                                      uint32_t* __restrict__ head_pos, uint32_t* __restrict__ nheads) {
+    constexpr int NT = SMALL_WAVES * 64;
     __shared__ uint64_t ka[SMALL_N], kb[SMALL_N];
-    __shared__ uint32_t h[1 << SORT_MAX_DIGIT_BITS];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t h[SMALL_WAVES][1 << SORT_MAX_DIGIT_BITS];  // h[w][bin]: count, then first output position, of wave w's keys of the bin
+    __shared__ uint32_t s_part[SMALL_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint32_t e = lane; e < n; e += 64) ka[e] = src(e);
+    // contiguous slices in entry order (multiples of 64 keys): stability = lower waves' keys of a bin come first
+    const uint32_t slice = ((n + SMALL_WAVES * 64 - 1) / (SMALL_WAVES * 64)) * 64;
+    const uint32_t lo = wave * slice < n ? wave * slice : n, hi = lo + slice < n ? lo + slice : n;
+    for (uint32_t e = tid; e < n; e += NT) ka[e] = src(e);
     uint64_t* from = ka;
     uint64_t* to = kb;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * digit_bits;
-        for (uint32_t b = lane; b < nb; b += 64) h[b] = 0u;
+        for (uint32_t i = tid; i < SMALL_WAVES * nb; i += NT) h[i / nb][i % nb] = 0u;
+        __syncthreads();  // (also: the keys of `from` are in place)
+        for (uint32_t e = lo + lane; e < hi; e += 64) atomicAdd(&h[wave][((uint32_t)(from[e] >> 32) >> shift) & mask], 1u);
         __syncthreads();
-        for (uint32_t e = lane; e < n; e += 64) atomicAdd(&h[((uint32_t)(from[e] >> 32) >> shift) & mask], 1u);
-        __syncthreads();
-        {   // exclusive scan of the bins: lane l owns bins l*per .. l*per + per - 1
-            const uint32_t per = nb >> 6;
+        {   // h[w][b] <- (keys of lower bins) + (keys of bin b in lower waves): thread t owns bins t*per .. t*per + per - 1
+            const uint32_t per = (nb + NT - 1) / NT;
+            const uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
             uint32_t sum = 0;
-            for (uint32_t j = 0; j < per; ++j) sum += h[lane * per + j];
-            uint32_t run = wave_inclusive_scan(sum, lane) - sum;
-            for (uint32_t j = 0; j < per; ++j) {
-                const uint32_t c = h[lane * per + j];
-                h[lane * per + j] = run;
-                run += c;
+            for (uint32_t b = b0; b < b1; ++b)
+#pragma unroll
+                for (int w2 = 0; w2 < SMALL_WAVES; ++w2) sum += h[w2][b];
+            const uint32_t incl = wave_inclusive_scan(sum, lane);
+            if (lane == 63) s_part[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (int w2 = 0; w2 < wave; ++w2) run += s_part[w2];
+            for (uint32_t b = b0; b < b1; ++b) {
+#pragma unroll
+                for (int w2 = 0; w2 < SMALL_WAVES; ++w2) {
+                    const uint32_t c = h[w2][b];
+                    h[w2][b] = run;
+                    run += c;
+                }
             }
         }
         __syncthreads();
-        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        for (uint32_t e0 = lo; e0 < hi; e0 += 64) {  // the wave's slice in order, 64 keys at a time (radix_scatter_kernel's ranking)
             const uint32_t e = e0 + lane;
-            const bool valid = e < n;
+            const bool valid = e < hi;
             const uint64_t k = valid ? from[e] : 0ull;
             const uint32_t d = ((uint32_t)(k >> 32) >> shift) & mask;
             uint64_t same = __ballot(valid);
@@ -322,27 +341,41 @@ __global__ __launch_bounds__(64) void small_sort_kernel(Src src, uint32_t n, int
                 same &= bit ? vote : ~vote;
             }
             if (valid) {
-                to[h[d] + (uint32_t)__popcll(same & lt)] = k;
-                if ((same >> lane) == 1ull) h[d] += (uint32_t)__popcll(same);
+                to[h[wave][d] + (uint32_t)__popcll(same & lt)] = k;
+                if ((same >> lane) == 1ull) h[wave][d] += (uint32_t)__popcll(same);
             }
         }
         __syncthreads();
         uint64_t* t = from; from = to; to = t;
     }
+    // ordered keys out; segment heads in ascending order: heads per slice, offsets across the waves, then the positions
     uint32_t heads = 0;
-    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+    for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
         const uint32_t e = e0 + lane;
-        const bool valid = e < n;
-        const uint64_t k = valid ? from[e] : 0ull;
-        const bool head = valid && (e == 0 || (uint32_t)(k >> 32) != (uint32_t)(from[e - 1] >> 32));
-        if (valid) out[e] = k;
-        const uint64_t m = __ballot(head);
-        if (head) head_pos[heads + (uint32_t)__popcll(m & lt)] = e;
-        heads += (uint32_t)__popcll(m);
+        const bool valid = e < hi;
+        const bool head = valid && (e == 0 || (uint32_t)(from[e] >> 32) != (uint32_t)(from[e - 1] >> 32));
+        if (valid) out[e] = from[e];
+        heads += (uint32_t)__popcll(__ballot(head));
     }
-    if (lane == 0) {
-        *nheads = heads;
-        head_pos[heads] = n;
+    if (lane == 0) s_part[wave] = heads;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < SMALL_WAVES; ++w2) {
+        if (w2 < wave) off += s_part[w2];
+        total += s_part[w2];
+    }
+    for (uint32_t e0 = lo; e0 < hi; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool valid = e < hi;
+        const bool head = valid && (e == 0 || (uint32_t)(from[e] >> 32) != (uint32_t)(from[e - 1] >> 32));
+        const uint64_t mm = __ballot(head);
+        if (head) head_pos[off + (uint32_t)__popcll(mm & lt)] = e;
+        off += (uint32_t)__popcll(mm);
+    }
+    if (tid == 0) {
+        *nheads = total;
+        head_pos[total] = n;
     }
 }
 
@@ -424,7 +457,7 @@ void sort_and_list(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, ui
     const bool small_on = !(small_env && small_env[0] == '0');
     if (n <= (uint32_t)SMALL_N && small_on) {
         const PassPlan pp = plan_passes(row_bits);
-        hipLaunchKernelGGL((small_sort_kernel<Src>), dim3(1), dim3(64), 0, s, first, n, pp.passes, pp.digit_bits, out, head_pos, nheads);
+        hipLaunchKernelGGL((small_sort_kernel<Src>), dim3(1), dim3(SMALL_WAVES * 64), 0, s, first, n, pp.passes, pp.digit_bits, out, head_pos, nheads);
         return;
     }
     radix_sort(first, n, row_bits, tmp, out, sc, s);

@@ -170,7 +170,28 @@ def cpu_baseline(args, model_kind=0, loss_kind=2):
                     "sample": f"{workers} independent worker threads x {users} users of the same generator "
                               f"({rows} interactions), {args.model}+{args.loss} dim {args.dim}, 1 epoch each, C oracle, {dtn:.1f} s wall "
                               f"(single thread: {single:.0f} interactions/s)"})
+    if workload_label(args, 1).startswith("BASELINE.json configs[2]"):
+        out["movielens_batch1"] = cpu_movielens_batch1()
     return out
+
+
+def cpu_movielens_batch1():
+    """The CPU leg of `test_mrr.batch_sequences_1`: BASELINE.json configs[1] (MovieLens-100K, LSTM Normal, dim 32, WARP,
+    Adagrad, 10 epochs) at one subsequence per optimiser step — the reference's own schedule, which has no parallelism
+    inside a step — on ONE host core through the C oracle (fit time only)."""
+    from helpers import movielens_protocol
+    from oracle.oracle import OracleModel
+    from sbr_rs_amd._abi import make_hparams
+
+    data, train, _test, rng = movielens_protocol()
+    hp = make_hparams(data.num_items(), 128, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, 1)
+    m = OracleModel(hp)
+    t0 = time.perf_counter()
+    loss = m.fit(train.user_pointers, train.item_ids)
+    dt = time.perf_counter() - t0
+    return {"fit_seconds": dt, "fit_loss": loss, "cores": 1, "kind": "port",
+            "train_interactions_per_s": 10 * len(train.item_ids) / dt,
+            "config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, max_sequence_length 128, batch_sequences 1"}
 
 
 def movielens_mrr():

@@ -29,7 +29,10 @@ namespace sbr {
 namespace {
 
 #ifndef SBR_WAVE_MAX_SEQ
-#define SBR_WAVE_MAX_SEQ 2048 /* ms per step at d = 32, len <= 64, wave / tile form: 256 sequences 0.32 / 0.53, 2 048 0.43 / 0.55, 4 096 0.66 / 0.72, 8 192 0.93 / 0.68 */
+/* ms per step, len <= 64, wave / tile form of the recurrent kernels (everything else equal): d = 32: 1 sequence 0.126 / 0.216,
+ * 256 0.224 / 0.437, 2 048 0.336 / 0.458, 4 096 0.629 / 0.603, 8 192 1.01 / 0.705; d = 16: 2 048 0.230 / 0.373, 4 096 0.411 / 0.477,
+ * 8 192 0.501 / 0.506 — the wave form up to 2 048 sequences per step at d = 32, 4 096 at d = 16 */
+#define SBR_WAVE_MAX_SEQ 2048
 #endif
 constexpr size_t WAVE_LDS_LIMIT = 150 * 1024;
 #define SBR_WAVE_RSRC_FLAGS 0x00020000 /* word 3 of a raw buffer resource on gfx9-class targets (32-bit data format, no swizzle) */
@@ -526,7 +529,7 @@ int wave_mode() {  // SBR_WAVE: 0 never, 1 whenever the shape allows, unset: up 
 bool wave_shape_ok(int d, int ng, int B, size_t lds_bytes) {
     if ((d != 16 && d != 32) || (ng != 3 && ng != 4) || B <= 0 || lds_bytes > WAVE_LDS_LIMIT) return false;
     const int mode = wave_mode();
-    return mode == 1 || (mode < 0 && B <= SBR_WAVE_MAX_SEQ);
+    return mode == 1 || (mode < 0 && B <= (d == 16 ? 2 * SBR_WAVE_MAX_SEQ : SBR_WAVE_MAX_SEQ));
 }
 template <class K>
 void allow_lds(K kernel, size_t bytes) {

@@ -36,7 +36,10 @@ constexpr int SORT_ITEMS = 64;                 // keys per lane of a wave-tile: 
 constexpr int SORT_ITEMS_FINE = 8;             // ... or 512-key tiles while the input is small (SORT_FINE_MAX_N): a step of a few
                                                // hundred sequences is 10^4-10^5 keys — six 4 096-key tiles would leave the
                                                // ordering to six waves (150 us per step at 25 000 keys, under a 100 us BPTT)
-constexpr uint32_t SORT_FINE_MAX_N = 1u << 18;
+#ifndef SBR_SORT_FINE_MAX_LOG2
+#define SBR_SORT_FINE_MAX_LOG2 18
+#endif
+constexpr uint32_t SORT_FINE_MAX_N = 1u << SBR_SORT_FINE_MAX_LOG2;
 constexpr int SORT_BATCH = 8;                  // keys per lane requested together
 constexpr int SORT_MAX_DIGIT_BITS = 11;
 constexpr int SORT_WAVES = 4;                  // wave-tiles per workgroup

@@ -8,18 +8,24 @@
  *   forward   z_t = bW + x_t Wx + h_{t-1} Wh is a k-ascending fma chain whose x part comes first, so
  *             P_t = bW + x_t Wx does not depend on the recurrence: all 256 threads of the workgroup compute P_t for every
  *             t into LDS up front (and copy the gathered rows to X for the dense-gradient GEMM); then wave 0 walks t:
- *             lane l continues the chains of gate columns l and l + 64 over h_{t-1} (read from LDS as broadcast
- *             16-byte pieces), the gate pre-activations cross lanes through LDS, every lane evaluates the cell of unit
- *             l mod d and the lane groups share the stores of G / C / H.
- *   backward  the gate values, cell states and dloss/dh rows of every step are staged into LDS by all 256 threads;
+ *             lane l continues the chains of gate columns l and l + 64 over h_{t-1}.  d = 32 with four gates (the
+ *             reference's configuration): one packed fma per k with h_k from a v_readlane, the rational tanh of the lane's
+ *             own two pre-activations, numerators / denominators across the half-waves by v_permlane32_swap — no LDS
+ *             between two steps.  Other shapes: h_{t-1} and the pre-activations cross lanes through LDS, every lane
+ *             evaluates the cell of unit l mod d.  The lane groups share the stores of G / C / H.
+ *   backward  the gate values, cell states, tanh(c_t) and dloss/dh rows of every step are staged into LDS by all 256
+ *             threads (the transcendental of the cell backward does not depend on the gradient coming down the sequence);
  *             wave 0 walks t downwards: cell backward in lane u = l mod d, dz to LDS and HBM, then lane c owns column c
  *             of dz W^T (row c of W in registers: 4d values) — columns < d are dX of the row, columns >= d the recurrent
- *             dh, which goes back through LDS.
+ *             dh, which returns to the unit lanes by v_permlane32_swap / v_permlane16_swap.
+ *   also here lstm_dw_block_kernel: the dense gradient of such steps with one wave per 32 x 32 output block.
  *
  * Arithmetic is the contract's, operation for operation (sbr_numerics.h; fma chains in k / j order from the bias / from
  * 0), so the results are bit-identical to the tile kernels' and the oracle's; tests/test_parity_gpu.py runs both forms.
- * A workgroup per sequence: up to SBR_WAVE_MAX_SEQ sequences per step take this path (launch_wave_* return false
- * otherwise and the caller launches the tile kernels). */
+ * A workgroup per sequence: up to SBR_WAVE_MAX_SEQ sequences per step (twice that at d = 16) take this path (launch_wave_*
+ * return false otherwise and the caller launches the tile kernels).  The machine model behind the design — a lone wave
+ * issues a dependent vector instruction every 8.8 cycles, so a step costs its instruction count — is measured by
+ * tools/valu_chain_ubench.hip; numbers in profiles/r03_small_steps.md. */
 #include <cstdlib>
 
 #include "sbr_kernels.h"
@@ -134,24 +140,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_wave_kernel(ModelView m, MbView 
         for (int k = 0; k < D; ++k) w2[k] = (v2f){m.W[(size_t)(D + k) * NGD + lane], m.W[(size_t)(D + k) * NGD + 64 + lane]};
         const bool low = lane < 32;
         float c_prev = 0.0f, h_prev = 0.0f;
-#ifdef SBR_PROF_WAVE
-        const long long pc0 = clock64(), pw0 = wall_clock64();
-        long long pacc[4] = {0, 0, 0, 0}, pt = pc0;
-#define WPROF(k_) { const long long n_ = clock64(); pacc[k_] += n_ - pt; pt = n_; }
-#else
-#define WPROF(k_)
-#endif
         for (int t = 0; t < nsteps; ++t) {
-            WPROF(3)
             v2f z2 = (v2f){Ps[t * NGD + lane], Ps[t * NGD + 64 + lane]};
-            // h_{t-1}[k] lives in lane k: a v_readlane per k puts it into a scalar register (no LDS round trip between the
-            // cell and the chain; the reads do not depend on the chain and fill its dependent-issue gaps)
+            // h_{t-1}[k] lives in lane k: a v_readlane per k puts it into a scalar register.  Each costs an issue slot of its
+            // own (17 cycles per readlane + fma pair, tools/valu_chain_ubench.hip), but there is no LDS write -> 16-byte read
+            // round trip between the cell and the chain any more: 44.1 -> 40.1 us per MovieLens subsequence
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 const float hk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h_prev), k));
                 z2 = pk_fma(pk_splat(hk), w2[k], z2);
             }
-            WPROF(0)
             // arguments of the rational tanh: i, f, o are sigmoids (tanh of half the pre-activation), g is a tanh
             const float half1 = 0.5f * z2.y;
             v2f p2, q2;
@@ -173,7 +171,6 @@ __global__ __launch_bounds__(256) void lstm_fwd_wave_kernel(ModelView m, MbView 
             const float go = sbr_fma(0.5f, po * (r_go * qg), 0.5f);
             const float cc = sbr_fma(gf, c_prev, gi * gg);
             c_prev = cc;
-            WPROF(1)
             const int r_ = __builtin_amdgcn_readfirstlane(Rs[t]);
             float* Grow = w.G + (size_t)r_ * 4 * D;
             Grow[lane] = low ? gi : gf;
@@ -183,14 +180,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_wave_kernel(ModelView m, MbView 
                 w.C[(size_t)r_ * D + u] = cc;
                 H[(size_t)r_ * D + u] = h_prev;
             }
-            WPROF(2)
         }
-#ifdef SBR_PROF_WAVE
-        if (lane == 0 && b == 0 && nsteps > 100)
-            printf("WAVEPROF fwd steps %d: cycles/step %lld (chain %lld, cell %lld, tanh(c)+stores %lld, loop %lld); shader clock %.0f MHz\n", nsteps,
-                   (clock64() - pc0) / nsteps, pacc[0] / nsteps, pacc[1] / nsteps, pacc[2] / nsteps, pacc[3] / nsteps,
-                   (double)(clock64() - pc0) / (double)(wall_clock64() - pw0) * 100.0);
-#endif
         return;
     }
     float wh[SLOTS][D];

@@ -388,6 +388,9 @@ __global__ __launch_bounds__(256) void materialize_dh_kernel(ModelView m, BlockV
 // ------------------------------------------------------------------------------------------------
 // K2': EWMA forward / backward scans — one d/4-lane group per sequence
 // ------------------------------------------------------------------------------------------------
+#ifndef EWMA_U
+#define EWMA_U 4 /* time steps whose gathers are in flight together in the EWMA scans */
+#endif
 template <int D>
 __global__ __launch_bounds__(256) void ewma_forward_kernel(ModelView m, MbView mb, float* H) {
     constexpr int L = D / 4;
@@ -404,18 +407,33 @@ __global__ __launch_bounds__(256) void ewma_forward_kernel(ModelView m, MbView m
     for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) {
         const int n = mb.steps[b];
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < n; ++t) {
-            const int r = mb.off[t] + b;
-            const float4 x = ld4(m.E + (size_t)mb.in_idx[r] * D + 4 * lg);
-            if (t == 0) {
-                s = x;
-            } else {
-                s.x = sbr_fma(a[0], s.x, oma[0] * x.x);
-                s.y = sbr_fma(a[1], s.y, oma[1] * x.y);
-                s.z = sbr_fma(a[2], s.z, oma[2] * x.z);
-                s.w = sbr_fma(a[3], s.w, oma[3] * x.w);
+        // the gathers do not depend on the scan: the rows of EWMA_U steps are requested together (their indices first), then the
+        // dependent fma chain runs over them — one sequence per step (the reference's schedule) would otherwise pay two
+        // dependent memory round trips per time step
+        for (int t0 = 0; t0 < n; t0 += EWMA_U) {
+            int r[EWMA_U];
+            uint32_t it[EWMA_U];
+            float4 x[EWMA_U];
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) r[q] = mb.off[t0 + q < n ? t0 + q : n - 1] + b;
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) it[q] = mb.in_idx[r[q]];
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) x[q] = ld4(m.E + (size_t)it[q] * D + 4 * lg);
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) {
+                if (t0 + q < n) {
+                    if (t0 + q == 0) {
+                        s = x[q];
+                    } else {
+                        s.x = sbr_fma(a[0], s.x, oma[0] * x[q].x);
+                        s.y = sbr_fma(a[1], s.y, oma[1] * x[q].y);
+                        s.z = sbr_fma(a[2], s.z, oma[2] * x[q].z);
+                        s.w = sbr_fma(a[3], s.w, oma[3] * x[q].w);
+                    }
+                    st4(H + (size_t)r[q] * D + 4 * lg, s);
+                }
             }
-            st4(H + (size_t)r * D + 4 * lg, s);
         }
     }
 }
@@ -437,35 +455,62 @@ __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView 
         const int n = mb.steps[b];
         float carry[4] = {0.f, 0.f, 0.f, 0.f};
         float da[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t = n - 1; t >= 0; --t) {
-            const int r = mb.off[t] + b;
-            const float4 dh = dh_loss4(m, blk, (size_t)r, 4 * lg, D);
-            float ds[4] = {dh.x, dh.y, dh.z, dh.w};
-            if (t != n - 1) {
+        for (int t0 = n - 1; t0 >= 0; t0 -= EWMA_U) {  // EWMA_U steps' rows requested together, as in the forward scan
+            int r[EWMA_U], rp[EWMA_U];
+            uint32_t ii[EWMA_U], ni[EWMA_U], oi[EWMA_U];
+            float g[EWMA_U];
+            float4 x[EWMA_U], sp[EWMA_U], en[EWMA_U], ep[EWMA_U];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
+            for (int q = 0; q < EWMA_U; ++q) {
+                const int t = t0 - q >= 0 ? t0 - q : 0;
+                r[q] = mb.off[t] + b;
+                rp[q] = mb.off[t > 0 ? t - 1 : 0] + b;
             }
-            float4 dx;
-            if (t > 0) {
-                const float4 x = ld4(m.E + (size_t)mb.in_idx[r] * D + 4 * lg);
-                const float4 sp = ld4(blk.H + (size_t)(mb.off[t - 1] + b) * D + 4 * lg);
-                const float xs[4] = {x.x, x.y, x.z, x.w};
-                const float sps[4] = {sp.x, sp.y, sp.z, sp.w};
-                float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = oma[j] * ds[j];
-                    carry[j] = a[j] * ds[j];
-                    da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+            for (int q = 0; q < EWMA_U; ++q) {
+                ii[q] = mb.in_idx[r[q]];
+                ni[q] = blk.neg[r[q]];
+                oi[q] = blk.out_idx[r[q]];
+                g[q] = blk.coef[r[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) {
+                x[q] = ld4(m.E + (size_t)ii[q] * D + 4 * lg);
+                sp[q] = ld4(blk.H + (size_t)rp[q] * D + 4 * lg);
+                en[q] = ld4(m.E + (size_t)ni[q] * D + 4 * lg);
+                ep[q] = ld4(m.E + (size_t)oi[q] * D + 4 * lg);
+            }
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) {
+                const int t = t0 - q;
+                if (t < 0) continue;
+                // dloss/dh: g*E[neg] - g*E[pos], two rounded products and one subtraction (dh_loss4)
+                float ds[4] = {g[q] * en[q].x - g[q] * ep[q].x, g[q] * en[q].y - g[q] * ep[q].y, g[q] * en[q].z - g[q] * ep[q].z,
+                               g[q] * en[q].w - g[q] * ep[q].w};
+                if (t != n - 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
                 }
-                dx = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-                dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                float4 dx;
+                if (t > 0) {
+                    const float xs[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
+                    const float sps[4] = {sp[q].x, sp[q].y, sp[q].z, sp[q].w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = oma[j] * ds[j];
+                        carry[j] = a[j] * ds[j];
+                        da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+                    }
+                    dx = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                }
+                st4(blk.dX + (size_t)r[q] * D + 4 * lg, dx);
             }
-            st4(blk.dX + (size_t)r * D + 4 * lg, dx);
         }
         st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
     }

@@ -528,7 +528,7 @@ def main():
         model.set_overlap(True)
     model.timing_enable(False)
 
-    def short_run(hp_x, ptr_x, items_x, steps, warm):
+    def short_run(hp_x, ptr_x, items_x, steps, warm, timers=True):
         """A few untimed-region steps of another configuration on a fresh model: (interactions/s, SCORE ms per launch,
         rows per launch, negatives per interaction)."""
         mdl = engine.Model(hp_x)
@@ -538,7 +538,7 @@ def main():
         for i in range(warm):
             lp.step(i % nmb)
         mdl.synchronize()
-        mdl.timing_enable(True)
+        mdl.timing_enable(timers)  # (the per-kernel events cost a small step a third of its time: off for those)
         mdl.timing_read()
         e0, n0 = be.plan.counters()
         rows = 0
@@ -552,10 +552,10 @@ def main():
         tm = mdl.timing_read()
         e1, n1 = be.plan.counters()
         be.close()
-        sc_ms = tm["SCORE"][0] / max(tm["SCORE"][1], 1) if "SCORE" in tm else None
+        sc_ms = tm["SCORE"][0] / max(tm["SCORE"][1], 1) if timers and "SCORE" in tm else None
         return rows / dt, sc_ms, rows / max(steps, 1), (n1 - n0) / max(e1 - e0, 1), 1e3 * dt / max(steps, 1)
 
-    cold, sweep = None, None
+    cold, sweep, small = None, None, None
     if world == 1 and not args.force_exchange and not args.partition_table and rank == 0:
         if args.cold_items > 0 and model_kind != 2:
             try:  # the same kernel against a table far larger than the Infinity Cache: no row is re-read from cache
@@ -580,6 +580,19 @@ def main():
                     sweep.append({"batch_sequences": bsz, "interactions_per_s": v, "ms_per_step": ms, "interactions_per_step": rpl})
             except Exception as e:
                 sweep.append({"error": repr(e)})
+        if args.batch_sweep and workload_label(args, 1).startswith("BASELINE.json configs[2]"):
+            # the reference's own regime: embedding_dim 32 (lib.rs:22-58) and few sequences per optimiser step — wave-per-sequence
+            # recurrent kernels, block-form dense gradient, single-launch ordering / reduction (profiles/r03_small_steps.md)
+            small = {"config": "synthetic 40 000 users x 100 000 items, len <= 64, dim 32, lstm+warp, whole optimiser steps, no per-kernel timers",
+                     "rows": []}
+            try:
+                sp, si = synthetic_csr(40_000, 100_000, 64)
+                for bsz in (1, 16, 256, 2048):
+                    v, _, rpl, _, ms = short_run(make_hp(args, 1, 0, 0, 2, 100_000, batch=bsz, dim=32, max_len=64), sp, si, 200 if bsz <= 256 else 19, 40 if bsz <= 256 else 1, timers=False)
+                    small["rows"].append({"batch_sequences": bsz, "interactions_per_s": v, "ms_per_step": ms, "interactions_per_step": rpl})
+                del sp, si
+            except Exception as e:
+                small["error"] = repr(e)
 
     if rank == 0:
         d, ng = args.dim, {0: 4, 1: 3, 2: 0}[model_kind]
@@ -686,6 +699,8 @@ def main():
             if hit and model_kind != 2:
                 out["value_quality_neutral"] = {"value": hit[0]["interactions_per_s"], "unit": "interactions/s", "ms_per_step": hit[0]["ms_per_step"],
                                                 "batch_sequences_per_gpu": qn["batch_sequences"], "criterion": qn["criterion"], "table": qn["table"]}
+        if small is not None:
+            out["small_steps"] = small
         if args.param_crc:
             import zlib
 

@@ -521,9 +521,17 @@ bool wave_shape_ok(int d, int ng, int B, size_t lds_bytes) {
     const int mode = wave_mode();
     return mode == 1 || (mode < 0 && B <= (d == 16 ? 2 * SBR_WAVE_MAX_SEQ : SBR_WAVE_MAX_SEQ));
 }
+// dynamic LDS beyond the default limit has to be granted per kernel; `granted` is the instantiation's high-water mark, so a
+// step of a few microseconds does not pay for the call again
+// (per device: the attribute belongs to the function on the current device, and one process may drive several)
 template <class K>
-void allow_lds(K kernel, size_t bytes) {
+void allow_lds(K kernel, size_t bytes, size_t* granted) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (bytes <= granted[dev]) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    granted[dev] = bytes;
 }
 
 }  // namespace
@@ -534,7 +542,8 @@ bool launch_wave_forward(const ModelView& m, const MbView& mb, float* H, const W
     if (!wave_shape_ok(d, m.ng, mb.B, lds)) return false;
 #define SBR_WAVE_FWD(DD, NN)                                                                                   \
     {                                                                                                          \
-        allow_lds(lstm_fwd_wave_kernel<DD, NN>, lds);                                                          \
+        static size_t granted[64] = {0};                                                                             \
+        allow_lds(lstm_fwd_wave_kernel<DD, NN>, lds, granted);                                                \
         hipLaunchKernelGGL((lstm_fwd_wave_kernel<DD, NN>), dim3(mb.B), dim3(256), lds, s, m, mb, H, w, tm_host);       \
     }
     if (d == 32 && m.ng == 4) SBR_WAVE_FWD(32, 4)
@@ -552,7 +561,8 @@ bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView&
     if (!wave_shape_ok(d, m.ng, b_host, lds)) return false;
 #define SBR_WAVE_BWD(DD, NN)                                                                                   \
     {                                                                                                          \
-        allow_lds(lstm_bwd_wave_kernel<DD, NN>, lds);                                                          \
+        static size_t granted[64] = {0};                                                                             \
+        allow_lds(lstm_bwd_wave_kernel<DD, NN>, lds, granted);                                                \
         hipLaunchKernelGGL((lstm_bwd_wave_kernel<DD, NN>), dim3(b_host), dim3(256), lds, s, m, mb, blk, w, tm_host);   \
     }
     if (d == 32 && m.ng == 4) SBR_WAVE_BWD(32, 4)
@@ -571,10 +581,12 @@ bool launch_wave_dense_gradient(const ModelView& m, const MbView& mb, const Bloc
     const int mode = e ? (std::atoi(e) ? 1 : 0) : -1;
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     if (mode == 0 || (mode < 0 && nch > SBR_DW_BLOCK_MAX_CHUNKS)) return false;
+    if ((size_t)rows_host * m.ng * d * 4 >= ((size_t)1 << 31)) return false; /* the kernel's 32-bit buffer offsets */
 #define SBR_DW_BLOCK_LAUNCH(DD, NN)                                                                                          \
     {                                                                                                                        \
         using Cfg = DwBlockCfg<DD, NN>;                                                                                      \
-        allow_lds(lstm_dw_block_kernel<DD, NN>, Cfg::lds_bytes);                                                             \
+        static size_t granted[64] = {0};                                                                                           \
+        allow_lds(lstm_dw_block_kernel<DD, NN>, Cfg::lds_bytes, granted);                                                    \
         hipLaunchKernelGGL((lstm_dw_block_kernel<DD, NN>), dim3(nch * Cfg::KB), dim3(Cfg::NT), Cfg::lds_bytes, s, m, mb, blk, w); \
     }
     if (d == 32 && m.ng == 4) SBR_DW_BLOCK_LAUNCH(32, 4)

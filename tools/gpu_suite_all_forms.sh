@@ -1,0 +1,9 @@
+#!/bin/bash
+# The GPU parity suite three times: with the engine's own choice of kernel forms, with the MFMA tile forms forced everywhere
+# (the forms that small test shapes no longer reach by default), and with the wave / block forms forced wherever the shape
+# allows.  All three must give the same 0 failures: the forms are bit-identical.  (On an MI355X; ~3 minutes.)
+cd "$(dirname "$0")/.." || exit 1
+set -e
+echo "== engine's choice";   python -m pytest tests -m gpu -x -q | tail -2
+echo "== tile forms forced"; SBR_WAVE=0 SBR_DW_BLOCK=0 SBR_SMALL_STEP_ROWS=0 SBR_SORT_ITEMS=64 python -m pytest tests -m gpu -x -q | tail -2
+echo "== wave forms forced"; SBR_WAVE=1 SBR_DW_BLOCK=1 python -m pytest tests -m gpu -x -q | tail -2

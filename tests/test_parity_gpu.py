@@ -840,16 +840,39 @@ def test_small_step_with_a_hot_row():
         assert_params_equal(g, o, kind, "hot row in a small step")
 
 
-def test_wave_form_falls_back_for_long_sequences(monkeypatch):
-    """The wave form stages every step of a sequence in LDS; a max_sequence_length that does not fit (here 300 steps at
-    d = 32) takes the tile kernels even when SBR_WAVE = 1 asks for the wave form."""
+@pytest.mark.parametrize("kind,d", [(ModelKind.LSTM_NORMAL, 32), (ModelKind.LSTM_COUPLED, 16)])
+def test_wave_form_walks_long_sequences_in_segments(monkeypatch, kind, d):
+    """The wave form stages 128 time steps of a sequence in LDS at a time and carries the recurrence's state in registers
+    from segment to segment: 300-step sequences (three segments each way, the last one ragged) against the oracle."""
     monkeypatch.setenv("SBR_WAVE", "1")
     users, items, T = 12, 101, 300
     ptr, it = synthetic_interactions(users, items, T, seed=5, min_len=250)
-    hp = hparams(items, T, 32, int(ModelKind.LSTM_NORMAL), LOSS_WARP, epochs=1, B=2)
+    hp = hparams(items, T, d, int(kind), LOSS_WARP, epochs=1, B=2)
     g, o = make_pair(hp)
     assert g.fit(ptr, it) == pytest.approx(o.fit(ptr, it), rel=1e-6)
-    assert_params_equal(g, o, ModelKind.LSTM_NORMAL, "long sequences")
+    assert_params_equal(g, o, kind, "long sequences")
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+@pytest.mark.parametrize("kind", [ModelKind.LSTM_NORMAL, ModelKind.LSTM_COUPLED])
+def test_non_finite_inputs_propagate_through_the_recurrent_pass(monkeypatch, kind, wave):
+    """A NaN (or an infinity) in an embedding row reaches the hidden state as the oracle says it does — in the tile form and in
+    the wave form, whose packed tanh clamps with v_med3_f32 + an unordered comparison instead of two comparison + select pairs."""
+    monkeypatch.setenv("SBR_WAVE", wave)
+    items, d = 40, 32
+    hp = hparams(items, 12, d, int(kind), LOSS_HINGE, B=1)
+    g, o = make_pair(hp)
+    E = g.get_param(Param.ITEM_EMBEDDING).copy().reshape(items, d)
+    E[3, 5] = np.nan
+    E[7, 0] = np.inf
+    E[9, 1] = -np.inf
+    for m in (g, o):
+        m.set_param(Param.ITEM_EMBEDDING, E)
+    for seq in ([1, 3, 5], [2, 4, 6, 8], [7, 1], [9, 2, 2], [1, 2, 3, 4, 5, 6]):
+        hg, ho = g.user_representation(np.array(seq, np.uint32)), o.user_representation(np.array(seq, np.uint32))
+        assert np.array_equal(np.isnan(hg), np.isnan(ho)), seq
+        fin = ~np.isnan(ho)
+        assert np.array_equal(hg[fin].view(np.uint32), ho[fin].view(np.uint32)), seq
 
 
 def test_full_size_properties():

@@ -503,6 +503,8 @@ struct sbr_fit_plan {
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
     bool sort_off_stream = false; /* the step's key ordering ran on another stream than the main one: ev_sorted joins it */
+    bool sorted_event_live = false; /* ev_sorted has been recorded at least once: the multi-device consumers wait on it whatever the
+                                     * last step's placement was (a completed event costs nothing; the flag above belongs to ONE step) */
     bool header_accumulated = false; /* single device: block_header_kernel already added this step to loss_acc / ex_acc */
     /* partitioned item table: this device's gradient list (addressed by sorted-key position), the owner
      * bounds, and the owner-side merge buffers */
@@ -1313,7 +1315,10 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
                                  early_sort ? &mv : nullptr, epoch_key, m->hp.num_items);
         }
         p->sort_off_stream = on != m->stream; /* on the main stream the update is ordered behind the sort anyway: no event */
-        if (p->sort_off_stream) HIPCHK(hipEventRecord(m->ev_sorted, on));
+        if (p->sort_off_stream) {
+            HIPCHK(hipEventRecord(m->ev_sorted, on));
+            p->sorted_event_live = true;
+        }
         return SBR_OK;
     };
     if (early_sort) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
@@ -1414,7 +1419,7 @@ sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* devic
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        if (p->sorted_event_live) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
         sbr::launch_seg_scatter(m->mv, bv, R, p->ndev, slice_rows(p), device_send, p->keys_sorted, p->seg, m->stream);
     }
     HIPCHK(hipGetLastError());
@@ -1569,7 +1574,7 @@ static sbr_status partition_reduce_own(sbr_fit_plan* p, uint64_t minibatch) {
     SBRCHK(partition_buffers(p));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
-    if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+    if (p->sorted_event_live) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         sbr::launch_seg_list(m->mv, bv, R, p->ndev, slice_rows(p), p->keys_sorted, p->glist, p->gblist, p->gfl, p->bounds_dev, p->seg,

@@ -527,6 +527,15 @@ __global__ void ewma_dab_chunk_kernel(const float* dab, int B, int D, float* par
     for (int b = b0; b < b1; ++b) pc = pc + dab[(size_t)b * D + k];
     partials[(size_t)c * D + k] = pc;
 }
+// both in one launch when all sequences fit one chunk (small steps: a launch is ~5 us of a ~60 us step)
+__global__ void ewma_dab_final_kernel(const float* dab, int B, int D, const float* alpha, float* dense) {
+    const int k = threadIdx.x;
+    if (k >= D) return;
+    float pc = 0.0f;
+    for (int b = 0; b < B; ++b) pc = pc + dab[(size_t)b * D + k];
+    const float a = sbr_sigmoidf(alpha[k]);
+    dense[k] = pc * (a * (1.0f - a));
+}
 __global__ void ewma_dense_final_kernel(const float* partials, int nchunks, int D, const float* alpha, float* dense) {
     const int k = threadIdx.x;
     if (k >= D) return;
@@ -2793,6 +2802,10 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     if (rows_host == 0) return; /* the empty case is handled by launch_recurrent_backward */
     if (m.ng == 0) { /* EWMA: dalpha from the per-sequence partials the backward scan left in w.dab */
         const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
+        if (nch == 1) {
+            hipLaunchKernelGGL(ewma_dab_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.dab, b_host, m.d, m.alpha, blk.dense);
+            return;
+        }
         hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.dab, b_host, m.d, w_in.partials);
         hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.partials, nch, m.d, m.alpha, blk.dense);
         return;

@@ -426,6 +426,7 @@ struct WorkBuffers {
 sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool training, WorkBuffers* wb) {
     const uint64_t d = (uint64_t)m->d;
     sbr::WorkView& v = wb->v;
+    v.fold_max_tiles = std::getenv("SBR_FOLD_MAX_TILES") ? std::atoi(std::getenv("SBR_FOLD_MAX_TILES")) : SBR_FOLD_MAX_TILES_DEFAULT;
     if (m->ng) {
         SBRCHK(dmalloc(&v.C, rmax * d));
         SBRCHK(dmalloc(&v.G, rmax * d * 4));

@@ -777,7 +777,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
     const int nslot = 256;
     const int q = (int)blockIdx.x / nslot, c = (int)blockIdx.x % nslot;
     const int fold_w = ntiles - q * nslot < nslot ? ntiles - q * nslot : nslot;
-    const int tile = (q & 1) ? q * nslot + (fold_w - 1 - c) : (int)blockIdx.x;
+    const int tile = (q & 1) && ntiles <= w.fold_max_tiles ? q * nslot + (fold_w - 1 - c) : (int)blockIdx.x;
     const int b0 = tile * ROWS;
     const int nsteps = mb.steps[b0];
     // the row offsets of the steps are read from LDS inside the time loop (a global read there would be a
@@ -1249,14 +1249,27 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
     constexpr int ROWS = 16 * RT;
     constexpr int Q = D / 4;
     constexpr int CITER = (ROWS * Q) / NT;  // = RT
-    constexpr int PF = RT >= 4 ? 4 : (NSZ % 2 == 0 ? 2 : 1);  // ring depth (k-blocks in flight per column tile)
+    // ring depth (k-blocks in flight per column tile).  16-sequence tiles: a k-block is 8 MFMAs = 256 pipe cycles, so two blocks
+    // ahead are less than a round trip to L2 and the GEMM phase ran at 60 % of the pipe (27 000 cycles for 256 MFMAs per wave,
+    // two waves per SIMD; the forward kernel's 16-MFMA blocks: 86 %) — four there
+#ifndef SBR_BWD_PF_RT1
+#define SBR_BWD_PF_RT1 4
+#endif
+    constexpr int PF = RT >= 4 ? 4 : (RT == 1 && NSZ % SBR_BWD_PF_RT1 == 0 && NSZ >= 2 * SBR_BWD_PF_RT1 ? SBR_BWD_PF_RT1 : (NSZ % 2 == 0 ? 2 : 1));
     static_assert(NSZ >= 2 * PF && NSZ % PF == 0, "ring does not tile the GEMM");
     __shared__ float Zs[ROWS * LDZ];
     __shared__ int s_off[SBR_MAX_T + 2];
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     auto thread_id = [&]() { int t_ = tid0; asm volatile("" : "+v"(t_)); return t_; };
-    const int b0 = blockIdx.x * ROWS;
+    // tiles are sorted by length; the list is folded as in the forward kernel, so that consecutive resident slots of a CU get
+    // long/short/long/short ... (without it 512 tiles on 256 CUs gave CU 0 the two longest tiles of the two halves — 93 steps —
+    // and CU 255 the two shortest — 35: BPTT 0.91 ms against the forward pass's 0.68 at 8 192 sequences per step)
+    const int nslot = 256, ntiles = (int)gridDim.x;
+    const int fq = (int)blockIdx.x / nslot, fc = (int)blockIdx.x % nslot;
+    const int fold_w = ntiles - fq * nslot < nslot ? ntiles - fq * nslot : nslot;
+    const int tile = (fq & 1) && ntiles <= w.fold_max_tiles ? fq * nslot + (fold_w - 1 - fc) : (int)blockIdx.x;
+    const int b0 = tile * ROWS;
     const int nsteps = mb.steps[b0];
     for (int idx = tid0; idx <= nsteps; idx += NT) s_off[idx] = mb.off[idx];
     for (int idx = tid0; idx < ROWS * D; idx += NT) Zs[(idx / D) * LDZ + (idx % D)] = 0.0f;  // no recurrent dh yet
@@ -1427,19 +1440,32 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[cc][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto mma_block = [&](int S, int slot) {
-            float av[RT][4];
+        // The dz operand of k-block S + 1 is read from LDS BEFORE the MFMAs of block S are issued: a wave holds only two
+        // accumulators here (the forward kernel: four), every second MFMA waits for its predecessor on the same accumulator, and
+        // an LDS read queued behind them would expose its whole latency once per block (measured: 71 % of the pipe in this
+        // phase against the forward kernel's 86 %)
+        float av[RT][4];
+        auto read_a = [&](int S) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * S + kq];
+                const float* arow = &Zs[(rt * 16 + c16) * LDZ + 16 * (S < NSZ ? S : NSZ - 1) + kq];
                 av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
             }
+        };
+        read_a(0);
+        auto mma_block = [&](int S, int slot) {
+            float ac[RT][4];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) ac[rt][sub] = av[rt][sub];
+            read_a(S + 1);
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], ring0[slot][sub], acc[0][rt], 0, 0, 0);
-                    acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], ring1[slot][sub], acc[1][rt], 0, 0, 0);
+                    acc[0][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][sub], ring0[slot][sub], acc[0][rt], 0, 0, 0);
+                    acc[1][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][sub], ring1[slot][sub], acc[1][rt], 0, 0, 0);
                 }
         };
 #pragma unroll
@@ -1505,8 +1531,8 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
 #pragma unroll 1
     for (int t = ts - 1; t >= 0; --t) step(t);
 #ifdef SBR_PROF_BWD
-    if ((blockIdx.x == 20 || blockIdx.x == 350) && (tid0 & 63) == 0 && (wv == 0 || wv == 5))
-        printf("BWDPROF tile %d wave %d steps %d per-step cycles: epilogue+ringreq %lld barA %lld cell %lld barB %lld gemm+requests %lld barC %lld\n", (int)blockIdx.x, wv,
+    if ((tile == 20 || tile == 350) && (tid0 & 63) == 0 && (wv == 0 || wv == 5))
+        printf("BWDPROF tile %d wave %d steps %d per-step cycles: epilogue+ringreq %lld barA %lld cell %lld barB %lld gemm+requests %lld barC %lld\n", tile, wv,
                nsteps, bprof[0] / nsteps, bprof[1] / nsteps, bprof[2] / nsteps, bprof[3] / nsteps, bprof[4] / nsteps, bprof[5] / nsteps);
 #endif
 }

@@ -52,8 +52,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
  * the kernel time is the longest tile's chain of dependent steps, and a 16-row step costs half the MFMA time of a 32-row
  * step on its CU.  M interactions/s of the whole step, 32- vs 16-sequence tiles, bench workload (profiles/r03_batch_sweep_tiles.md):
  * 256 sequences 3.4 / 5.8, 1 024 12.7 / 21.7, 4 096 43.7 / 66.4, 8 192 74.4 / 96.5, 16 384 (512 tiles) 100.5 / 104.0,
- * 50 000 122.3 / 114.7. */
-#define SBR_SEQ_RT1_MAX_TILES 640
+ * 50 000 122.3 / 114.7.  Since BPTT folds its tile list, keeps four weight blocks in flight and reads its dz operand a block
+ * ahead (all of which the 16-sequence form gains most from), ms per step 32- / 16-sequence tiles on one box: 8 192 3.53 / 2.63,
+ * 12 000 4.02 / 3.45, 20 000 5.96 / 5.85, 24 000 6.08 / 5.74, 30 000 7.60 / 7.27, 35 000 9.57 / 9.57, 40 000 9.82 / 9.92,
+ * 50 000 13.66 / 13.79: the 16-sequence form up to 1 000 32-sequence tiles (32 000 sequences per step). */
+#define SBR_SEQ_RT1_MAX_TILES 1000
 #endif
 #ifndef SBR_BWD_RT4_MIN_TILES
 #define SBR_BWD_RT4_MIN_TILES 3000

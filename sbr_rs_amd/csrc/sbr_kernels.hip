@@ -914,12 +914,32 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
             for (int p = 0; p < UPW; ++p)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) acc[rt][p][g] = (f32x4){bias[p][g], bias[p][g], bias[p][g], bias[p][g]};
-        auto mma_block = [&](int S, f32x4 (*bf)[NG]) {
-            float av[RT][4];
+        // the [x | h] operand of k-block S + 1 is read from LDS before the MFMAs of block S are issued (16-sequence tiles: the
+        // registers are there; the 32-sequence form has none to spare and the other resident workgroup to cover the read)
+        constexpr bool A_AHEAD = RT == 1;
+        float av[RT][4];
+        auto read_a = [&](int S) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const float* arow = &As[(rt * 16 + j16) * LDA + 16 * S + kq];
+                const float* arow = &As[(rt * 16 + j16) * LDA + 16 * (S < NS ? S : NS - 1) + kq];
                 av[rt][0] = arow[0]; av[rt][1] = arow[4]; av[rt][2] = arow[8]; av[rt][3] = arow[12];
+            }
+        };
+        if constexpr (A_AHEAD) read_a(0);
+        auto mma_block = [&](int S, f32x4 (*bf)[NG]) {
+            float ac[RT][4];
+            if constexpr (A_AHEAD) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) ac[rt][sub] = av[rt][sub];
+                read_a(S + 1);
+            } else {
+                read_a(S);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub) ac[rt][sub] = av[rt][sub];
             }
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
@@ -929,7 +949,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                     for (int p = 0; p < UPW; ++p)
 #pragma unroll
                         for (int g = 0; g < NG; ++g)
-                            acc[rt][p][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][sub], bf[p][g][sub], acc[rt][p][g], 0, 0, 0);
+                            acc[rt][p][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][sub], bf[p][g][sub], acc[rt][p][g], 0, 0, 0);
         };
         // sched_barrier: the request that refills a ring slot is issued as soon as the slot has been consumed
         // (PF - 1 blocks of MFMAs ahead of its use), not sunk to the end of the loop body by the scheduler

@@ -708,10 +708,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_splat(float x) { return (v2f){x, x}; }
 __device__ __forceinline__ void tanh_pq_x2(v2f x, v2f* p, v2f* q) {
-    x.x = x.x > SBR_TANH_CLAMP ? SBR_TANH_CLAMP : x.x;  // comparison + select: NaN stays NaN (sbr_approx.h)
-    x.x = x.x < -SBR_TANH_CLAMP ? -SBR_TANH_CLAMP : x.x;
-    x.y = x.y > SBR_TANH_CLAMP ? SBR_TANH_CLAMP : x.y;
-    x.y = x.y < -SBR_TANH_CLAMP ? -SBR_TANH_CLAMP : x.y;
+    // sbr_tanh_pq's clamp (two comparison + select pairs; a NaN stays NaN) as one v_med3_f32 — which alone would turn a NaN
+    // into -C — and one unordered comparison + select that puts the NaN back: the same bits for every input, fewer vector
+    // instructions (which f32 MFMAs do not hide)
+    const float cx = __builtin_amdgcn_fmed3f(x.x, -SBR_TANH_CLAMP, SBR_TANH_CLAMP), cy = __builtin_amdgcn_fmed3f(x.y, -SBR_TANH_CLAMP, SBR_TANH_CLAMP);
+    x.x = x.x != x.x ? x.x : cx;
+    x.y = x.y != x.y ? x.y : cy;
     const v2f x2 = x * x;
     v2f n = pk_splat(-2.76076847742355e-16f);
     n = pk_fma(n, x2, pk_splat(2.00018790482477e-13f));

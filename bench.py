@@ -2,7 +2,8 @@
 """bench.py — train interactions/sec of the sequence-recommender hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by the driver through torch.distributed.run, one rank per GPU)
+    (N > 1: one rank per GPU.  Under a launcher — WORLD_SIZE set, e.g. the driver's `python -m torch.distributed.run` —
+    this process IS a rank; without one it starts the N ranks itself through the same launcher on 127.0.0.1.)
 
 A *step* is one optimiser step of the hot path: one minibatch of `--batch-sequences` synthetic
 subsequences per GPU through forward (embedding gather + LSTM), WARP negative sampling + loss,
@@ -31,8 +32,9 @@ streams; concurrent families include each other's contention); `kernels_standalo
 second, UNTIMED pass with stream overlap off (N = 1): every family alone, with the sparse update's
 HBM figure and the GEMM-shaped kernels' MFMA figures; `roofline_mfma` are the in-region MFMA
 figures; `cpu_baseline` is the CPU oracle (a scalar C port of the same algorithm; the Rust
-reference cannot be built here) timed on the host, single-thread and on independent worker
-threads, on a bounded sample of the same workload, rank 0, N = 1 only; `test_mrr` is configs[1]
+reference cannot be built here) timed on the host in the reference's parallel shape — every core a
+worker on ONE shared parameter set, Hogwild and synchronised — and single-thread, each leg bounded in
+wall time, rank 0, N = 1 only; `test_mrr` is configs[1]
 (MovieLens-100K), untimed.
 """
 from __future__ import annotations
@@ -111,87 +113,64 @@ def measured_traffic(which, rows_per_launch, k_mean, d):
 
 
 def cpu_baseline(args, model_kind=0, loss_kind=2):
-    """The oracle (kind "port") on a bounded sample of the same workload: every worker thread owns a
-    model and one minibatch worth of users of the same generator and runs one epoch of it; fit time
-    only.  Workers are independent (≙ the reference's rayon workers on their own partitions,
-    sequence_model.rs:99-102, without its shared-parameter traffic or rendezvous), so the aggregate
-    is an upper bound for a `cores`-thread CPU run; the single-thread figure is reported beside it."""
-    import threading
-
+    """The oracle (kind "port") in the REFERENCE'S PARALLEL SHAPE on the host (sequence_model.rs:90-102): the subsequences of a
+    bounded sample of the same generator are cut into one partition per worker thread, every worker runs on ONE shared
+    parameter set (Arc<HogwildParameter>, lstm.rs:175-181) and takes one optimiser step per subsequence (the reference's
+    schedule, :111-169).  Workers = every host core (the reference's default, lstm.rs:68); both of its parallelism modes are
+    timed — Asynchronous = Hogwild, no locks (mod.rs:36-38), and Synchronous = rendezvous + one update at a time
+    (mod.rs:39-40, sequence_model.rs:163-166) — beside the single-thread figure (num_threads(1), lstm.rs:462).  Each leg is
+    bounded by --cpu-seconds of wall time; `value` is the faster all-core mode.  Thread timing orders the updates: a throughput
+    baseline, not a parity run."""
     from oracle.oracle import OracleModel
 
     users = min(args.cpu_users, args.users)
-    workers = max(1, min(os.cpu_count() or 1, args.cpu_threads))
-
-    def prepare(seed):
-        ptr, items = synthetic_csr(users, args.items, args.max_len, seed=seed)
-        hp = make_hp(args, 1, 0, model_kind, loss_kind, args.items, epochs=1, batch=min(args.batch_sequences, users))
-        m = OracleModel(hp)
-        plan = m.fit_begin(ptr, items)
-        nmb = plan.epoch_prepare()
-        return m, plan, nmb, sum(plan.minibatch_rows(mb) for mb in range(nmb))
-
-    def run(job):
-        _m, plan, nmb, _rows = job
-        for mb in range(nmb):
-            plan.step(mb)  # ctypes releases the GIL for the duration of the C call
-
-    one = prepare(43)
-    t0 = time.perf_counter()
-    run(one)
-    dt1 = time.perf_counter() - t0
-    single = one[3] / dt1
-    out = {"value": single, "unit": "interactions/s", "cores": 1, "kind": "port",
-           "sample": f"{users} users of the same generator ({one[3]} interactions, {one[2]} minibatch(es)), "
-                     f"{args.model}+{args.loss} dim {args.dim}, 1 epoch, single-thread C oracle, {dt1:.1f} s",
-           "single_thread_value": single, "host_cores_available": os.cpu_count()}
-    del one
-    if workers > 1:
-        jobs = [None] * workers
-        ready, go = threading.Barrier(workers + 1), threading.Barrier(workers + 1)
-
-        def worker(w):
-            jobs[w] = prepare(100 + w)  # model initialisation also runs outside the GIL
-            ready.wait()
-            go.wait()
-            run(jobs[w])
-
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(workers)]
-        for t in threads:
-            t.start()
-        ready.wait()
-        t0 = time.perf_counter()
-        go.wait()
-        for t in threads:
-            t.join()
-        dtn = time.perf_counter() - t0
-        rows = sum(j[3] for j in jobs)
-        out.update({"value": rows / dtn, "cores": workers,
-                    "sample": f"{workers} independent worker threads x {users} users of the same generator "
-                              f"({rows} interactions), {args.model}+{args.loss} dim {args.dim}, 1 epoch each, C oracle, {dtn:.1f} s wall "
-                              f"(single thread: {single:.0f} interactions/s)"})
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, args.cpu_threads if args.cpu_threads > 0 else cores))
+    ptr, items = synthetic_csr(users, args.items, args.max_len, seed=43)
+    hp = make_hp(args, 1, 0, model_kind, loss_kind, args.items, epochs=1_000_000, batch=1)  # bounded by time, not by epochs
+    m = OracleModel(hp)  # ONE model: the three legs continue training the same shared parameters
+    legs = {}
+    for name, w, sync in (("single_thread", 1, True), ("all_cores_hogwild", workers, False), ("all_cores_synchronous", workers, True)):
+        rows, secs, _loss = m.fit_threads(ptr, items, w, sync, args.cpu_seconds)
+        legs[name] = {"interactions_per_s": rows / secs, "interactions": rows, "seconds": secs, "workers": w}
+    best = max(("all_cores_hogwild", "all_cores_synchronous"), key=lambda k: legs[k]["interactions_per_s"])
+    out = {"value": legs[best]["interactions_per_s"], "unit": "interactions/s", "cores": workers, "kind": "port", "mode": best,
+           "sample": f"{users} users of the same generator, {args.model}+{args.loss} dim {args.dim}, {args.items} items; {workers} worker threads on "
+                     f"ONE shared parameter set, one partition each (sequence_model.rs:90-102), one optimiser step per subsequence; "
+                     f"each leg bounded by {args.cpu_seconds:.0f} s of wall time; C oracle",
+           "single_thread_value": legs["single_thread"]["interactions_per_s"], "host_cores_available": cores, "legs": legs}
+    del m
     if workload_label(args, 1).startswith("BASELINE.json configs[2]"):
-        out["movielens_batch1"] = cpu_movielens_batch1()
+        out["movielens_batch1"] = cpu_movielens_batch1(workers)
     return out
 
 
-def cpu_movielens_batch1():
+def cpu_movielens_batch1(workers):
     """The CPU leg of `test_mrr.batch_sequences_1`: BASELINE.json configs[1] (MovieLens-100K, LSTM Normal, dim 32, WARP,
-    Adagrad, 10 epochs) at one subsequence per optimiser step — the reference's own schedule, which has no parallelism
-    inside a step — on ONE host core through the C oracle (fit time only)."""
+    Adagrad, 10 epochs) at one subsequence per optimiser step — the reference's own schedule — through the C oracle: on ONE
+    host core (the sequential contract run, whose result the GPU reproduces bit for bit), and in the reference's parallel shape
+    on every core (one shared parameter set, Hogwild and synchronised; fit time only)."""
     from helpers import movielens_protocol
     from oracle.oracle import OracleModel
     from sbr_rs_amd._abi import make_hparams
 
     data, train, _test, rng = movielens_protocol()
-    hp = make_hparams(data.num_items(), 128, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, 1)
-    m = OracleModel(hp)
+    mk = lambda: OracleModel(make_hparams(data.num_items(), 128, 32, 0.16, 0.0004, 0, 2, 0, 1, rng.state_seed(), 10, 1, 0, 1))
+    m = mk()
     t0 = time.perf_counter()
     loss = m.fit(train.user_pointers, train.item_ids)
     dt = time.perf_counter() - t0
-    return {"fit_seconds": dt, "fit_loss": loss, "cores": 1, "kind": "port",
-            "train_interactions_per_s": 10 * len(train.item_ids) / dt,
-            "config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, max_sequence_length 128, batch_sequences 1"}
+    out = {"fit_seconds": dt, "fit_loss": loss, "cores": 1, "kind": "port",
+           "train_interactions_per_s": 10 * len(train.item_ids) / dt,
+           "config": "MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad, 10 epochs, max_sequence_length 128, batch_sequences 1"}
+    w = min(workers, 256)
+    for name, sync in (("all_cores_hogwild", False), ("all_cores_synchronous", True)):
+        try:
+            rows, secs, lv = mk().fit_threads(train.user_pointers, train.item_ids, w, sync, 0.0)
+            out[name] = {"fit_seconds": secs, "fit_loss": lv, "workers": w, "interactions": rows}
+        except Exception as e:  # fewer subsequences than workers: the reference panics there (chunks_mut(0))
+            out[name] = {"error": repr(e), "workers": w}
+    return out
 
 
 def movielens_mrr():
@@ -342,6 +321,25 @@ def simulate_world(args, model_kind, loss_kind):
     }
 
 
+def self_launch(n: int) -> int:
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 with a free
+    port (the user-sharded step needs one process per GPU, sequence_model.rs:90-102 ≙ DESIGN.md §8).  The ranks inherit stdout,
+    so rank 0's single JSON line is this process's last line too; returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and the peer mappings need it on this stack
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,10 +360,11 @@ def main():
     ap.add_argument("--parallelism", choices=["sync", "async"], default="sync",
                     help="multi-GPU step: sync = Parallelism::Synchronous (the reference default); async = the "
                          "staleness-one pipeline (Parallelism::Asynchronous): compute k+1 under the exchange of step k")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="worker threads of the CPU baseline (capped at the host's cores; each owns a ~1 GB model; "
-                         "on the 256-core GPU host 16 threads gave 416 K interactions/s, 32 threads 322 K)")
-    ap.add_argument("--cpu-users", type=int, default=4096, help="users in the CPU-baseline sample (one CPU minibatch)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="worker threads of the CPU baseline (0 = every host core, the reference's default num_threads, lstm.rs:68); "
+                         "all of them share ONE model")
+    ap.add_argument("--cpu-users", type=int, default=100_000, help="users in the CPU-baseline sample (capped at --users)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-time bound of each of the three CPU-baseline legs")
     ap.add_argument("--standalone-steps", type=int, default=6,
                     help="extra untimed steps with stream overlap disabled, for standalone per-kernel times (0 = skip)")
     ap.add_argument("--cold-items", type=int, default=4_000_000,
@@ -397,9 +396,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.simulate_world <= 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's launcher would
+        # (python -m torch.distributed.run, one rank per GPU); rank 0's JSON line stays the last line of stdout
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
     multi = world > 1 or args.simulate_world > 1
     if args.users is None:
@@ -502,6 +503,8 @@ def main():
     elapsed = t1 - t0
     if dist is not None:
         rdev = "cpu" if args.backend == "gloo" else "cuda"
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, 1e3 * elapsed / max(args.steps, 1))
         t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -511,6 +514,7 @@ def main():
         dist.barrier()
     else:
         rows_total = rows_timed
+        per_rank = [1e3 * elapsed / max(args.steps, 1)]
     timing = model.timing_read()
     ex1, neg1 = plan.counters()
     sparse_entries, sparse_unique = plan.sparse_stats() if hasattr(plan, "sparse_stats") else (0, 0)
@@ -594,6 +598,18 @@ def main():
             except Exception as e:
                 small["error"] = repr(e)
 
+    crc_ranks = None
+    if args.param_crc:  # every rank's replica (a partitioned table is read whole through the rank's mapping)
+        import zlib
+
+        from sbr_rs_amd._abi import Param
+
+        names = ["ITEM_EMBEDDING", "ITEM_EMBEDDING_ACC", "ITEM_BIAS", "ITEM_BIAS_ACC"] + (["LSTM_W", "LSTM_W_ACC", "LSTM_B"] if model_kind != 2 else ["EWMA_ALPHA"])
+        own = {n: zlib.crc32(model.get_param(getattr(Param, n)).tobytes()) for n in names}
+        crc_ranks = [own]
+        if dist is not None and world > 1:
+            crc_ranks = [None] * world
+            dist.all_gather_object(crc_ranks, own)
     if rank == 0:
         d, ng = args.dim, {0: 4, 1: 3, 2: 0}[model_kind]
         # negatives actually scored per interaction over the timed steps (all devices)
@@ -685,6 +701,10 @@ def main():
                        "item_table": "partitioned across the ranks (one copy)" if args.partition_table else "replicated",
                        "parallelism": (f"user-sharded dp{world}, {'staleness-one pipelined (Asynchronous)' if args.parallelism == 'async' else 'synchronous'} "
                                        f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
+            "process_group_ranks": dist.get_world_size() if dist is not None else 1,
+            "rccl_ranks": dist.get_world_size() if dist is not None and args.backend == "nccl" else 0,
+            "collective_backend": (args.backend if args.backend == "gloo" else "nccl (RCCL)") if dist is not None else None,
+            "ms_per_step_per_rank": per_rank,
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
             "roofline": roofline, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
@@ -701,13 +721,10 @@ def main():
                                                 "batch_sequences_per_gpu": qn["batch_sequences"], "criterion": qn["criterion"], "table": qn["table"]}
         if small is not None:
             out["small_steps"] = small
-        if args.param_crc:
-            import zlib
-
-            from sbr_rs_amd._abi import Param
-
-            names = ["ITEM_EMBEDDING", "ITEM_EMBEDDING_ACC", "ITEM_BIAS", "ITEM_BIAS_ACC"] + (["LSTM_W", "LSTM_W_ACC", "LSTM_B"] if ng else ["EWMA_ALPHA"])
-            out["param_crc"] = {n: zlib.crc32(model.get_param(getattr(Param, n)).tobytes()) for n in names}
+        if crc_ranks:
+            out["param_crc"] = crc_ranks[0]
+            out["param_crc_ranks_equal"] = all(c == crc_ranks[0] for c in crc_ranks)
+            out["param_crc_ranks"] = len(crc_ranks)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, model_kind, loss_kind)

@@ -482,6 +482,15 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
     /// of more than two items exists (sequence_model.rs:86-88).
     Result<float, FittingError> fit(const data::CompressedInteractions& interactions) { return replicas_->fit(interactions); }
 
+    /// The number the reference's `fit` would have returned for the last `fit` call: sequence_model.rs:157 reads the
+    /// loss node BEFORE :160 runs its forward pass, so every subsequence contributes what the worker's previous
+    /// subsequence of the same length left there.  `fit` itself returns the true mean loss.
+    float last_fit_lagged_loss() const {
+        float v = 0.0f;
+        check(sbr_model_last_fit_lagged_loss(replicas_->primary(), &v), "sbr_model_last_fit_lagged_loss");
+        return v;
+    }
+
     Result<ImplicitUser, PredictionError> user_representation(const std::vector<ItemId>& item_ids) const override {
         const std::vector<std::uint32_t> ids = narrow(item_ids);
         ImplicitUser user{std::vector<float>(replicas_->hparams().embedding_dim)};

@@ -103,7 +103,8 @@ typedef enum sbr_debug_buffer {
     SBR_DBG_DENSE_GRAD = 6, /* f32 dense grad block: LSTM [2*dim+1][gates*dim] (last row = bias) / EWMA [dim] */
     SBR_DBG_IN_IDX = 7,     /* u32 [R] */
     SBR_DBG_OUT_IDX = 8,    /* u32 [R] */
-    SBR_DBG_TRIES = 9       /* u32 [R] number of negatives scored (k of BASELINE.md §4) */
+    SBR_DBG_TRIES = 9,      /* u32 [R] number of negatives scored (k of BASELINE.md §4) */
+    SBR_DBG_DZ = 10         /* f32 [R][gates*dim] gradient w.r.t. the gate pre-activations (LSTM; column blocks as SBR_PARAM_LSTM_W) */
 } sbr_debug_buffer;
 
 /* ≙ Hyperparameters::build (lstm.rs:197-201, ewma.rs:201-205): allocates device parameters and
@@ -136,6 +137,14 @@ sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p);
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
 sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows);
 sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples);
+/* The number the reference's `fit` returns.  sequence_model.rs:157 adds `loss.value()` of the loss node BEFORE :160 runs its
+ * forward pass, so every subsequence contributes what the worker's previous subsequence OF THE SAME LENGTH left in that node
+ * (0 the first time), accumulated in f32; `fit` returns the sum over the workers of accumulator / (1 + examples) (:173-177).
+ * sbr_fit_end / sbr_model_fit report the true mean instead; this is the lagged figure for a caller that must return what the
+ * crate returns.  sbr_fit_end_lagged: THIS device's term (single device: the whole figure; multi-device hosts add the terms in
+ * device order in f32).  sbr_model_last_fit_lagged_loss: the whole figure of the last completed sbr_model_fit / sbr_group_fit. */
+sbr_status sbr_fit_end_lagged(sbr_fit_plan* p, float* out_term);
+sbr_status sbr_model_last_fit_lagged_loss(const sbr_model* m, float* out_loss);
 /* Running totals of the plan, all devices: loss terms processed and negatives scored by the WARP
  * search (the k of BASELINE.md §4's bytes-per-interaction formula). */
 sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored);
@@ -262,6 +271,9 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
 sbr_status sbr_model_param_count(const sbr_model* m, int32_t which, uint64_t* out_count);
 sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uint64_t count);
 sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count);
+/* Selected rows of an item-table block — SBR_PARAM_ITEM_EMBEDDING / _ACC / _M: host_out [n][embedding_dim]; SBR_PARAM_ITEM_BIAS /
+ * _ACC / _M: host_out [n] — without moving the whole table (1e7 items x 256 is 10 GB per block). */
+sbr_status sbr_model_get_param_rows(sbr_model* m, int32_t which, const uint32_t* rows, uint64_t n, float* host_out);
 sbr_status sbr_model_get_epoch(const sbr_model* m, uint64_t* out_global_epoch);
 /* Optimiser steps taken so far (Adam's bias-correction counter) and the epoch counter that keys the
  * negative draws: together with the parameter blocks this is the complete resumable state. */

@@ -42,6 +42,7 @@ def lib():
         L.orc_model_param_count.argtypes = [vp, C.c_int, u64p]
         L.orc_model_get_param.argtypes = [vp, C.c_int, vp, C.c_uint64]
         L.orc_model_set_param.argtypes = [vp, C.c_int, vp, C.c_uint64]
+        L.orc_model_get_param_rows.argtypes = [vp, C.c_int, vp, C.c_uint64, vp]
         L.orc_model_get_epoch.argtypes = [vp]
         L.orc_model_get_epoch.restype = C.c_uint64
         L.orc_model_get_opt_steps.argtypes = [vp]
@@ -68,6 +69,13 @@ def lib():
         L.orc_fit_epoch_async.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
         L.orc_fit_end_lagged.argtypes = [vp, fp]
+        L.orc_model_last_fit_lagged_loss.argtypes = [vp, fp]
+        L.orc_fit_step_local_sample.argtypes = [vp, C.c_int, C.c_uint64, vp, C.c_uint32, vp, u32p, vp]
+        L.orc_row_step.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, fp, fp]
+        L.orc_dense_chain.argtypes = [vp, vp, C.c_uint64]
+        L.orc_dense_chain.restype = C.c_float
+        L.orc_model_apply_dense.argtypes = [vp, vp, C.c_uint64]
+        L.orc_fit_threads.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, C.c_double, u64p, C.POINTER(C.c_double), fp]
         L.orc_model_padding_is_zero.argtypes = [vp]
         L.orc_model_set_reference_order.argtypes = [vp, C.c_int]
         L.orc_model_get_rng.argtypes = [vp, vp]
@@ -155,6 +163,20 @@ class OraclePlan:
         _check(lib().orc_fit_export_local(self._h, device, _ptr(out)))
         return out
 
+    def step_local_sample(self, mb: int, sel_b, device: int = 0):
+        """Forward + negative sampling + loss + BPTT of ONLY the sequences `sel_b` (ascending indices into the full
+        minibatch's packed order) with the position counters they have in the full minibatch.  Returns (rows, off): per
+        compact packed row of the sample the packed row of the same (step, sequence) in the full minibatch, and the full
+        minibatch's off table (rows before step t; T entries).  debug_fetch then reads the sample's arrays.  For parity at
+        sizes the oracle cannot run whole."""
+        sel = np.ascontiguousarray(sel_b, dtype=np.uint32)
+        T = int(self.model.hp.max_sequence_length)
+        rows = np.zeros(sel.size * (T - 1), dtype=np.uint32)
+        off = np.zeros(T, dtype=np.uint64)
+        n = C.c_uint32()
+        _check(lib().orc_fit_step_local_sample(self._h, device, mb, _ptr(sel), sel.size, _ptr(rows), C.byref(n), _ptr(off)))
+        return rows[: n.value].copy(), off
+
     def step_apply(self, all_blocks: np.ndarray):
         all_blocks = np.ascontiguousarray(all_blocks, dtype=np.uint8)
         _check(lib().orc_fit_step_apply(self._h, _ptr(all_blocks)))
@@ -208,6 +230,8 @@ class OraclePlan:
             out = np.zeros((rows, d), dtype=np.float32)
         elif which == 6:
             out = np.zeros(self.model.dense_count(), dtype=np.float32)
+        elif which == 10:
+            out = np.zeros((rows, {0: 4, 1: 3, 2: 0}[int(self.model.hp.model)] * d), dtype=np.float32)
         else:
             out = np.zeros(rows, dtype=_DBG_DTYPE.get(which, np.float32))
         _check(lib().orc_fit_debug_fetch(self._h, device, which, _ptr(out), out.nbytes))
@@ -223,6 +247,15 @@ class OraclePlan:
             self.close()
         except Exception:
             pass
+
+
+def dense_chain(a, dz) -> np.float32:
+    """One element of the dense gradient from its operand columns over all packed rows, contract order (a = None: bias row)."""
+    dz = np.ascontiguousarray(dz, dtype=np.float32)
+    if a is not None:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.size == dz.size
+    return np.float32(lib().orc_dense_chain(_ptr(a) if a is not None else None, _ptr(dz), dz.size))
 
 
 class OracleModel:
@@ -247,6 +280,14 @@ class OracleModel:
     def get_param(self, which: int) -> np.ndarray:
         out = np.zeros(self.param_count(which), dtype=np.float32)
         _check(lib().orc_model_get_param(self._h, int(which), _ptr(out), out.size))
+        return out
+
+    def get_param_rows(self, which: int, rows) -> np.ndarray:
+        """Selected rows of an item-table block ([n, embedding_dim]; biases: [n]) without copying the whole table."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        table = self.param_count(which) != int(self.hp.num_items)
+        out = np.zeros((rows.size, self.dim) if table else rows.size, dtype=np.float32)
+        _check(lib().orc_model_get_param_rows(self._h, int(which), _ptr(rows), rows.size, _ptr(out)))
         return out
 
     def set_param(self, which: int, values: np.ndarray):
@@ -282,6 +323,41 @@ class OracleModel:
         loss = C.c_float()
         _check(lib().orc_model_fit(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
         return loss.value
+
+    def row_step(self, vecs, scale, has_bias, w, acc, b, bacc):
+        """One item-table row's optimiser step from an explicit, ordered entry list (contract order of the per-row reduction,
+        then Adagrad with this model's hyper-parameters): returns (w, acc, b, bacc) after the step."""
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        scale = np.ascontiguousarray(scale, dtype=np.float32)
+        hb = np.ascontiguousarray(has_bias, dtype=np.uint8)
+        w = np.array(w, dtype=np.float32, copy=True)
+        acc = np.array(acc, dtype=np.float32, copy=True)
+        bb, ba = C.c_float(float(b)), C.c_float(float(bacc))
+        assert vecs.shape == (scale.size, self.storage_dim) and w.size == acc.size == self.storage_dim
+        _check(lib().orc_row_step(self._h, scale.size, _ptr(vecs), _ptr(scale), _ptr(hb), _ptr(w), _ptr(acc), C.byref(bb), C.byref(ba)))
+        return w, acc, np.float32(bb.value), np.float32(ba.value)
+
+    def apply_dense(self, dense):
+        """The dense half of one optimiser step from an explicit dense-gradient block."""
+        dense = np.ascontiguousarray(dense, dtype=np.float32)
+        _check(lib().orc_model_apply_dense(self._h, _ptr(dense), dense.size))
+
+    def fit_threads(self, user_ptr, item_ids, workers: int, synchronous: bool, max_seconds: float = 0.0):
+        """The reference's parallel shape (sequence_model.rs:90-102) for the timed CPU baseline: `workers` threads on THIS
+        model's one shared parameter set, one partition each; Hogwild (no locks) or barrier-synchronised optimiser steps.
+        Not deterministic.  Returns (interactions processed, wall seconds, loss)."""
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        rows, secs, loss = C.c_uint64(), C.c_double(), C.c_float()
+        _check(lib().orc_fit_threads(self._h, _ptr(up), _ptr(it), len(up) - 1, int(workers), 1 if synchronous else 0,
+                                     float(max_seconds), C.byref(rows), C.byref(secs), C.byref(loss)))
+        return rows.value, secs.value, loss.value
+
+    def last_fit_lagged_loss(self) -> float:
+        """The figure the reference's `fit` would have returned for the last `fit` call."""
+        v = C.c_float()
+        _check(lib().orc_model_last_fit_lagged_loss(self._h, C.byref(v)))
+        return v.value
 
     def fit_begin(self, user_ptr, item_ids) -> OraclePlan:
         return OraclePlan(self, user_ptr, item_ids)

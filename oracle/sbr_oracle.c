@@ -1,6 +1,7 @@
 /* sbr_oracle.c — CPU ORACLE (test infrastructure, NOT the product).
  *
- * A plain-C, single-threaded restatement of the sbr-rs sequence-recommender hot path, used only
+ * A plain-C restatement of the sbr-rs sequence-recommender hot path (sequential; one threaded mode for the timed CPU
+ * baseline, orc_fit_threads), used only
  * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for the HIP
  * engine (libsbr_hip.so).  Nothing under sbr_rs_amd/ links, imports or executes this file.
  *
@@ -56,6 +57,7 @@ typedef struct orc_model {
      * batch_sequences must be 1 (the reference's schedule).  Used to measure whether the substitutions move test MRR
      * (tools/mrr_stream_sweep.py --reference-order). */
     int reference_order;
+    float last_lagged_loss; /* orc_fit_end_lagged of the last orc_model_fit */
 } orc_model;
 
 typedef struct orc_local { /* one device's view of one minibatch */
@@ -84,10 +86,10 @@ typedef struct orc_plan {
     orc_local* loc; /* [ndev] */
     double loss_sum;
     uint64_t examples;
-    double loss_dev[16];    /* per partition (sequence_model.rs:173-177 sums the partitions' ratios) */
-    uint64_t examples_dev[16];
+    double* loss_dev;       /* [ndev] per partition (sequence_model.rs:173-177 sums the partitions' ratios) */
+    uint64_t* examples_dev;
     /* the figure the reference actually returns: see orc_lagged_loss_update */
-    float lagged_dev[16];
+    float* lagged_dev;
     float* lagged_node;     /* [ndev][max_sequence_length]: value left in the loss node of each length */
     uint64_t epochs_prepared;
     uint64_t epoch_key_epoch;
@@ -221,6 +223,19 @@ int orc_model_get_param(orc_model* m, int which, float* out, uint64_t count) {
     float* p = orc_param_ptr(m, which, &n, &kind);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < n; ++i) out[i] = p[orc_param_stored_index(m, kind, n, i)];
+    return SBR_OK;
+}
+/* selected rows of an item-table block: embeddings / their optimiser state [n][embedding_dim], biases [n] */
+int orc_model_get_param_rows(orc_model* m, int which, const uint32_t* rows, uint64_t n, float* out) {
+    uint64_t cnt; int kind;
+    float* p = orc_param_ptr(m, which, &cnt, &kind);
+    uint64_t I = m->hp.num_items, d = (uint64_t)m->d, dl = (uint64_t)m->dl;
+    if (!p || !cnt || (kind != 1 && cnt != I)) return SBR_ERR_INVALID_ARGUMENT;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (rows[i] >= I) return SBR_ERR_INVALID_ARGUMENT;
+        if (kind == 1) memcpy(out + i * dl, p + (uint64_t)rows[i] * d, dl * 4);
+        else out[i] = p[rows[i]];
+    }
     return SBR_OK;
 }
 int orc_model_set_param(orc_model* m, int which, const float* in, uint64_t count) {
@@ -404,6 +419,9 @@ int orc_fit_begin(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
     p->loc = (orc_local*)calloc(ndev, sizeof(orc_local));
     for (int q = 0; q < ndev; ++q) orc_local_alloc(&p->loc[q], p->Rmax, (int)T, m->d, m->ng);
     p->lagged_node = (float*)calloc((size_t)ndev * T, sizeof(float));
+    p->loss_dev = (double*)calloc(ndev, sizeof(double));
+    p->examples_dev = (uint64_t*)calloc(ndev, sizeof(uint64_t));
+    p->lagged_dev = (float*)calloc(ndev, sizeof(float));
     *out = p;
     return SBR_OK;
 }
@@ -412,7 +430,7 @@ void orc_fit_plan_destroy(orc_plan* p) {
     if (!p) return;
     for (int q = 0; q < p->ndev; ++q) orc_local_free(&p->loc[q]);
     free(p->loc); free(p->seq_start); free(p->seq_len); free(p->part_rng); free(p->fit_seed); free(p->items);
-    free(p->lagged_node);
+    free(p->lagged_node); free(p->loss_dev); free(p->examples_dev); free(p->lagged_dev);
     free(p);
 }
 
@@ -468,6 +486,60 @@ static void orc_pack(orc_plan* p, int q, uint64_t mb, orc_local* L) {
         }
     }
     free(order); free(cnt); free(pos);
+}
+
+/* SAMPLED parity at sizes the oracle cannot run whole (tests/test_parity_gpu.py::test_bench_regime_*): pack only the
+ * sequences sel_b[0..nsel) — indices b of the FULL minibatch's packed order (length descending, stable), ascending — with the
+ * position counters `ctr` they have in the full minibatch, so that forward, negative draws, loss and BPTT of each of them are
+ * exactly what the full step computes for it (a sequence's rows depend on the parameters and on its own items only).
+ * out_full_rows[compact row] = the packed row off_full[t] + b of the same (t, sequence) in the full minibatch. */
+static int orc_pack_sample(orc_plan* p, int q, uint64_t mb, const uint32_t* sel_b, uint32_t nsel, orc_local* L, uint32_t* out_full_rows,
+                           uint64_t* out_off_full /* [T] rows of the full minibatch before step t; may be NULL */) {
+    uint64_t B = p->m->hp.batch_sequences, T = p->m->hp.max_sequence_length;
+    uint64_t p0 = mb * B, p1 = p0 + B;
+    if (p1 > p->part_len) p1 = p->part_len;
+    int nb = (int)(p1 - p0);
+    const uint64_t* st = p->seq_start + (uint64_t)q * p->part_len;
+    const uint32_t* ln = p->seq_len + (uint64_t)q * p->part_len;
+    for (uint32_t j = 0; j < nsel; ++j)
+        if (sel_b[j] >= (uint32_t)nb || (j && sel_b[j] <= sel_b[j - 1])) return SBR_ERR_INVALID_ARGUMENT;
+    int* order = (int*)malloc(sizeof(int) * (nb ? nb : 1));
+    int* cnt = (int*)calloc(T + 2, sizeof(int));
+    for (int i = 0; i < nb; ++i) cnt[ln[p0 + i]]++;
+    int* pos = (int*)calloc(T + 2, sizeof(int));
+    int acc = 0;
+    for (int l = (int)T; l >= 0; --l) { pos[l] = acc; acc += cnt[l]; }
+    for (int i = 0; i < nb; ++i) order[pos[ln[p0 + i]]++] = i;
+    /* full minibatch: off_full[t] = rows before step t = sum over steps < t of the sequences alive there */
+    uint64_t* off_full = (uint64_t*)calloc(T + 1, sizeof(uint64_t));
+    for (uint64_t t = 0; t + 1 < T; ++t) {
+        uint64_t alive = 0; /* sequences with len - 1 > t: lengths are sorted descending, count by the histogram */
+        for (uint64_t l = t + 2; l <= T; ++l) alive += (uint64_t)cnt[l];
+        off_full[t + 1] = off_full[t] + alive;
+    }
+    int Tm = nsel ? (int)ln[p0 + order[sel_b[0]]] - 1 : 0;
+    L->B = (int)nsel; L->Tm = Tm;
+    L->off[0] = 0;
+    for (int t = 0; t < Tm; ++t) {
+        int bt = 0;
+        for (uint32_t j = 0; j < nsel; ++j) if ((int)ln[p0 + order[sel_b[j]]] - 1 > t) bt = (int)j + 1; else break;
+        L->off[t + 1] = L->off[t] + bt;
+    }
+    L->R = L->off[Tm];
+    for (uint32_t j = 0; j < nsel; ++j) {
+        uint64_t pp = p0 + order[sel_b[j]];
+        int n = (int)ln[pp];
+        for (int t = 0; t < n - 1; ++t) {
+            int r = L->off[t] + (int)j;
+            L->in_idx[r] = p->items[st[pp] + t];
+            L->out_idx[r] = p->items[st[pp] + t + 1];
+            L->ctr[r] = (uint32_t)(pp * T + (uint64_t)t);
+            out_full_rows[r] = (uint32_t)(off_full[t] + sel_b[j]);
+        }
+    }
+    if (out_off_full) memcpy(out_off_full, off_full, T * sizeof(uint64_t));
+    free(order); free(cnt); free(pos); free(off_full);
+    return SBR_OK;
 }
 
 int orc_fit_minibatch_rows(orc_plan* p, int q, uint64_t mb, uint64_t* out_rows) {
@@ -737,6 +809,75 @@ int orc_fit_step_local(orc_plan* p, int q, uint64_t mb) {
     return SBR_OK;
 }
 
+static uint64_t orc_ndense(const orc_model* m);
+int orc_fit_step_local_sample(orc_plan* p, int q, uint64_t mb, const uint32_t* sel_b, uint32_t nsel, uint32_t* out_full_rows,
+                              uint32_t* out_nrows, uint64_t* out_off_full) {
+    if (!p || !sel_b || !out_full_rows || !out_nrows || nsel == 0) return SBR_ERR_INVALID_ARGUMENT;
+    orc_local* L = &p->loc[q];
+    int st = orc_pack_sample(p, q, mb, sel_b, nsel, L, out_full_rows, out_off_full);
+    if (st != SBR_OK) return st;
+    orc_forward(p->m, L);
+    orc_score(p->m, L, orc_epoch_key_of(p->fit_seed[q], p->epoch_key_epoch), &p->part_rng[q]);
+    orc_backward(p->m, L); /* L->dense is the sample's own dense gradient, not the minibatch's */
+    *out_nrows = (uint32_t)L->R;
+    return SBR_OK;
+}
+
+/* One item-table row's optimiser step from an explicit entry list, in the contract's order (orc_reduce_row + orc_row_update):
+ * entry e contributes scale[e] * vecs[e][0..d) (input row: scale 1 and dX; target row: -coef and h; negative row: +coef and h)
+ * and, if has_bias[e], scale[e] to the bias gradient; entries in (packed row, kind) order; chunks of ORC_SEG_CHUNK.  Updates
+ * w / acc / *b / *bacc in place with the model's hyper-parameters (Adagrad).  For the sampled update check at bench size. */
+int orc_row_step(orc_model* m, uint32_t n, const float* vecs, const float* scale, const uint8_t* has_bias, float* w, float* acc,
+                 float* b, float* bacc) {
+    if (!m || n == 0 || m->hp.optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_INVALID_ARGUMENT;
+    int d = m->d;
+    float* g = (float*)malloc(sizeof(float) * d);
+    float* part = (float*)malloc(sizeof(float) * d);
+    float gb = 0.0f; int has_b = 0, first_chunk = 1;
+    for (uint32_t c0 = 0; c0 < n; c0 += ORC_SEG_CHUNK) {
+        uint32_t c1 = c0 + ORC_SEG_CHUNK < n ? c0 + ORC_SEG_CHUNK : n;
+        float pb = 0.0f; int phb = 0, first = 1;
+        for (uint32_t e = c0; e < c1; ++e) {
+            const float* srcv = vecs + (size_t)e * d;
+            float sc = scale[e];
+            if (first) { for (int k = 0; k < d; ++k) part[k] = sc * srcv[k]; first = 0; }
+            else for (int k = 0; k < d; ++k) part[k] = part[k] + sc * srcv[k];
+            if (has_bias[e]) { pb = phb ? pb + sc : sc; phb = 1; }
+        }
+        if (first_chunk) { for (int k = 0; k < d; ++k) g[k] = part[k]; first_chunk = 0; }
+        else for (int k = 0; k < d; ++k) g[k] = g[k] + part[k];
+        if (phb) { gb = has_b ? gb + pb : pb; has_b = 1; }
+    }
+    float dummy = 0.0f;
+    for (int k = 0; k < d; ++k) orc_opt(m, &w[k], &acc[k], &dummy, g[k]);
+    if (has_b) orc_opt(m, b, bacc, &dummy, gb);
+    free(g); free(part);
+    return SBR_OK;
+}
+
+/* One element of the dense gradient from its two operand columns over ALL packed rows, in the contract's order (orc_backward):
+ * rows in chunks of ORC_DW_CHUNK_ROWS, inside a chunk a row-ascending fma chain from 0 (a == NULL: the bias row, a plain add
+ * chain), chunk partials added in chunk order. */
+float orc_dense_chain(const float* a, const float* dz, uint64_t rows) {
+    float total = 0.0f;
+    for (uint64_t r0 = 0, c = 0; r0 < rows; r0 += ORC_DW_CHUNK_ROWS, ++c) {
+        uint64_t r1 = r0 + ORC_DW_CHUNK_ROWS < rows ? r0 + ORC_DW_CHUNK_ROWS : rows;
+        float part = 0.0f;
+        if (a) for (uint64_t r = r0; r < r1; ++r) part = fmaf(a[r], dz[r], part);
+        else for (uint64_t r = r0; r < r1; ++r) part = part + dz[r];
+        total = c == 0 ? part : total + part;
+    }
+    return total;
+}
+
+/* The dense half of an optimiser step from an explicit gradient block (orc_begin_optimizer_step + orc_dense_update) */
+int orc_model_apply_dense(orc_model* m, const float* dense, uint64_t count) {
+    if (!m || !dense || count != orc_ndense(m)) return SBR_ERR_INVALID_ARGUMENT;
+    orc_begin_optimizer_step(m);
+    orc_dense_update(m, dense);
+    return SBR_OK;
+}
+
 /* ---- exchange block: what one device contributes to an optimiser step --------------------- */
 /* layout (all 4-byte words unless noted), Rmax = batch_sequences*(T-1):
  *   [0]      u32 R
@@ -812,26 +953,18 @@ static void orc_reduce_row(const orc_entry* ent, uint64_t i, uint64_t j, int d, 
  *  with +g*h — sorted by (row, device, packed row, kind); duplicates added in that order; one
  *  Adagrad update (with L2) per touched row, also for rows whose summed data-gradient is zero
  *  (SURVEY App. A-14); biases likewise for target/negative rows. */
-static int orc_apply_own_block(orc_plan* p, const void* block, int q) {
-    /* one optimiser step from ONE device's block: its dense gradient, then its sparse entries per row */
-    orc_model* m = p->m;
+/* one optimiser step from ONE worker's gradients: its dense gradient, then its sparse entries per row */
+static void orc_apply_gradients(orc_model* m, uint32_t R, const uint32_t* in_idx, const uint32_t* out_idx, const uint32_t* neg,
+                                const orc_entry_src* es, const float* dense) {
     int d = m->d;
-    uint64_t Rmax = (uint64_t)p->Rmax, nd = orc_ndense(m);
+    uint64_t nd = orc_ndense(m);
     orc_begin_optimizer_step(m);
-    const uint32_t* w = (const uint32_t*)block;
-    const float* dense = (const float*)(w + 8 + 4 * Rmax + 2 * Rmax * (uint64_t)d);
     float* dg = (float*)malloc(nd * 4);
     memcpy(dg, dense, nd * 4);
-    double ls; uint64_t ex;
-    memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
-    p->loss_sum += ls; p->examples += ex;
-    p->loss_dev[q] += ls; p->examples_dev[q] += ex;
     orc_dense_update(m, dg);
     free(dg);
-    uint32_t R = w[0];
     uint64_t ne = 3ull * R;
     orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (ne ? ne : 1));
-    const uint32_t* in_idx = w + 8; const uint32_t* out_idx = in_idx + Rmax; const uint32_t* neg = out_idx + Rmax;
     for (uint32_t r = 0; r < R; ++r) {
         ent[3 * r].row = in_idx[r]; ent[3 * r].src = 3u * r;
         ent[3 * r + 1].row = out_idx[r]; ent[3 * r + 1].src = 3u * r + 1;
@@ -840,19 +973,34 @@ static int orc_apply_own_block(orc_plan* p, const void* block, int q) {
     qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
     float* gsum = (float*)malloc(sizeof(float) * d);
     float* part = (float*)malloc(sizeof(float) * d);
-    orc_entry_src es = { (const float*)(w + 8 + 4 * Rmax), (const float*)(w + 8 + 4 * Rmax) + Rmax * (uint64_t)d,
-                         (const float*)(w + 8 + 3 * Rmax) };
     uint64_t i = 0;
     while (i < ne) {
         uint32_t row = ent[i].row;
         uint64_t j = i;
         while (j < ne && ent[j].row == row) ++j;
         float gb; int has_b;
-        orc_reduce_row(ent, i, j, d, &es, 0, gsum, part, &gb, &has_b);
+        orc_reduce_row(ent, i, j, d, es, 0, gsum, part, &gb, &has_b);
         orc_row_update(m, row, gsum, 1, has_b, gb);
         i = j;
     }
     free(part); free(gsum); free(ent);
+}
+
+static int orc_apply_own_block(orc_plan* p, const void* block, int q) {
+    /* one optimiser step from ONE device's exported block */
+    orc_model* m = p->m;
+    int d = m->d;
+    uint64_t Rmax = (uint64_t)p->Rmax;
+    const uint32_t* w = (const uint32_t*)block;
+    const float* dense = (const float*)(w + 8 + 4 * Rmax + 2 * Rmax * (uint64_t)d);
+    double ls; uint64_t ex;
+    memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
+    p->loss_sum += ls; p->examples += ex;
+    p->loss_dev[q] += ls; p->examples_dev[q] += ex;
+    const uint32_t* in_idx = w + 8; const uint32_t* out_idx = in_idx + Rmax; const uint32_t* neg = out_idx + Rmax;
+    orc_entry_src es = { (const float*)(w + 8 + 4 * Rmax), (const float*)(w + 8 + 4 * Rmax) + Rmax * (uint64_t)d,
+                         (const float*)(w + 8 + 3 * Rmax) };
+    orc_apply_gradients(m, w[0], in_idx, out_idx, neg, &es, dense);
     return SBR_OK;
 }
 
@@ -1057,6 +1205,116 @@ int orc_fit_epoch_async(orc_plan* p, uint64_t nmb) {
     return st;
 }
 
+/* ---- The reference's PARALLEL SHAPE on the CPU: bench.py's cpu_baseline leg only ------------------------------------------
+ * sequence_model.rs:90-102: the shuffled subsequences are cut into num_threads partitions (:91-98), one rayon worker per
+ * partition (:99-102), ALL workers on ONE shared parameter set (Arc<HogwildParameter>, lstm.rs:175-181), one optimiser step per
+ * batch_sequences subsequences (1 = the reference's schedule, :111-169); default num_threads = all cores (lstm.rs:68).
+ *   synchronous = 0  Parallelism::Asynchronous (mod.rs:36-38): Hogwild — every worker writes its update into the shared
+ *                    parameters the moment it has it, no locks (the data races are the algorithm, as in the reference);
+ *   synchronous = 1  Parallelism::Synchronous (mod.rs:39-40; sequence_model.rs:163-166): wyrm's SynchronizedOptimizer as
+ *                    recalled — the live workers rendezvous, each update goes in under exclusion, then all
+ *                    are released.
+ * Thread timing decides the order of the updates, so this mode is NOT deterministic and no parity test uses it: it is the
+ * timed CPU baseline beside the GPU number (one shared ~1 GB table instead of round 3's private tables).  Runs the model's
+ * num_epochs epochs, or until max_seconds of wall time have passed (checked between steps; <= 0: no limit).  `workers` may
+ * exceed the 16 devices the parity paths are built for.  Negatives: the contract's counter-keyed draws (orc_score). */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    orc_plan* p;
+    int q, synchronous;
+    uint64_t nmb;
+    double t_start, max_seconds;
+    pthread_barrier_t* bar;
+    pthread_mutex_t* mu;
+    volatile int* stop;
+    uint64_t rows_done;
+    double loss_done;
+} orc_worker;
+
+static double orc_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* orc_worker_main(void* arg) {
+    orc_worker* w = (orc_worker*)arg;
+    orc_plan* p = w->p;
+    orc_model* m = p->m;
+    orc_local* L = &p->loc[w->q];
+    for (uint64_t mb = 0; mb < w->nmb; ++mb) {
+        if (!w->synchronous && w->max_seconds > 0 && orc_now() - w->t_start > w->max_seconds) break;
+        orc_pack(p, w->q, mb, L);
+        orc_forward(m, L);
+        orc_score(m, L, orc_epoch_key_of(p->fit_seed[w->q], p->epoch_key_epoch), &p->part_rng[w->q]);
+        orc_backward(m, L);
+        orc_entry_src es = { L->H, L->dX, L->coef };
+        if (w->synchronous) {
+            pthread_barrier_wait(w->bar);                 /* sync_optim.step(): wait for every live worker ... */
+            pthread_mutex_lock(w->mu);                    /* ... the updates go in one at a time ... */
+            orc_apply_gradients(m, (uint32_t)L->R, L->in_idx, L->out_idx, L->neg, &es, L->dense);
+            pthread_mutex_unlock(w->mu);
+            if (w->q == 0 && w->max_seconds > 0 && orc_now() - w->t_start > w->max_seconds) *w->stop = 1;
+            pthread_barrier_wait(w->bar);                 /* ... and everybody is released */
+        } else {
+            orc_apply_gradients(m, (uint32_t)L->R, L->in_idx, L->out_idx, L->neg, &es, L->dense); /* Hogwild: no lock */
+        }
+        w->rows_done += (uint64_t)L->R;
+        w->loss_done += L->loss_sum;
+        if (w->synchronous && *w->stop) break;
+    }
+    return NULL;
+}
+
+int orc_fit_threads(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users, uint32_t workers,
+                    int synchronous, double max_seconds, uint64_t* out_interactions, double* out_seconds, float* out_loss) {
+    if (!m || workers == 0 || workers > 4096) return SBR_ERR_INVALID_ARGUMENT;
+    const uint32_t saved = m->hp.num_devices;
+    m->hp.num_devices = workers; /* one partition per worker (sequence_model.rs:91-98) */
+    orc_plan* p = NULL;
+    int st = orc_fit_begin(m, user_ptr, item_ids, num_users, &p);
+    m->hp.num_devices = saved;
+    if (st != SBR_OK) return st;
+    pthread_barrier_t bar;
+    pthread_mutex_t mu;
+    pthread_barrier_init(&bar, NULL, workers);
+    pthread_mutex_init(&mu, NULL);
+    orc_worker* ws = (orc_worker*)calloc(workers, sizeof(orc_worker));
+    pthread_t* th = (pthread_t*)calloc(workers, sizeof(pthread_t));
+    volatile int stop = 0;
+    uint64_t rows = 0;
+    double loss = 0.0;
+    const double t0 = orc_now();
+    for (uint32_t e = 0; e < m->hp.num_epochs && !stop; ++e) {
+        uint64_t nmb = 0;
+        orc_fit_epoch_prepare(p, &nmb);
+        for (uint32_t q = 0; q < workers; ++q) {
+            ws[q].p = p; ws[q].q = (int)q; ws[q].synchronous = synchronous; ws[q].nmb = nmb;
+            ws[q].t_start = t0; ws[q].max_seconds = max_seconds; ws[q].bar = &bar; ws[q].mu = &mu; ws[q].stop = &stop;
+            pthread_create(&th[q], NULL, orc_worker_main, &ws[q]);
+        }
+        for (uint32_t q = 0; q < workers; ++q) pthread_join(th[q], NULL);
+        if (max_seconds > 0 && orc_now() - t0 > max_seconds) stop = 1;
+    }
+    const double dt = orc_now() - t0;
+    float total = 0.0f; /* ≙ the fold at sequence_model.rs:173-177 (true loss sums) */
+    for (uint32_t q = 0; q < workers; ++q) {
+        rows += ws[q].rows_done;
+        loss += ws[q].loss_done;
+        total += (float)(ws[q].loss_done / (1.0 + (double)ws[q].rows_done));
+    }
+    if (out_interactions) *out_interactions = rows;
+    if (out_seconds) *out_seconds = dt;
+    if (out_loss) *out_loss = total;
+    pthread_barrier_destroy(&bar);
+    pthread_mutex_destroy(&mu);
+    free(ws); free(th);
+    orc_fit_plan_destroy(p);
+    return SBR_OK;
+}
+
 int orc_fit_end(orc_plan* p, float* out_loss, uint64_t* out_examples) {
     /* ≙ the sum over the workers of loss_value / (1.0 + examples) (sequence_model.rs:173-177).  The
      * reference reads a stale node value (:157 before :160); reported here: the true
@@ -1092,6 +1350,7 @@ int orc_fit_debug_fetch(orc_plan* p, int q, int which, void* out, uint64_t bytes
         case SBR_DBG_IN_IDX: src = L->in_idx; n = R * 4; break;
         case SBR_DBG_OUT_IDX: src = L->out_idx; n = R * 4; break;
         case SBR_DBG_TRIES: src = L->tries; n = R * 4; break;
+        case SBR_DBG_DZ: src = L->dZ; n = R * (uint64_t)p->m->ng * d * 4; break;
         default: return SBR_ERR_INVALID_ARGUMENT;
     }
     if (bytes < n) return SBR_ERR_INVALID_ARGUMENT;
@@ -1112,7 +1371,15 @@ int orc_model_fit(orc_model* m, const uint64_t* user_ptr, const uint32_t* item_i
         else for (uint64_t mb = 0; mb < nmb; ++mb) orc_fit_step(p, mb);
     }
     orc_fit_end(p, out_loss, NULL);
+    orc_fit_end_lagged(p, &m->last_lagged_loss);
     orc_fit_plan_destroy(p);
+    return SBR_OK;
+}
+
+/* what the reference's `fit` would have returned for the last orc_model_fit (sequence_model.rs:157, :173-177) */
+int orc_model_last_fit_lagged_loss(const orc_model* m, float* out_loss) {
+    if (!m || !out_loss) return SBR_ERR_INVALID_ARGUMENT;
+    *out_loss = m->last_lagged_loss;
     return SBR_OK;
 }
 

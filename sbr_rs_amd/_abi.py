@@ -51,6 +51,7 @@ class Debug(enum.IntEnum):
     IN_IDX = 7
     OUT_IDX = 8
     TRIES = 9
+    DZ = 10
 
 
 class KernelFamily(enum.IntEnum):
@@ -65,7 +66,7 @@ class KernelFamily(enum.IntEnum):
 
 
 NUM_KERNEL_FAMILIES = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SbrHparams(C.Structure):

@@ -36,6 +36,8 @@ def load():
         "sbr_fit_minibatch_rows": [vp, C.c_uint64, u64p],
         "sbr_fit_end": [vp, fp, u64p],
         "sbr_fit_counters": [vp, u64p, u64p],
+        "sbr_fit_end_lagged": [vp, fp],
+        "sbr_model_last_fit_lagged_loss": [vp, fp],
         "sbr_model_get_rng": [vp, vp],
         "sbr_model_set_rng": [vp, vp],
         "sbr_fit_sparse_stats": [vp, u64p, u64p],
@@ -59,6 +61,7 @@ def load():
         "sbr_model_param_count": [vp, C.c_int32, u64p],
         "sbr_model_get_param": [vp, C.c_int32, vp, C.c_uint64],
         "sbr_model_set_param": [vp, C.c_int32, vp, C.c_uint64],
+        "sbr_model_get_param_rows": [vp, C.c_int32, vp, C.c_uint64, vp],
         "sbr_model_get_epoch": [vp, u64p],
         "sbr_model_get_counters": [vp, u64p, u64p],
         "sbr_model_set_counters": [vp, C.c_uint64, C.c_uint64],
@@ -113,10 +116,10 @@ def load():
 DECLARED_SYMBOLS = [
     "sbr_model_create", "sbr_model_destroy", "sbr_model_fit", "sbr_fit_begin", "sbr_fit_epoch_prepare",
     "sbr_fit_epoch_prefetch",
-    "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_counters", "sbr_model_get_rng", "sbr_model_set_rng", "sbr_fit_sparse_stats", "sbr_fit_plan_destroy", "sbr_fit_chunk_bytes", "sbr_fit_dense_bytes",
+    "sbr_fit_step", "sbr_fit_minibatch_rows", "sbr_fit_end", "sbr_fit_end_lagged", "sbr_model_last_fit_lagged_loss", "sbr_fit_counters", "sbr_model_get_rng", "sbr_model_set_rng", "sbr_fit_sparse_stats", "sbr_fit_plan_destroy", "sbr_fit_chunk_bytes", "sbr_fit_dense_bytes",
     "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_fit_step_scatter", "sbr_fit_step_dense", "sbr_fit_step_owner_reduce", "sbr_fit_step_owner_reduce_on", "sbr_fit_step_apply_table", "sbr_fit_step_apply_rows", "sbr_fit_step_apply_dense", "sbr_model_set_stream", "sbr_model_synchronize",
     "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
-    "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_epoch", "sbr_model_get_counters", "sbr_model_set_counters", "sbr_device_info", "sbr_status_string",
+    "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_param_rows", "sbr_model_get_epoch", "sbr_model_get_counters", "sbr_model_set_counters", "sbr_device_info", "sbr_status_string",
     "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_set_overlap", "sbr_model_timing_read", "sbr_set_device", "sbr_group_fit", "sbr_device_count", "sbr_group_create", "sbr_model_is_partitioned", "sbr_model_create_partitioned", "sbr_partition_num_parts", "sbr_fit_exchange_export", "sbr_fit_exchange_import",
     "sbr_fit_step_scatter_shared", "sbr_fit_step_owner_reduce_peers", "sbr_fit_step_apply_table_peers",
     "sbr_partition_part_info", "sbr_partition_export_part", "sbr_partition_import_part", "sbr_partition_finalize",

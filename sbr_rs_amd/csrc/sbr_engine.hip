@@ -290,6 +290,7 @@ struct sbr_model {
     bool partition_finalized = true;
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
+    float last_lagged_loss = 0.0f; /* what the reference's fit would have returned for the last sbr_model_fit / sbr_group_fit */
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
@@ -507,6 +508,12 @@ struct sbr_fit_plan {
     bool sorted_event_live = false; /* ev_sorted has been recorded at least once: the multi-device consumers wait on it whatever the
                                      * last step's placement was (a completed event costs nothing; the flag above belongs to ONE step) */
     bool header_accumulated = false; /* single device: block_header_kernel already added this step to loss_acc / ex_acc */
+    /* the loss figure the reference's fit returns (sbr_report.hip): [accumulator | loss-node value per sequence length], the
+     * per-sequence sums of the current step, and the events that order the one-wave chain kernel (sorter stream) against the
+     * main stream */
+    float *lag_state = nullptr, *lag_seqsum = nullptr;
+    hipEvent_t ev_seqsum = nullptr, ev_lagged = nullptr;
+    bool lag_busy = false; /* ev_lagged is pending on another stream than the main one */
     /* partitioned item table: this device's gradient list (addressed by sorted-key position), the owner
      * bounds, and the owner-side merge buffers */
     float *glist = nullptr, *gblist = nullptr;
@@ -569,7 +576,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 6; }
+uint32_t sbr_abi_version(void) { return 7; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -861,6 +868,25 @@ sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uin
     return SBR_OK;
 }
 
+/* selected rows of an item-table block (embeddings and their optimiser state: [n][embedding_dim]; biases: [n]) */
+sbr_status sbr_model_get_param_rows(sbr_model* m, int32_t which, const uint32_t* rows, uint64_t n, float* host_out) {
+    if (!m || !host_out || (n && !rows)) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t count = 0, stored = 0;
+    int shape = SHAPE_FLAT;
+    float* p = param_ptr(m, which, &count, &stored, &shape);
+    const uint64_t I = m->hp.num_items;
+    const bool table = shape == SHAPE_ROWS, bias = shape == SHAPE_FLAT && stored == I && (which == SBR_PARAM_ITEM_BIAS || which == SBR_PARAM_ITEM_BIAS_ACC || which == SBR_PARAM_ITEM_BIAS_M);
+    if (!p || !count || (!table && !bias)) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const uint64_t w = table ? (uint64_t)m->dl : 1, ws = table ? (uint64_t)m->d : 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (rows[i] >= I) return SBR_ERR_INVALID_ARGUMENT;
+        HIPCHK(hipMemcpy(host_out + i * w, p + (uint64_t)rows[i] * ws, w * 4, hipMemcpyDeviceToHost));
+    }
+    return SBR_OK;
+}
+
 sbr_status sbr_model_set_param(sbr_model* m, int32_t which, const float* host_in, uint64_t count) {
     if (!m || !host_in) return SBR_ERR_INVALID_ARGUMENT;
     uint64_t n = 0, stored = 0;
@@ -1048,9 +1074,14 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
+    if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + T);
+    if (st == SBR_OK) st = dmalloc(&p->lag_seqsum, p->bmax);
+    if (st == SBR_OK && (hipEventCreateWithFlags(&p->ev_seqsum, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess)) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
     if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
+    hipMemsetAsync(p->lag_state, 0, (1 + T) * sizeof(float), m->stream); /* the reference builds its loss nodes per fit call */
     hipMemsetAsync(p->loss_acc, 0, 17 * sizeof(double), m->stream);
     hipMemsetAsync(p->ex_acc, 0, 18 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
@@ -1082,6 +1113,9 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     }
     hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
     hipFree(p->loss_acc); hipFree(p->ex_acc);
+    hipFree(p->lag_state); hipFree(p->lag_seqsum);
+    if (p->ev_seqsum) hipEventDestroy(p->ev_seqsum);
+    if (p->ev_lagged) hipEventDestroy(p->ev_lagged);
     hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
     hipFree(p->seg.P); hipFree(p->seg.Pb); hipFree(p->seg.Pf);
     hipFree(p->seg.head_pos); hipFree(p->seg.nheads);
@@ -1331,10 +1365,22 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
         sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
     }
+    /* the figure the reference's fit returns (sbr_report.hip): a small step folds it into the header launch; otherwise the
+     * per-sequence sums come from a parallel kernel here and the sequential chain over the sequences runs as one wave on the
+     * sorter stream (queued at the end of this call), off the critical path */
+    if (p->lag_busy) { /* the previous step's chain may still be running on the sorter stream: it owns lag_state / lag_seqsum */
+        HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
+        p->lag_busy = false;
+    }
+    const bool fuse_lag = !overlap && mb.B <= SBR_HEADER_LAG_MAX_B;
+    if (!fuse_lag) {
+        sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, m->stream);
+        if (overlap) HIPCHK(hipEventRecord(p->ev_seqsum, m->stream));
+    }
     /* single device: the loss accumulators take the block's header in the header kernel itself (one launch fewer per step) */
     p->header_accumulated = p->ndev == 1;
-    sbr::launch_block_header(m->mv, bv, p->wb.v, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
-                             p->header_accumulated ? p->ex_acc : nullptr, m->stream);
+    sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
+                             p->header_accumulated ? p->ex_acc : nullptr, fuse_lag ? p->lag_state : nullptr, m->stream);
     /* host order: with the ordering on its own stream the backward pass is queued FIRST — the ordering's up to nine short
      * launches would otherwise sit in the host's queue ahead of it (50 us at a few hundred sequences per step, as long as
      * the pass itself); ev_scored, recorded here, is what the ordering waits for either way */
@@ -1360,6 +1406,15 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     if (!early_sort && place == SORT_POST) SBRCHK(launch_sort(m->stream));
     if (side != m->stream) HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = side != m->stream;
+    if (!fuse_lag) {
+        hipStream_t ls = overlap ? m->sorter : m->stream;
+        if (ls != m->stream) HIPCHK(hipStreamWaitEvent(ls, p->ev_seqsum, 0));
+        sbr::launch_lagged_chain(mv, p->lag_seqsum, mb.B, p->lag_state, ls);
+        if (ls != m->stream) {
+            HIPCHK(hipEventRecord(p->ev_lagged, ls));
+            p->lag_busy = true;
+        }
+    }
     p->last_R = mb.R;
     p->last_block = block;
     HIPCHK(hipGetLastError());
@@ -1617,6 +1672,28 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
     return SBR_OK;
 }
 
+/* ≙ the value `fit` returns in the reference: sum over the workers of (stale loss-node values) / (1 + examples)
+ * (sequence_model.rs:157 before :160, :173-177).  This device's term; single device: the whole figure. */
+sbr_status sbr_fit_end_lagged(sbr_fit_plan* p, float* out_term) {
+    if (!p || !out_term) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipStreamSynchronize(m->sorter));
+    float lagged = 0.0f;
+    unsigned long long ex[18];
+    HIPCHK(hipMemcpy(&lagged, p->lag_state, sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ex, p->ex_acc, sizeof(ex), hipMemcpyDeviceToHost));
+    *out_term = lagged / (1.0f + (float)ex[2 + p->rank]);
+    return SBR_OK;
+}
+
+sbr_status sbr_model_last_fit_lagged_loss(const sbr_model* m, float* out_loss) {
+    if (!m || !out_loss) return SBR_ERR_INVALID_ARGUMENT;
+    *out_loss = m->last_lagged_loss;
+    return SBR_OK;
+}
+
 sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* out_negatives_scored) {
     if (!p) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(p->m));
@@ -1655,6 +1732,7 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) st = sbr_fit_step(p, mb);
     }
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
+    if (st == SBR_OK) st = sbr_fit_end_lagged(p, &m->last_lagged_loss);
     sbr_fit_plan_destroy(p);
     return st;
 }
@@ -2022,6 +2100,13 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                 for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(sync_step(mb));
         }
         for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(dev[r].plan, nullptr, nullptr));
+        float lagged = 0.0f; /* the workers' terms added in worker order, f32 (sequence_model.rs:173-177) */
+        for (uint32_t r = 0; r < n; ++r) {
+            float term = 0.0f;
+            SBRCHK(sbr_fit_end_lagged(dev[r].plan, &term));
+            lagged = lagged + term;
+        }
+        for (uint32_t r = 0; r < n; ++r) models[r]->last_lagged_loss = lagged;
         return sbr_fit_end(dev[0].plan, out_loss, nullptr);
     };
     const sbr_status st = run();
@@ -2181,6 +2266,7 @@ sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, u
         case SBR_DBG_IN_IDX: src = bv.in_idx; n = R * 4; break;
         case SBR_DBG_OUT_IDX: src = bv.out_idx; n = R * 4; break;
         case SBR_DBG_TRIES: src = p->wb.v.tries; n = R * 4; break;
+        case SBR_DBG_DZ: if (!m->ng) return SBR_ERR_INVALID_ARGUMENT; src = p->wb.v.dZ; n = R * (uint64_t)m->ng * d * 4; break;
         default: return SBR_ERR_INVALID_ARGUMENT;
     }
     if (bytes < n) return SBR_ERR_INVALID_ARGUMENT;

@@ -119,9 +119,20 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
 /* debug only: dloss/dh of every packed row (the training path never materialises it) */
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
 /* header of the exchange block (rows, loss sum, examples); loss_acc / ex_acc non-null (single device): the plan's accumulators
- * take the header in the same launch */
-void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, double* loss_acc,
-                         unsigned long long* ex_acc, hipStream_t s);
+ * take the header in the same launch; lag_state non-null (small step, <= SBR_HEADER_LAG_MAX_B sequences): the lagged loss figure
+ * (below) in the same launch too */
+#define SBR_HEADER_LAG_MAX_B 1024
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, const MbView& mb, int rows_host, double* loss_acc,
+                         unsigned long long* ex_acc, float* lag_state, hipStream_t s);
+void launch_block_header_parts(uint32_t* header, int rows_host, const double* part_loss, const unsigned int* part_tries, int nparts,
+                               double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
+                               hipStream_t s);
+/* sbr_report.hip — the loss figure the reference's `fit` returns (sequence_model.rs:157 reads the loss node BEFORE :160 runs its
+ * forward pass: every subsequence contributes what the worker's previous subsequence of the same length left there).  seq_loss:
+ * per-sequence summed loss, t ascending; lagged_chain: the strictly sequential f32 accumulation over the minibatch's sequences on
+ * one wave.  lag_state = [accumulator | node value per sequence length]. */
+void launch_seq_loss(const MbView& mb, const float* loss, float* seqsum, int b_host, hipStream_t s);
+void launch_lagged_chain(const MbView& mb, const float* seqsum, int b_host, float* lag_state, hipStream_t s);
 /* BPTT (dX, dZ) and, separately, the dense gradient into blk.dense (may run on a second stream:
  * it reads only dZ, X, H) */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

@@ -141,46 +141,6 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // K1+K3+K4: gather + negative sampling + loss + dloss/dh  (the HBM-roofline kernel)
 // One d/4-lane group per packed row; 16 B per lane per gathered embedding row.
 // ------------------------------------------------------------------------------------------------
-// header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction,
-// compared with a tolerance) and example count
-__global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
-                                                          const unsigned int* part_tries, int nparts, double* loss_acc,
-                                                          unsigned long long* ex_acc) {
-    __shared__ double part[4];
-    __shared__ unsigned int tpart[4];
-    double acc = 0.0;
-    unsigned int tacc = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) {
-        acc += part_loss[i];
-        tacc += part_tries[i];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        acc += __shfl_xor(acc, off, 64);
-        tacc += __shfl_xor(tacc, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        part[threadIdx.x >> 6] = acc;
-        tpart[threadIdx.x >> 6] = tacc;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        header[0] = (uint32_t)R;
-        header[1] = tpart[0] + tpart[1] + tpart[2] + tpart[3]; /* negatives scored in this minibatch (reporting only) */
-        header[2] = header[3] = 0;
-        const double loss = part[0] + part[1] + part[2] + part[3];
-        *reinterpret_cast<double*>(header + 4) = loss;
-        *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
-        if (loss_acc) { /* single device: the plan's accumulators take the header here (accumulate_loss_kernel with one block) */
-            loss_acc[0] += loss;
-            loss_acc[1] += loss;
-            ex_acc[0] += (unsigned long long)R;
-            ex_acc[1] += header[1];
-            ex_acc[2] += (unsigned long long)R;
-        }
-    }
-}
-
 template <int D>
 __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
                                                     uint64_t epoch_key) {
@@ -2762,10 +2722,10 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
     });
 }
 
-void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, int rows_host, double* loss_acc,
-                         unsigned long long* ex_acc, hipStream_t s) {
-    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, blk.header, rows_host, w.part_loss, w.part_tries,
-                       rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0, loss_acc, ex_acc);
+void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, const MbView& mb, int rows_host, double* loss_acc,
+                         unsigned long long* ex_acc, float* lag_state, hipStream_t s) {
+    launch_block_header_parts(blk.header, rows_host, w.part_loss, w.part_tries,
+                              rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0, loss_acc, ex_acc, mb, w.loss, lag_state, s);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

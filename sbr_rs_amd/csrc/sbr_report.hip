@@ -1,0 +1,148 @@
+// sbr_report.hip — the loss figure the reference's `fit` returns, on the device.
+//
+// /root/reference/src/models/sequence_model.rs:157 adds `loss.value().scalar_sum()` of the node losses[loss_idx]
+// BEFORE :160 runs `loss.forward()` on it: what a worker accumulates for a subsequence of n items is the value its
+// previous subsequence OF THE SAME LENGTH left in that node (0 the first time), in f32, and `fit` returns the sum over
+// the workers of that accumulator / (1 + examples) (:173-177).  The engine's sbr_fit_end reports the true sums; this
+// file keeps the reference's figure beside it so that a caller behind INTEGRATION.md can return what the crate returns.
+//
+// Per minibatch (sequences b = 0..B-1 in packed order = steps descending, so sequences of one length are one run):
+//   sum_b    = l_0 + l_1 + ... + l_{steps_b - 1}            t-ascending f32 chain  (L_t = L_{t-1} + l_t, lstm.rs:322-328)
+//   x_b      = first of its run ? node[steps_b] : sum_{b-1}  what the node of that length held when b read it
+//   total    = ((total + x_0) + x_1) + ...                   strictly sequential f32 chain over b
+//   node[s]  = sum of the last sequence of the run of length s
+// A length occurs in at most one run of a minibatch, so the x_b are independent of each other and only the chain over b is
+// sequential: ONE wave walks it, 64 values per coalesced load, v_readlane + v_add_f32 per value (a lone wave issues a
+// dependent VALU instruction every ~9 cycles: 50 000 sequences ~ 0.4 ms, on the sorter stream underneath BPTT).
+// The CPU checker restates it sequentially (tests compare the two bit for bit).
+
+#include <hip/hip_runtime.h>
+
+#include "sbr_kernels.h"
+
+namespace sbr {
+
+// one thread per sequence: the summed loss node of the sequence, t ascending
+__global__ __launch_bounds__(256) void seq_loss_kernel(MbView mb, const float* loss, float* seqsum) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= mb.B) return;
+    const int n = mb.steps[b];
+    float s = 0.0f;
+#pragma unroll 8
+    for (int t = 0; t < n; ++t) s = s + loss[mb.off[t] + b];
+    seqsum[b] = s;
+}
+
+// state[0] = the partition's accumulator (loss_value of sequence_model.rs:105), state[1 + s] = value left in the loss node of
+// a sequence with s + 1 steps.  One wave; `steps` / `seqsum` in global memory or LDS.
+__device__ __forceinline__ void lagged_chain(const int* steps, const float* seqsum, int B, float* state, int lane) {
+    float* node = state + 1;
+    float acc = state[0];
+    for (int base = 0; base < B; base += 64) {
+        const int j = base + lane;
+        const bool live = j < B;
+        const int s = live ? steps[j] : 0;
+        const int sp = live && j > 0 ? steps[j - 1] : -1;
+        const int sn = live && j + 1 < B ? steps[j + 1] : -1;
+        float x = 0.0f, mine = 0.0f;
+        if (live) {
+            mine = seqsum[j];
+            x = sp != s ? node[s - 1] : seqsum[j - 1];
+        }
+        const int n = B - base < 64 ? B - base : 64;
+        if (n == 64) {
+#pragma unroll
+            for (int l = 0; l < 64; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+        } else {
+            for (int l = 0; l < n; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+        }
+        if (live && sn != s) node[s - 1] = mine; /* the run's last sequence: no later sequence of this minibatch reads this node */
+    }
+    if (lane == 0) state[0] = acc;
+}
+
+__global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, const float* seqsum, int B, float* state) {
+    lagged_chain(steps, seqsum, B, state, threadIdx.x);
+}
+
+// header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction, compared with a tolerance) and
+// example count.  loss_acc / ex_acc non-null (single device): the plan's accumulators take the header in the same launch.
+// lag_state non-null (a small step, everything on one stream): the lagged figure of up to SBR_HEADER_LAG_MAX_B sequences in the
+// same launch as well — a small step is a chain of ~5 us launches and cannot afford two more.
+__global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
+                                                          const unsigned int* part_tries, int nparts, double* loss_acc,
+                                                          unsigned long long* ex_acc, MbView mb, const float* loss, float* lag_state) {
+    __shared__ double part[4];
+    __shared__ unsigned int tpart[4];
+    __shared__ float ssum[SBR_HEADER_LAG_MAX_B];
+    __shared__ int ssteps[SBR_HEADER_LAG_MAX_B];
+    double acc = 0.0;
+    unsigned int tacc = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        acc += part_loss[i];
+        tacc += part_tries[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc += __shfl_xor(acc, off, 64);
+        tacc += __shfl_xor(tacc, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[threadIdx.x >> 6] = acc;
+        tpart[threadIdx.x >> 6] = tacc;
+    }
+    if (lag_state) { /* a wave per sequence, 64 loss terms per coalesced load, then the t-ascending chain by v_readlane: one
+                      * sequence per step (the reference's schedule) must not wait for ~100 dependent load-add pairs */
+        const int lane = threadIdx.x & 63;
+        for (int b = threadIdx.x >> 6; b < mb.B; b += 4) {
+            const int n = mb.steps[b];
+            float s = 0.0f;
+            for (int base = 0; base < n; base += 64) {
+                const int t = base + lane;
+                const float v = t < n ? loss[mb.off[t] + b] : 0.0f;
+                const int cnt = n - base < 64 ? n - base : 64;
+                for (int l = 0; l < cnt; ++l) s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+            }
+            if (lane == 0) {
+                ssum[b] = s;
+                ssteps[b] = n;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        header[0] = (uint32_t)R;
+        header[1] = tpart[0] + tpart[1] + tpart[2] + tpart[3]; /* negatives scored in this minibatch (reporting only) */
+        header[2] = header[3] = 0;
+        const double lsum = part[0] + part[1] + part[2] + part[3];
+        *reinterpret_cast<double*>(header + 4) = lsum;
+        *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
+        if (loss_acc) { /* single device: the plan's accumulators take the header here (accumulate_loss_kernel with one block) */
+            loss_acc[0] += lsum;
+            loss_acc[1] += lsum;
+            ex_acc[0] += (unsigned long long)R;
+            ex_acc[1] += header[1];
+            ex_acc[2] += (unsigned long long)R;
+        }
+    }
+    if (lag_state && threadIdx.x < 64) lagged_chain(ssteps, ssum, mb.B, lag_state, threadIdx.x);
+}
+
+void launch_block_header_parts(uint32_t* header, int rows_host, const double* part_loss, const unsigned int* part_tries, int nparts,
+                               double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, header, rows_host, part_loss, part_tries, nparts, loss_acc, ex_acc,
+                       mb, loss, lag_state);
+}
+
+void launch_seq_loss(const MbView& mb, const float* loss, float* seqsum, int b_host, hipStream_t s) {
+    if (b_host <= 0) return;
+    hipLaunchKernelGGL(seq_loss_kernel, dim3((b_host + 255) / 256), dim3(256), 0, s, mb, loss, seqsum);
+}
+
+void launch_lagged_chain(const MbView& mb, const float* seqsum, int b_host, float* state, hipStream_t s) {
+    if (b_host <= 0) return;
+    hipLaunchKernelGGL(lagged_chain_kernel, dim3(1), dim3(64), 0, s, mb.steps, seqsum, b_host, state);
+}
+
+}  // namespace sbr

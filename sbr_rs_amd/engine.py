@@ -151,6 +151,12 @@ class FitPlan:
         _check(self._L.sbr_fit_end(self._h, C.byref(loss), C.byref(ex)))
         return loss.value, ex.value
 
+    def end_lagged(self) -> float:
+        """This device's term of the figure the reference's ``fit`` returns (stale loss-node values, sequence_model.rs:157)."""
+        v = C.c_float()
+        _check(self._L.sbr_fit_end_lagged(self._h, C.byref(v)))
+        return v.value
+
     def counters(self):
         ex, neg = C.c_uint64(), C.c_uint64()
         _check(self._L.sbr_fit_counters(self._h, C.byref(ex), C.byref(neg)))
@@ -169,6 +175,8 @@ class FitPlan:
             out = np.zeros((rows, d), dtype=np.float32)
         elif which == 6:
             out = np.zeros(self.model.dense_count(), dtype=np.float32)
+        elif which == 10:
+            out = np.zeros((rows, {0: 4, 1: 3, 2: 0}[int(self.model.hp.model)] * d), dtype=np.float32)
         else:
             out = np.zeros(rows, dtype=np.uint32 if which in _DBG_U32 else np.float32)
         _check(self._L.sbr_fit_debug_fetch(self._h, which, _ptr(out), out.nbytes))
@@ -229,6 +237,14 @@ class Model:
             _check(self._L.sbr_model_get_param(self._h, int(which), _ptr(out), out.size))
         return out
 
+    def get_param_rows(self, which: int, rows) -> np.ndarray:
+        """Selected rows of an item-table block ([n, embedding_dim]; biases: [n]) without moving the whole table."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        table = self.param_count(which) != int(self.hp.num_items)
+        out = np.zeros((rows.size, self.dim) if table else rows.size, dtype=np.float32)
+        _check(self._L.sbr_model_get_param_rows(self._h, int(which), _ptr(rows), rows.size, _ptr(out)))
+        return out
+
     def set_param(self, which: int, values):
         values = np.ascontiguousarray(values, dtype=np.float32).ravel()
         _check(self._L.sbr_model_set_param(self._h, int(which), _ptr(values), values.size))
@@ -283,6 +299,13 @@ class Model:
         loss = C.c_float()
         _check(self._L.sbr_model_fit(self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
         return loss.value
+
+    def last_fit_lagged_loss(self) -> float:
+        """What the reference's ``fit`` would have returned for the last ``fit`` / ``group_fit``; ``fit`` itself
+        returns the true mean loss."""
+        v = C.c_float()
+        _check(self._L.sbr_model_last_fit_lagged_loss(self._h, C.byref(v)))
+        return v.value
 
     def fit_begin(self, user_ptr, item_ids) -> FitPlan:
         return FitPlan(self, user_ptr, item_ids)

@@ -187,6 +187,13 @@ class _ImplicitSequenceModel:
 
         return group_fit(self._replicas(), interactions.user_pointers, interactions.item_ids)
 
+    def last_fit_lagged_loss(self) -> float:
+        """The number the reference's ``fit`` would have returned for the last single-process ``fit`` (one device or
+        ``num_threads`` replicas): sequence_model.rs:157 reads the loss node before :160 runs its forward pass, so every
+        subsequence contributes what the worker's previous subsequence of the same length left there.  ``fit`` returns the
+        true mean loss."""
+        return self.params.last_fit_lagged_loss()
+
     def _replicas(self):
         """Replica r of a single-process multi-device model lives on HIP device r mod device_count;
         the peers are created at the first fit, from the same seed as the primary."""

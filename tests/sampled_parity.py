@@ -1,0 +1,137 @@
+"""Oracle parity of ONE optimiser step at sizes the oracle cannot run whole (the bench's own regime), by sampling.
+
+The side under test ("full": the HIP engine on the GPU; in the CPU self-test a second oracle) runs the first optimiser step of
+a fit on the whole minibatch.  The oracle then
+  1. runs forward + negative sampling + loss + BPTT for a SAMPLE of the minibatch's sequences only — with the epoch key and
+     the position counters those sequences have in the full minibatch (oracle.step_local_sample; a sequence's rows depend on
+     the parameters and on its own items only) — and every packed row of the sample is compared bit for bit with the same
+     row of the full step: indices, hidden states, negatives, trip counts, coefficients, losses, dX and (LSTM) dZ;
+  2. recomputes, for a sample of item-table rows, the row's optimiser step from EVERY entry of the full minibatch that touches
+     it, in the contract's order (oracle.row_step: (packed row, kind) order, 256-entry chunks, Adagrad with L2), from the full
+     step's own H / dX / coef — and compares E, E_acc, b, b_acc of those rows after the step bit for bit;
+  3. (LSTM) recomputes sampled elements of the dense gradient as the contract's chunked fma chain over ALL packed rows
+     (oracle.dense_chain) from the full step's X / H / dZ columns, compares them with the step's dense-gradient block, and
+     compares W, W_acc, bW, bW_acc after the step with the oracle's dense Adagrad applied to that block.
+What is not re-derived by the oracle: H / dX / dZ of the unsampled sequences (inputs of 2 and 3 are the full step's own
+arrays, verified on the sample), and EWMA's d-element alpha gradient.
+≙ one iteration of /root/reference/src/models/sequence_model.rs:111-169 for a minibatch."""
+from __future__ import annotations
+
+import numpy as np
+
+from sbr_rs_amd._abi import Debug, Param
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = np.flatnonzero((_bits(a) if a.dtype == np.float32 else a).ravel() != (_bits(b) if b.dtype == np.float32 else b).ravel())
+    assert bad.size == 0, f"{what}: {bad.size}/{a.size} differ; first at {bad[0]}: full={a.ravel()[bad[0]]!r} oracle={b.ravel()[bad[0]]!r}"
+
+
+def count_subsequences(ptr, T):
+    """Chunks of at most T items with more than two items (data.rs:406-431 + sequence_model.rs:81)."""
+    lens = np.diff(np.asarray(ptr, dtype=np.int64))
+    rem = lens % T
+    first = np.where(rem == 0, np.minimum(lens, T), rem)  # the short chunk comes first
+    return int(np.sum(first > 2) + np.sum((lens - first) // T))
+
+
+def pick_sequences(nb, nsel, rs):
+    """Ascending packed-order indices across the first, middle and last tiles of the minibatch (tile = 16 / 32 / 64 sequences;
+    beyond tile 1 024 of 32 when the minibatch is that large: the unfolded tile order of the sequence-resident kernels)."""
+    fixed = [0, 1, 15, 16, 31, 32, 63, 64, nb // 2, nb // 2 + 1, nb - 65, nb - 33, nb - 17, nb - 2, nb - 1, 32 * 1024 + 5, 32 * 1100 + 31]
+    fixed = [b for b in fixed if 0 <= b < nb]
+    extra = rs.choice(nb, size=max(0, min(nb, nsel) - len(set(fixed))), replace=False) if nb > len(set(fixed)) else []
+    return np.unique(np.concatenate([np.array(fixed, dtype=np.int64), np.asarray(extra, dtype=np.int64)])).astype(np.uint32)
+
+
+def check_first_step(full, o, po, *, lstm: bool, nb: int, nsel=64, nrows=256, ndense=48, seed=0):
+    """`full`: adapter of the side that runs the whole step — .rows (packed rows of minibatch 0), .step_local(), .fetch(which),
+    .apply(), .model (get_param / get_param_rows).  `o`, `po`: an oracle model with the SAME hyper-parameters (and so the same
+    initial parameters) and its plan, epoch prepared, not stepped."""
+    rs = np.random.RandomState(seed)
+    g = full.model
+    d = g.storage_dim
+    I = int(g.hp.num_items)
+    ng = {0: 4, 1: 3, 2: 0}[int(g.hp.model)]
+    full.step_local()
+    R = full.rows
+    # ---- 1. sampled sequences ---------------------------------------------------------------------------------------
+    sel = pick_sequences(nb, nsel, rs)
+    idx, off = po.step_local_sample(0, sel)
+    n = idx.size
+    assert n > 0 and idx.max() < R
+    whichs = [Debug.IN_IDX, Debug.OUT_IDX, Debug.HIDDEN, Debug.NEGATIVES, Debug.TRIES, Debug.COEF, Debug.LOSS, Debug.DINPUT] + ([Debug.DZ] if lstm else [])
+    arrays = {}
+    for w in whichs:
+        arrays[w] = full.fetch(w)
+        _same(arrays[w][idx], po.debug_fetch(w, n), f"sampled sequences: {w.name}")
+    in_idx, out_idx, neg, coef, H, dX = (arrays[w] for w in (Debug.IN_IDX, Debug.OUT_IDX, Debug.NEGATIVES, Debug.COEF, Debug.HIDDEN, Debug.DINPUT))
+    assert off[-1] <= R and int(off[1]) == nb
+    # ---- 3a. sampled elements of the dense gradient (before the step is applied: it reads the initial table) -----------
+    dense = full.fetch(Debug.DENSE_GRAD) if lstm else None
+    if lstm:
+        assert d == g.dim, "the dense-gradient sample is written for the kernels' own widths"
+        nz = ng * d
+        dZ = arrays[Debug.DZ]
+        E0 = g.get_param(Param.ITEM_EMBEDDING).reshape(I, d)  # the initial table (LSTM configurations: 1e6 items = 0.5 GB)
+        offi = off.astype(np.int64)
+        rr = np.arange(R, dtype=np.int64)
+        row_t = np.searchsorted(offi, rr, side="right") - 1
+        prev = np.where(row_t > 0, offi[np.maximum(row_t - 1, 0)] + (rr - offi[row_t]), -1)
+        from oracle.oracle import dense_chain
+
+        third = ndense // 3
+        ks = np.concatenate([rs.randint(0, d, third), d + rs.randint(0, d, third), np.full(ndense - 2 * third, 2 * d)])
+        js = rs.randint(0, nz, ks.size)
+        for k, j in zip(ks, js):
+            dzc = np.ascontiguousarray(dZ[:, j])
+            if k < d:
+                a = E0[in_idx, k]                                                       # x_t = E[in_t]
+            elif k < 2 * d:
+                a = np.where(prev >= 0, H[np.maximum(prev, 0), k - d], np.float32(0.0))  # h_{t-1}, 0 at t = 0
+            else:
+                a = None                                                                # bias row: plain add chain
+            want = dense_chain(None if a is None else a.astype(np.float32), dzc)
+            _same(np.array([dense[k * nz + j]], dtype=np.float32), np.array([want], dtype=np.float32), f"dense gradient element ({k}, {j})")
+        del E0
+    # ---- 2. sampled item rows: the whole optimiser step of the row ------------------------------------------------------
+    all_rows = np.stack([in_idx, out_idx, neg], axis=1).ravel()  # entry e = 3 r + kind
+    order = np.argsort(all_rows, kind="stable")                  # (row, packed row, kind) order
+    sorted_rows = all_rows[order]
+    pick = rs.choice(R, size=min(R, nrows), replace=False)
+    items = np.unique(np.concatenate([in_idx[pick[: nrows // 3]], out_idx[pick[nrows // 3: 2 * nrows // 3]], neg[pick[2 * nrows // 3:]]])).astype(np.uint32)
+    before = {p: g.get_param_rows(p, items) for p in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC)}
+    for p in before:  # the full side's initial rows are the oracle's
+        _same(before[p], o.get_param_rows(p, items), f"initial {p.name} rows")
+    full.apply()
+    after = {p: g.get_param_rows(p, items) for p in before}
+    lo = np.searchsorted(sorted_rows, items, side="left")
+    hi = np.searchsorted(sorted_rows, items, side="right")
+    max_entries = 0
+    for i, item in enumerate(items):
+        e = order[lo[i]:hi[i]]
+        assert e.size > 0
+        max_entries = max(max_entries, e.size)
+        r, kind = e // 3, e % 3
+        vecs = np.where((kind == 0)[:, None], dX[r], H[r]).astype(np.float32)
+        scale = np.where(kind == 0, np.float32(1.0), np.where(kind == 1, -coef[r], coef[r])).astype(np.float32)
+        pad = lambda v: np.concatenate([v, np.zeros(d - v.size, dtype=np.float32)]) if v.size < d else v
+        w, acc, b, bacc = o.row_step(vecs, scale, kind != 0, pad(before[Param.ITEM_EMBEDDING][i]), pad(before[Param.ITEM_EMBEDDING_ACC][i]),
+                                     before[Param.ITEM_BIAS][i], before[Param.ITEM_BIAS_ACC][i])
+        dl = g.dim
+        _same(after[Param.ITEM_EMBEDDING][i], w[:dl], f"item {item}: embedding row after the step ({e.size} entries)")
+        _same(after[Param.ITEM_EMBEDDING_ACC][i], acc[:dl], f"item {item}: accumulator row after the step")
+        _same(np.array([after[Param.ITEM_BIAS][i]]), np.array([b]), f"item {item}: bias after the step")
+        _same(np.array([after[Param.ITEM_BIAS_ACC][i]]), np.array([bacc]), f"item {item}: bias accumulator after the step")
+    # ---- 3b. dense parameters after the step ------------------------------------------------------------------------------
+    if lstm and d == g.dim:
+        o.apply_dense(dense)
+        for p in (Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC):
+            _same(g.get_param(p), o.get_param(p), f"{p.name} after the step")
+    return {"rows": int(R), "sampled_sequences": int(sel.size), "sampled_rows": int(n), "sampled_items": int(items.size), "max_entries_per_item": int(max_entries)}

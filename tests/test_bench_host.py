@@ -50,3 +50,23 @@ def test_quality_neutral_batch_is_committed_with_its_evidence():
     assert all(rows[b] >= 0.97 * base for b in rows if b <= qn["batch_sequences"])
     assert rows[16384] < 0.97 * base and rows[50000] < 0.8 * base  # what the bench's default batch costs the LSTM
     assert os.path.exists(os.path.join(ROOT, qn["table"]))
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment — the driver's command shape — must start two ranks
+    through torch.distributed.run by itself.  On this CPU box each rank then stops at the engine's "needs an MI355X" check:
+    what is asserted here is that both ranks were started (round 3 exited before doing anything)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    import torch
+
+    if torch.cuda.is_available():
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert "must be launched through" not in res.stderr
+        assert res.stderr.count("bench.py needs an MI355X") == 2, res.stderr[-2000:]

@@ -152,3 +152,20 @@ def test_rccl_exchange_world_one_equals_single_device(transport):
     exch = _bench(["--force-exchange", "--backend", "nccl", "--transport", transport])
     assert exch["param_crc"] == plain["param_crc"]
     assert exch["interactions_timed"] == plain["interactions_timed"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launched():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the command the driver's SCALE run issues): bench.py starts its two ranks
+    itself through torch.distributed.run; they share cuda:0 here, so the collectives travel over gloo.  One JSON line, n_gpus 2,
+    a two-rank process group, and both replicas end with the same parameters (CRC-32 per array, gathered over the ranks)."""
+    env_drop = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_drop if k in os.environ}
+    try:
+        line = _bench(["--gpus", "2", "--backend", "gloo"])
+    finally:
+        os.environ.update(saved)
+    assert line["n_gpus"] == 2 and line["process_group_ranks"] == 2 and line["scaling"] == "weak"
+    assert len(line["ms_per_step_per_rank"]) == 2
+    assert line["param_crc_ranks"] == 2 and line["param_crc_ranks_equal"] is True
+    assert line["steps"] == 2 and line["interactions_timed"] > 0

@@ -461,3 +461,36 @@ def test_oracle_reproduces_committed_vectors(oracle_lib, name):
         assert a.dtype == b.dtype and a.shape == b.shape, (name, k)
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
                               b.view(np.uint32) if b.dtype == np.float32 else b), (name, k)
+
+
+@pytest.mark.parametrize("kind,loss,d", [(ModelKind.LSTM_NORMAL, LOSS_WARP, 32), (ModelKind.LSTM_COUPLED, LOSS_HINGE, 16), (ModelKind.EWMA, LOSS_HINGE, 64)])
+def test_sampled_step_checker_agrees_with_the_whole_step(oracle_lib, kind, loss, d):
+    """tests/sampled_parity.py is how the bench's own regime is compared with the oracle on the GPU (50 000 sequences per step:
+    the oracle cannot run the whole step).  Here the "full" side is a second oracle at a size it can run whole: the sampled
+    restatement — sequences packed alone with their full-minibatch counters, per-row optimiser steps from explicit entry lists,
+    dense-gradient elements as column chains — must reproduce the whole step's numbers bit for bit."""
+    from sampled_parity import check_first_step, count_subsequences
+
+    items, T, B = 211, 9, 700
+    ptr, it = synthetic_interactions(900, items, T + 4, seed=5, zipf=True)  # chunks: T + 4 > T; hot rows: > 256 entries per item
+    hp = hparams(items, T, d, int(kind), loss, B=B, epochs=1)
+    full_m, o = OracleModel(hp), OracleModel(hp)
+    pf, po = full_m.fit_begin(ptr, it), o.fit_begin(ptr, it)
+    assert pf.epoch_prepare() == po.epoch_prepare()
+
+    class Full:
+        model = full_m
+        rows = pf.minibatch_rows(0)
+
+        def step_local(self):
+            self.block = pf.step_local(0)
+
+        def fetch(self, which):
+            return pf.debug_fetch(which, self.rows)
+
+        def apply(self):
+            pf.step_apply(self.block)
+
+    nb = min(B, count_subsequences(ptr, T))
+    out = check_first_step(Full(), o, po, lstm=kind != ModelKind.EWMA, nb=nb, nsel=40, nrows=90, ndense=30)
+    assert out["sampled_sequences"] >= 30 and out["max_entries_per_item"] > 256  # the chunked hot-row reduction is exercised

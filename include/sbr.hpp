@@ -581,6 +581,10 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
         sbr_hparams hp;
         get(&hp, sizeof hp);
         if ((hp.model == SBR_MODEL_EWMA) != (expect_ewma != 0)) throw std::runtime_error("load: the file holds the other model type: " + path);
+        // a corrupt header must not size allocations or build replicas (sbr_model_create re-checks the rest)
+        if (hp.num_items == 0 || hp.embedding_dim == 0 || hp.embedding_dim > 256 || hp.num_devices == 0 || hp.num_devices > 16 ||
+            hp.device_rank != 0 || hp.batch_sequences == 0 || hp.max_sequence_length < 3 || hp.model < 0 || hp.model > 2)
+            throw std::runtime_error("load: implausible hyper-parameters in " + path);
         std::uint8_t part = 0;
         get(&part, 1);
         std::uint64_t epoch = 0, steps = 0;
@@ -590,10 +594,17 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
         replicas_ = std::make_unique<Replicas>(hp, part != 0);
         std::uint32_t nb = 0;
         get(&nb, 4);
+        if (nb > SBR_PARAM_EWMA_ALPHA_M + 1) throw std::runtime_error("load: implausible block count in " + path);
+        std::uint32_t seen = 0;
         for (std::uint32_t i = 0; i < nb; ++i) {
             std::int32_t which = 0;
-            std::uint64_t count = 0;
+            std::uint64_t count = 0, expect = 0;
             get(&which, 4); get(&count, 8);
+            // the engine says how many elements block `which` of THIS model has: a corrupt count never sizes an allocation
+            if (which < 0 || which > SBR_PARAM_EWMA_ALPHA_M || (seen >> which & 1u) ||
+                sbr_model_param_count(replicas_->primary(), which, &expect) != SBR_OK || expect == 0 || count != expect)
+                throw std::runtime_error("load: parameter block " + std::to_string(which) + " does not fit the model in " + path);
+            seen |= 1u << which;
             std::vector<float> v(count);
             get(v.data(), count * sizeof(float));
             const bool table = which == SBR_PARAM_ITEM_EMBEDDING || which == SBR_PARAM_ITEM_EMBEDDING_ACC || which == SBR_PARAM_ITEM_BIAS ||
@@ -602,6 +613,11 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
                 if (part && table && r > 0) continue;  // a partitioned table exists once: written through replica 0
                 check(sbr_model_set_param(replicas_->handles()[r], (sbr_param)which, v.data(), count), "sbr_model_set_param");
             }
+        }
+        for (std::int32_t which = 0; which <= SBR_PARAM_EWMA_ALPHA_M; ++which) {  // every non-empty block of the model must have been in the file
+            std::uint64_t expect = 0;
+            if (sbr_model_param_count(replicas_->primary(), which, &expect) == SBR_OK && expect != 0 && !(seen >> which & 1u))
+                throw std::runtime_error("load: parameter block " + std::to_string(which) + " is missing from " + path);
         }
         for (sbr_model* h : replicas_->handles()) {
             check(sbr_model_set_counters(h, epoch, steps), "sbr_model_set_counters");

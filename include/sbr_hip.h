@@ -154,7 +154,10 @@ sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* o
 sbr_status sbr_fit_sparse_stats(sbr_fit_plan* p, uint64_t* out_entries, uint64_t* out_unique_rows);
 void sbr_fit_plan_destroy(sbr_fit_plan* p);
 
-/* The two halves of a single-device step (sbr_fit_step = local + apply). */
+/* The two halves of a single-device step (sbr_fit_step = local + apply).  With one device sbr_fit_step_local COMMITS the
+ * minibatch's loss terms and example count to the plan's totals (sbr_fit_end / sbr_fit_counters) — the header launch that
+ * closes the scoring pass adds them — whether or not sbr_fit_step_apply follows; the exchange halves below do not count them a
+ * second time. */
 sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch);
 sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch);
 

@@ -8,7 +8,8 @@ import os
 from ._abi import ABI_VERSION, SbrHparams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsbr_hip.so")
+# SBR_HIP_LIB: another build of the same engine (kernel A/B experiments: tools/, profiles/); never a different implementation
+LIB_PATH = os.environ.get("SBR_HIP_LIB") or os.path.join(_HERE, "libsbr_hip.so")
 _lib = None
 
 

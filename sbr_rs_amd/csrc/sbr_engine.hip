@@ -85,6 +85,9 @@ void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<flo
     }
 }
 
+#ifndef SBR_EWMA_FUSED_DEFAULT
+#define SBR_EWMA_FUSED_DEFAULT 1
+#endif
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
 }  // namespace
@@ -1357,13 +1360,22 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         return SBR_OK;
     };
     if (early_sort) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
-    {
-        ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
-        sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
-    }
-    {
+    /* EWMA + single-negative loss (BASELINE configs[4]): scan and score in one pass per sequence, optionally the backward scan too
+     * (SBR_EWMA_FUSED = 0: three launches / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
+    static const char* ewma_env = std::getenv("SBR_EWMA_FUSED");
+    const int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? (ewma_env ? std::atoi(ewma_env) : SBR_EWMA_FUSED_DEFAULT) : 0;
+    if (ewma_fused) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
-        sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
+        sbr::launch_ewma_forward_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, ewma_fused >= 2, m->stream);
+    } else {
+        {
+            ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
+            sbr::launch_recurrent_forward(m->mv, mv, bv.H, p->wb.v, mb.Tm, off_host, m->stream);
+        }
+        {
+            ScopedTimer t(m, SBR_K_SCORE, 1);
+            sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
+        }
     }
     /* the figure the reference's fit returns (sbr_report.hip): a small step folds it into the header launch; otherwise the
      * per-sequence sums come from a parallel kernel here and the sequential chain over the sequences runs as one wave on the
@@ -1387,7 +1399,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const bool sort_first = place == SORT_PRE;
     if (!early_sort && sort_first) SBRCHK(launch_sort(sorter));
     if (!early_sort && place == SORT_OWN_STREAM) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
-    {
+    if (ewma_fused < 2) {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }
@@ -1536,7 +1548,10 @@ static sbr_status apply_dense_blocks(sbr_fit_plan* p, const void* device_dense_a
     const uint64_t db = (8 + dense_count(m)) * 4;
     const uint8_t* dall = reinterpret_cast<const uint8_t*>(device_dense_all);
     if (begins_step) begin_optimizer_step(m);
-    sbr::launch_accumulate_loss(dall, db, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    /* one device driven through the exchange halves (bench.py --force-exchange): step_local's header launch has already added
+     * this step to the plan's loss accumulators */
+    if (!(p->ndev == 1 && p->header_accumulated)) sbr::launch_accumulate_loss(dall, db, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    p->header_accumulated = false;
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
         sbr::launch_dense_apply(m->mv, dall, db, 32, p->ndev, m->stream);
@@ -2386,9 +2401,20 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     /* users per scoring launch: the rank GEMM streams the item table once per 128 users whatever the launch size, but every
      * launch has its ramp and tail — 8 192 users x 1e6 items at d = 128: 104 / 108 / 109 / 112 TFLOP/s at 1 024 / 2 048 /
      * 4 096 / 8 192 users per launch (SBR_EVAL_USERS overrides: the A/B switch) */
-    static const size_t EVAL_B = std::getenv("SBR_EVAL_USERS") ? (size_t)std::atoi(std::getenv("SBR_EVAL_USERS")) : 8192;
-    for (size_t c0 = 0; c0 < users.size(); c0 += EVAL_B) {
-        const size_t c1 = std::min(c0 + EVAL_B, users.size());
+    static const size_t EVAL_B = []() -> size_t {
+        const char* e = std::getenv("SBR_EVAL_USERS");
+        const long v = e ? std::atol(e) : 0;
+        return v >= 128 ? (size_t)v : 8192; /* unset, non-numeric or tiny: the default (a zero step would never advance) */
+    }();
+    /* the forward pass's scratch is (users x history steps) rows of 6d floats: bound a launch by rows as well */
+    const size_t eval_rows_cap = (size_t)1 << 22;
+    for (size_t c0 = 0, c1 = 0; c0 < users.size(); c0 = c1) {
+        size_t rows = 0;
+        for (c1 = c0; c1 < users.size() && c1 - c0 < EVAL_B; ++c1) {
+            const uint64_t nh = user_ptr[users[c1] + 1] - user_ptr[users[c1]] - 1;
+            rows += (size_t)std::min<uint64_t>(nh, T);
+            if (rows > eval_rows_cap && c1 > c0) break;
+        }
         const size_t nu = c1 - c0;
         std::vector<const uint32_t*> first(nu);
         std::vector<int> nsteps(nu);

@@ -402,6 +402,9 @@ __global__ __launch_bounds__(256) void ewma_forward_kernel(ModelView m, MbView m
 }
 
 template <int D>
+__device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int b, int n,
+                                                  int lg, const float (&a)[4], const float (&oma)[4]);
+template <int D>
 __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView mb, BlockView blk, WorkView w) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
@@ -414,68 +417,175 @@ __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView 
         a[j] = sbr_sigmoidf(m.alpha[4 * lg + j]);
         oma[j] = 1.0f - a[j];
     }
+    for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) ewma_backward_seq<D>(m, mb, blk, w, b, mb.steps[b], lg, a, oma);
+}
+
+// ------------------------------------------------------------------------------------------------
+// EWMA with a single-negative loss (hinge, BPR: BASELINE configs[4]) — ONE pass per sequence.
+// The scan does not depend on the scores and the negative of a single-negative loss is a hash of the row counter, so the lane
+// group that walks a sequence keeps s_t in registers, gathers x_t, the target row and the negative row of EWMA_U steps
+// together, scores each step against the s_t it has just formed (ewma.rs:302-335: the scan node and the two dot nodes of a
+// step) and writes H once — for the sparse update and the backward scan; the separate scan launch, its H round trip (write
+// 4d B + read 4d B per row) and the score pass's own index traffic are gone.  WHOLE = true continues with the backward scan of
+// the same sequence in the same lane group (ewma_backward_seq): its x / target / negative rows and its H rows were touched
+// moments ago by this very group, newest first in the order the backward scan wants them.
+// Same arithmetic, same bits as ewma_forward_kernel + score_single_kernel (+ ewma_backward_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int b, int n,
+                                                  int lg, const float (&a)[4], const float (&oma)[4]) {
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float da[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = n - 1; t0 >= 0; t0 -= EWMA_U) {  // EWMA_U steps' rows requested together, as in the forward scan
+        int r[EWMA_U], rp[EWMA_U];
+        uint32_t ii[EWMA_U], ni[EWMA_U], oi[EWMA_U];
+        float g[EWMA_U];
+        float4 x[EWMA_U], sp[EWMA_U], en[EWMA_U], ep[EWMA_U];
+#pragma unroll
+        for (int q = 0; q < EWMA_U; ++q) {
+            const int t = t0 - q >= 0 ? t0 - q : 0;
+            r[q] = mb.off[t] + b;
+            rp[q] = mb.off[t > 0 ? t - 1 : 0] + b;
+        }
+#pragma unroll
+        for (int q = 0; q < EWMA_U; ++q) {
+            ii[q] = mb.in_idx[r[q]];
+            ni[q] = blk.neg[r[q]];
+            oi[q] = blk.out_idx[r[q]];
+            g[q] = blk.coef[r[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < EWMA_U; ++q) {
+            x[q] = ld4(m.E + (size_t)ii[q] * D + 4 * lg);
+            sp[q] = ld4(blk.H + (size_t)rp[q] * D + 4 * lg);
+            en[q] = ld4(m.E + (size_t)ni[q] * D + 4 * lg);
+            ep[q] = ld4(m.E + (size_t)oi[q] * D + 4 * lg);
+        }
+#pragma unroll
+        for (int q = 0; q < EWMA_U; ++q) {
+            const int t = t0 - q;
+            if (t < 0) continue;
+            // dloss/dh: g*E[neg] - g*E[pos], two rounded products and one subtraction (dh_loss4)
+            float ds[4] = {g[q] * en[q].x - g[q] * ep[q].x, g[q] * en[q].y - g[q] * ep[q].y, g[q] * en[q].z - g[q] * ep[q].z,
+                           g[q] * en[q].w - g[q] * ep[q].w};
+            if (t != n - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
+            }
+            float4 dx;
+            if (t > 0) {
+                const float xs[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
+                const float sps[4] = {sp[q].x, sp[q].y, sp[q].z, sp[q].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = oma[j] * ds[j];
+                    carry[j] = a[j] * ds[j];
+                    da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+                }
+                dx = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+            }
+            st4(blk.dX + (size_t)r[q] * D + 4 * lg, dx);
+        }
+    }
+    st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
+}
+
+template <int D, bool WHOLE>
+__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    float a[4], oma[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = sbr_sigmoidf(m.alpha[4 * lg + j]);
+        oma[j] = 1.0f - a[j];
+    }
+    double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
+    unsigned int tries_part = 0;
     for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) {
         const int n = mb.steps[b];
-        float carry[4] = {0.f, 0.f, 0.f, 0.f};
-        float da[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int t0 = n - 1; t0 >= 0; t0 -= EWMA_U) {  // EWMA_U steps' rows requested together, as in the forward scan
-            int r[EWMA_U], rp[EWMA_U];
-            uint32_t ii[EWMA_U], ni[EWMA_U], oi[EWMA_U];
-            float g[EWMA_U];
-            float4 x[EWMA_U], sp[EWMA_U], en[EWMA_U], ep[EWMA_U];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t0 = 0; t0 < n; t0 += EWMA_U) {
+            int r[EWMA_U];
+            uint32_t it[EWMA_U], pi[EWMA_U], cand[EWMA_U];
+            float4 x[EWMA_U], ep[EWMA_U], ec[EWMA_U];
+            float bp[EWMA_U], bc[EWMA_U];
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) r[q] = mb.off[t0 + q < n ? t0 + q : n - 1] + b;
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
-                const int t = t0 - q >= 0 ? t0 - q : 0;
-                r[q] = mb.off[t] + b;
-                rp[q] = mb.off[t > 0 ? t - 1 : 0] + b;
+                it[q] = mb.in_idx[r[q]];
+                pi[q] = mb.out_idx[r[q]];
+                cand[q] = sbr_neg_draw(epoch_key, mb.ctr[r[q]], 0u, m.num_items);
             }
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
-                ii[q] = mb.in_idx[r[q]];
-                ni[q] = blk.neg[r[q]];
-                oi[q] = blk.out_idx[r[q]];
-                g[q] = blk.coef[r[q]];
+                x[q] = ld4(m.E + (size_t)it[q] * D + 4 * lg);
+                ep[q] = ld4(m.E + (size_t)pi[q] * D + 4 * lg);
+                bp[q] = m.b[pi[q]];
+                ec[q] = ld4(m.E + (size_t)cand[q] * D + 4 * lg);
+                bc[q] = m.b[cand[q]];
             }
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
-                x[q] = ld4(m.E + (size_t)ii[q] * D + 4 * lg);
-                sp[q] = ld4(blk.H + (size_t)rp[q] * D + 4 * lg);
-                en[q] = ld4(m.E + (size_t)ni[q] * D + 4 * lg);
-                ep[q] = ld4(m.E + (size_t)oi[q] * D + 4 * lg);
-            }
-#pragma unroll
-            for (int q = 0; q < EWMA_U; ++q) {
-                const int t = t0 - q;
-                if (t < 0) continue;
-                // dloss/dh: g*E[neg] - g*E[pos], two rounded products and one subtraction (dh_loss4)
-                float ds[4] = {g[q] * en[q].x - g[q] * ep[q].x, g[q] * en[q].y - g[q] * ep[q].y, g[q] * en[q].z - g[q] * ep[q].z,
-                               g[q] * en[q].w - g[q] * ep[q].w};
-                if (t != n - 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
-                }
-                float4 dx;
-                if (t > 0) {
-                    const float xs[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
-                    const float sps[4] = {sp[q].x, sp[q].y, sp[q].z, sp[q].w};
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = oma[j] * ds[j];
-                        carry[j] = a[j] * ds[j];
-                        da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+                if (t0 + q < n) {
+                    if (t0 + q == 0) {
+                        s = x[q];
+                    } else {
+                        s.x = sbr_fma(a[0], s.x, oma[0] * x[q].x);
+                        s.y = sbr_fma(a[1], s.y, oma[1] * x[q].y);
+                        s.z = sbr_fma(a[2], s.z, oma[2] * x[q].z);
+                        s.w = sbr_fma(a[3], s.w, oma[3] * x[q].w);
                     }
-                    dx = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-                    dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                    st4(blk.H + (size_t)r[q] * D + 4 * lg, s);
+                    const float pos = bp[q] + group_allreduce<L>(dot4(s, ep[q]));
+                    const float neg = bc[q] + group_allreduce<L>(dot4(s, ec[q]));
+                    float g, l;
+                    if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
+                    else l = sbr_loss_hinge(pos, neg, &g);
+                    if (lg == 0) {
+                        blk.neg[r[q]] = cand[q];
+                        blk.coef[r[q]] = g;
+                        blk.in_idx[r[q]] = it[q];
+                        blk.out_idx[r[q]] = pi[q];
+                        w.loss[r[q]] = l;
+                        w.tries[r[q]] = 1u;
+                        loss_part += (double)l;
+                        tries_part += 1u;
+                    }
                 }
-                st4(blk.dX + (size_t)r[q] * D + 4 * lg, dx);
             }
         }
-        st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
+        if constexpr (WHOLE) {
+            /* lane 0's stores to blk.neg / coef / out_idx are read back by the whole group below */
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            ewma_backward_seq<D>(m, mb, blk, w, b, n, lg, a, oma);
+        }
+    }
+    __shared__ double s_loss[4];
+    __shared__ unsigned int s_tries[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        loss_part += __shfl_xor(loss_part, off, 64);
+        tries_part += __shfl_xor(tries_part, off, 64);
+    }
+    if (lane == 0) {
+        s_loss[threadIdx.x >> 6] = loss_part;
+        s_tries[threadIdx.x >> 6] = tries_part;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
     }
 }
 
@@ -2713,6 +2823,18 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                                    epoch_key);
         });
     }
+}
+
+/* EWMA + single-negative loss: scan and score in one pass per sequence (ewma_seq_kernel); whole = the backward scan too.  The
+ * grid is launch_score's, so that launch_block_header finds the same number of loss partials. */
+void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                               int rows_host, bool whole, hipStream_t s) {
+    if (rows_host <= 0) return;
+    DISPATCH_D(m.d, {
+        const int grid = score_grid(DD, rows_host, true);
+        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+    });
 }
 
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s) {

@@ -35,7 +35,9 @@
 /* ---- fixed constants of the contract ------------------------------------------------------ */
 #define SBR_WARP_MAX_TRIES 5            /* sequence_model.rs:58 */
 #define SBR_ADAGRAD_EPS 1e-10f          /* wyrm Adagrad eps (recalled) */
+#ifndef SBR_DW_CHUNK_ROWS               /* (overridable for TIMING experiments only: another value is another contract) */
 #define SBR_DW_CHUNK_ROWS 1024          /* split-K chunk (rows of the packed minibatch) for dense grads */
+#endif
 /* Per-row reduction of sparse gradient entries: a row's entries (sorted by packed row, kind) are cut into
  * chunks of SBR_SEG_CHUNK counted from the row's first entry; a chunk partial is the in-order sum of its
  * entries (the first one initialises), the row total the in-order sum of the chunk partials.  A row with

@@ -42,6 +42,13 @@ constexpr int SORT_ITEMS_FINE = 8;             // ... or 512-key tiles while the
 constexpr uint32_t SORT_FINE_MAX_N = 1u << SBR_SORT_FINE_MAX_LOG2;
 constexpr int SORT_BATCH = 8;                  // keys per lane requested together
 constexpr int SORT_MAX_DIGIT_BITS = 11;
+/* wave priority of the ordering's kernels (s_setprio 0..3): they run on their own stream underneath BPTT, whose MFMA waves are
+ * older and win the issue arbitration of every SIMD (MI355X_MICROARCH.md "VALU issue is arbitrated ... by priority, then age") —
+ * a ~0.1 ms job then takes the whole backward pass.  A/B: profiles/r04_tail_experiments.md */
+#ifndef SBR_SORT_SETPRIO
+#define SBR_SORT_SETPRIO 0
+#endif
+#define SORT_PRIO() do { if (SBR_SORT_SETPRIO) __builtin_amdgcn_s_setprio(SBR_SORT_SETPRIO); } while (0)
 constexpr int SORT_WAVES = 4;                  // wave-tiles per workgroup
 
 struct PassPlan {
@@ -103,6 +110,11 @@ struct SrcMerge {  // partitioned table: (row, device, position) of every list h
     }
 };
 
+// LDS traffic between the lanes of ONE wave (a bin's running offset: every lane of a digit group reads it, the group's highest
+// lane updates it, the next round reads it again): the hardware executes a wave's LDS instructions in order, so no barrier is
+// needed — but the compiler must keep the program order and may not cache the value in a register across the round
+__device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -116,6 +128,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
                                                                      uint32_t* __restrict__ counts) {
+    SORT_PRIO();
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, ui
 // one wave per bin: exclusive scan of the bin's tile counts (in place) and the bin total
 __global__ __launch_bounds__(256) void radix_binscan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t nb,
                                                             uint32_t* __restrict__ bintotal) {
+    SORT_PRIO();
     const int lane = threadIdx.x & 63;
     const uint32_t bin = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (bin >= nb) return;
@@ -173,6 +187,7 @@ template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
                                                                         const uint32_t* __restrict__ counts,
                                                                         const uint32_t* __restrict__ bintotal, uint64_t* __restrict__ out) {
+    SORT_PRIO();
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src,
                 out[pos] = k[j];
                 if ((same >> lane) == 1ull) h[d] += (uint32_t)__popcll(same);  // the group's highest lane, after every lane's read
             }
+            wave_lds_order();  // the next round's h[d] reads must see this write: one wave, LDS in program order, compiler fenced
         }
     }
 }
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src,
 template <bool WRITE, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void head_tiles_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t ntiles,
                                                                      uint32_t* __restrict__ tile_heads, uint32_t* __restrict__ head_pos) {
+    SORT_PRIO();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t tile = blockIdx.x * SORT_WAVES + wave;
     if (tile >= ntiles) return;
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void head_tiles_kernel(const uint6
 // exclusive scan of the tiles' head counts (in place), the head count and the sentinel head_pos[nheads] = n
 __global__ __launch_bounds__(1024) void head_scan_kernel(uint32_t* __restrict__ tile_heads, uint32_t ntiles, uint32_t n,
                                                          uint32_t* __restrict__ nheads, uint32_t* __restrict__ head_pos) {
+    SORT_PRIO();
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -347,6 +365,7 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void small_sort_kernel(Src src, u
                 to[h[wave][d] + (uint32_t)__popcll(same & lt)] = k;
                 if ((same >> lane) == 1ull) h[wave][d] += (uint32_t)__popcll(same);
             }
+            wave_lds_order();
         }
         __syncthreads();
         uint64_t* t = from; from = to; to = t;

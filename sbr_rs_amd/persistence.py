@@ -94,14 +94,17 @@ def load_model(path: str):
     z = np.load(_npz_path(path))
     world = int(z["hp_num_devices"].item())
     partitioned = "partitioned" in z.files and int(z["partitioned"].item()) == 1
-    if launched and world > 1:
-        if dist.get_world_size() != world:
-            raise ValueError(f"the model was saved with num_threads = {world}; the process group has {dist.get_world_size()} ranks")
+    if launched and world > 1 and dist.get_world_size() == world:
+        # (a process group of another size — e.g. one left over from something else — loads the replicas in this process, below)
         rank = dist.get_rank()  # one process per GPU: every rank restores ITS replica
         if partitioned:
             from .partitioned import create_partitioned_model
 
-            eng = _restore_into(create_partitioned_model(_hparams_of(z, rank)), z, table=True)
+            # the table exists once and is mapped by every rank: rank 0 alone writes its blocks, and nobody returns (and
+            # starts reading rows) before that write has finished
+            eng = _restore_into(create_partitioned_model(_hparams_of(z, rank)), z, table=rank == 0)
+            eng.synchronize()
+            dist.barrier()
         else:
             eng = load_engine(path, device_rank=rank)
         return (ImplicitEWMAModel if int(eng.hp.model) == 2 else ImplicitLSTMModel)(eng)

@@ -117,14 +117,76 @@ def measured_traffic(which, rows_per_launch, k_mean, d, items=None):
     return None, None
 
 
+def live_traffic(kernel, warmup_dispatches, timeout_s=240):
+    """HBM bytes per launch of `kernel` at THIS run's operating point, measured now: two rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, only --kernel-trace beside them — MI355X_MICROARCH.md "HBM") around a child run of this
+    command line (same workload, batch, steps; extras off), the timed dispatches only.  Corrections as calibrated in
+    profiles/r03_counter_calibration.md: both counters in KiB; FETCH_SIZE counts half of every coalesced read and of 512-byte
+    row gathers; an isolated 4-byte bias read may be counted as a whole 64-byte sector (not halved): upper = (2 F + W) KiB,
+    lower = upper - 64 B x (1 + k) x rows.  Returns a dict, or None if rocprofv3 is missing / a pass fails."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_dispatches import per_dispatch
+
+    tmp = tempfile.mkdtemp(prefix="sbr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    drop = {"--traffic"}
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a in drop:
+            skip = True
+            continue
+        if a.startswith("--traffic="):
+            continue
+        argv.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + argv + ["--traffic", "off", "--no-cpu-baseline", "--no-mrr", "--batch-sweep=",
+                                                                  "--standalone-steps", "0", "--cold-items", "0"]
+    vals, line = {}, None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            res = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "run", "--"] + child, cwd="/tmp", env=env,
+                                 capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if res.returncode != 0 or not dbs:
+                return None
+            vals[counter] = per_dispatch(dbs[0], counter, kernel)[warmup_dispatches:]
+            line = json.loads([x for x in res.stdout.splitlines() if x.startswith('{"metric"')][-1])
+        n = min(len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"]))
+        if n == 0 or not line or not line.get("roofline"):
+            return None
+        f, w = sum(vals["FETCH_SIZE"][:n]) / n, sum(vals["WRITE_SIZE"][:n]) / n
+        roof = line["roofline"]
+        up = (2.0 * f + w) * 1024.0
+        return {"hbm_bytes_per_launch": up, "hbm_bytes_per_launch_lower": up - 64.0 * (1 + roof["mean_negatives_scored"]) * roof["rows_per_launch"],
+                "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "dispatches_averaged": n, "rows_per_launch": roof["rows_per_launch"],
+                "mean_negatives_scored": roof["mean_negatives_scored"], "kernel": kernel}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(args, model_kind=0, loss_kind=2):
     """The oracle (kind "port") in the REFERENCE'S PARALLEL SHAPE on the host (sequence_model.rs:90-102): the subsequences of a
     bounded sample of the same generator are cut into one partition per worker thread, every worker runs on ONE shared
     parameter set (Arc<HogwildParameter>, lstm.rs:175-181) and takes one optimiser step per subsequence (the reference's
     schedule, :111-169).  Workers = every host core (the reference's default, lstm.rs:68); both of its parallelism modes are
     timed — Asynchronous = Hogwild, no locks (mod.rs:36-38), and Synchronous = rendezvous + one update at a time
-    (mod.rs:39-40, sequence_model.rs:163-166) — beside the single-thread figure (num_threads(1), lstm.rs:462).  Each leg is
-    bounded by --cpu-seconds of wall time; `value` is the faster all-core mode.  Thread timing orders the updates: a throughput
+    (mod.rs:39-40, sequence_model.rs:163-166) — beside the single-thread figure (num_threads(1), lstm.rs:462) and two
+    intermediate Hogwild worker counts (the scaling curve: every worker's dense Adagrad step rewrites the same 1 MB of LSTM weights,
+    so the shared-parameter shape stops scaling long before the core count).  Each leg is bounded by --cpu-seconds of wall time;
+    `value` is the faster all-core mode.  Thread timing orders the updates: a throughput
     baseline, not a parity run."""
     from oracle.oracle import OracleModel
 
@@ -135,7 +197,9 @@ def cpu_baseline(args, model_kind=0, loss_kind=2):
     hp = make_hp(args, 1, 0, model_kind, loss_kind, args.items, epochs=1_000_000, batch=1)  # bounded by time, not by epochs
     m = OracleModel(hp)  # ONE model: the three legs continue training the same shared parameters
     legs = {}
-    for name, w, sync in (("single_thread", 1, True), ("all_cores_hogwild", workers, False), ("all_cores_synchronous", workers, True)):
+    plan = [("single_thread", 1, True)] + [(f"hogwild_{w}_threads", w, False) for w in (16, 64) if w < workers] + \
+           [("all_cores_hogwild", workers, False), ("all_cores_synchronous", workers, True)]
+    for name, w, sync in plan:
         rows, secs, _loss = m.fit_threads(ptr, items, w, sync, args.cpu_seconds)
         legs[name] = {"interactions_per_s": rows / secs, "interactions": rows, "seconds": secs, "workers": w}
     best = max(("all_cores_hogwild", "all_cores_synchronous"), key=lambda k: legs[k]["interactions_per_s"])
@@ -371,7 +435,7 @@ def main():
                     help="worker threads of the CPU baseline (0 = every host core, the reference's default num_threads, lstm.rs:68); "
                          "all of them share ONE model")
     ap.add_argument("--cpu-users", type=int, default=100_000, help="users in the CPU-baseline sample (capped at --users)")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-time bound of each of the three CPU-baseline legs")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall-time bound of each CPU-baseline leg (1, 16, 64 and all threads)")
     ap.add_argument("--standalone-steps", type=int, default=6,
                     help="extra untimed steps with stream overlap disabled, for standalone per-kernel times (0 = skip)")
     ap.add_argument("--cold-items", type=int, default=4_000_000,
@@ -383,6 +447,11 @@ def main():
                          "and bytes per link instead of the throughput line's usual extras")
     ap.add_argument("--batch-sweep", type=str, default="1024,4096,8192,16384",
                     help="extra batch sizes measured untimed after the main run (reported with the main one as batch_sweep); '' = skip")
+    ap.add_argument("--traffic", choices=["live", "profile", "off"], default="live",
+                    help="roofline.traffic (HBM bytes per launch of the gather + score kernel): live = measured in this very invocation by "
+                         "two rocprofv3 PMC passes around a child run at the same operating point (N = 1; falls back to `profile` if "
+                         "rocprofv3 is unavailable); profile = the committed profile of the same operating point "
+                         "(profiles/score_kernel_traffic.json) or null; off = null")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mrr", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -583,7 +652,7 @@ def main():
                 cptr, citems = synthetic_csr(args.users, args.cold_items, args.max_len)
                 _, sc_ms, rpl, kc, _ = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.cold_items), cptr, citems, 3, 1)
                 cb = ((2 + kc) * 4 * args.dim + (1 + kc) * 4) * rpl
-                ct, ctl = measured_traffic("cold", rpl, kc, args.dim) if args.cold_items == 4_000_000 else (None, None)
+                ct, ctl = measured_traffic("cold", rpl, kc, args.dim, args.cold_items)
                 cold = {"items": args.cold_items, "table_bytes": args.cold_items * args.dim * 4, "avg_launch_ms": sc_ms,
                         "mean_negatives_scored": kc, "algorithmic_bytes_per_launch": cb, "traffic": ct, "traffic_lower": ctl,
                         "achieved": cb / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -659,11 +728,29 @@ def main():
             # HBM bytes per launch MEASURED for this very configuration: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
             # runs) around the default bench command, the timed dispatches only, corrected per profiles/r03_counter_calibration.md;
             # printed only when this run's rows per launch and mean k are within 5 % of the profiled run's, else null
-            traffic, traffic_lower = measured_traffic("warm", rows_per_launch, k_mean, d)
-            roofline = {"kernel": "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)", "bound": "hbm",
+            traffic = traffic_lower = None
+            traffic_source = None
+            pmc_kernel = "ewma_seq_kernel" if model_kind == 2 and loss_kind != 2 else "score_kernel" if loss_kind == 2 else "score_single_kernel"
+            if args.traffic == "live" and world == 1 and not args.force_exchange:
+                lt = live_traffic(pmc_kernel, args.warmup)
+                # the child's operating point must be this run's (same command line): rows per launch and negatives per row within 5 %
+                if lt and abs(lt["rows_per_launch"] / max(rows_per_launch, 1) - 1) <= 0.05 and abs(lt["mean_negatives_scored"] / max(k_mean, 1e-9) - 1) <= 0.05:
+                    traffic, traffic_lower = lt["hbm_bytes_per_launch"], lt["hbm_bytes_per_launch_lower"]
+                    traffic_source = (f"measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) around a child run of "
+                                      f"the same command line, the {lt['dispatches_averaged']} timed dispatches of {pmc_kernel}; FETCH_SIZE {lt['FETCH_SIZE_KiB_mean']:.0f} KiB, "
+                                      f"WRITE_SIZE {lt['WRITE_SIZE_KiB_mean']:.0f} KiB per launch; bytes = (2 F + W) x 1024, lower figure = minus 64 B per bias read "
+                                      "(profiles/r03_counter_calibration.md)")
+            if traffic is None and args.traffic != "off":
+                traffic, traffic_lower = measured_traffic("warm", rows_per_launch, k_mean, d, args.items)
+                traffic_source = "profiles/score_kernel_traffic.json (PMC passes of the same command at this operating point; interval: profiles/r03_counter_calibration.md)" if traffic else None
+            kname = ("ewma_seq_kernel (EWMA scan + gather + negative + loss in one pass per sequence; x_t replaces the h_t read, h_t is written "
+                     "once on top of the priced bytes; sbr_kernels.hip)" if model_kind == 2 and loss_kind != 2 else
+                     "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)" if loss_kind == 2 else
+                     "score_single_kernel (gather + negative + loss, sbr_kernels.hip)")
+            roofline = {"kernel": kname, "bound": "hbm",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_lower": traffic_lower,
-                        "traffic_source": "profiles/score_kernel_traffic.json (PMC, same command; interval: profiles/r03_counter_calibration.md)" if traffic else None,
+                        "traffic_source": traffic_source, "traffic_over_algorithmic": [traffic_lower / bytes_per_launch, traffic / bytes_per_launch] if traffic else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
                         "avg_launch_ms": score["ms_per_launch"]}

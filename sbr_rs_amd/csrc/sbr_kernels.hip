@@ -141,11 +141,17 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // K1+K3+K4: gather + negative sampling + loss + dloss/dh  (the HBM-roofline kernel)
 // One d/4-lane group per packed row; 16 B per lane per gathered embedding row.
 // ------------------------------------------------------------------------------------------------
-template <int D>
+// U rows per lane group are in flight together (their retry rounds in lockstep).  U = 1 at large launches: the kernel is
+// bandwidth-bound there and extra rows per group only add retry rounds (a group runs max-over-its-rows rounds; 0.72 -> 0.76 ms at
+// 50 000 sequences per step with U = 2, round 2).  U = 2 at small launches (the quality-neutral 8 192 sequences per step =
+// 256 K rows): a wave then walks ~18 passes of ~1.75 dependent memory round trips each and the kernel is THEIR LATENCY, not the
+// bytes — half the passes with twice the rows in flight.  Same arithmetic per row, same bits.
+template <int D, int U>
 __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
                                                     uint64_t epoch_key) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
+    constexpr int RPW = GPW * U;  // rows per wave and pass
     const int lane = threadIdx.x & 63;
     const int lg = lane % L;
     const int grp = lane / L;
@@ -156,58 +162,100 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
     const bool spread = L >= 8 && max_tries > 1;
     double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
     unsigned int tries_part = 0;
-    for (int base = wave * GPW; base < mb.R; base += nwaves * GPW) {
-        const int r = base + grp;
-        const bool valid = r < mb.R;
-        const int rr = valid ? r : mb.R - 1;
-        const float4 h = ld4(blk.H + (size_t)rr * D + 4 * lg);
-        const uint32_t pi = mb.out_idx[rr];
-        const uint32_t ctr = mb.ctr[rr];
-        const float4 ep = ld4(m.E + (size_t)pi * D + 4 * lg);
-        const float bp = m.b[pi];
-        // WARP: lane lg of the group draws candidate lg & 7 — the five draws of the row cost one evaluation of the
-        // 64-bit hash instead of one per try (every lane would compute the same value); try k reads lane k's
-        uint32_t draws = sbr_neg_draw(epoch_key, ctr, spread ? (uint32_t)(lg & 7) : 0u, m.num_items);
-        // first candidate is always scored: issue its gather together with the positive's
-        uint32_t cand = spread ? (uint32_t)__shfl((int)draws, grp * L, 64) : draws;
-        float4 ec = ld4(m.E + (size_t)cand * D + 4 * lg);
-        float bc = m.b[cand];
-        const float pos = bp + group_allreduce<L>(dot4(h, ep));
-        bool done = false;
-        uint32_t nj = 0, tries = 0;
-        float neg = 0.0f;
+    // Software pipeline over the passes of a wave: the ids, the counter and the h row of the NEXT pass are requested while this
+    // pass's table rows are in flight, so a pass starts with its positive and first candidate rows already addressable — one
+    // dependent memory round trip fewer per pass.
+    const int last_row = mb.R - 1;
+    int base = wave * RPW;
+    uint32_t pi_n[U], ctr_n[U];
+    float4 h_n[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int r0 = base + u * GPW + grp;
+        const int rr0 = r0 < mb.R ? r0 : last_row;
+        pi_n[u] = mb.out_idx[rr0];
+        ctr_n[u] = mb.ctr[rr0];
+        h_n[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+    }
+    for (; base < mb.R; base += nwaves * RPW) {
+        float4 h[U], ep[U], ec[U];
+        uint32_t pi[U], ctr[U], draws[U], cand[U], nj[U], tries[U];
+        float bp[U], bc[U], pos[U], neg[U];
+        bool done[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            h[u] = h_n[u];
+            pi[u] = pi_n[u];
+            ctr[u] = ctr_n[u];
+            ep[u] = ld4(m.E + (size_t)pi[u] * D + 4 * lg);
+            bp[u] = m.b[pi[u]];
+            // WARP: lane lg of the group draws candidate lg & 7 — the five draws of the row cost one evaluation of the
+            // 64-bit hash instead of one per try (every lane would compute the same value); try k reads lane k's
+            draws[u] = sbr_neg_draw(epoch_key, ctr[u], spread ? (uint32_t)(lg & 7) : 0u, m.num_items);
+            // first candidate is always scored: issue its gather together with the positive's
+            cand[u] = spread ? (uint32_t)__shfl((int)draws[u], grp * L, 64) : draws[u];
+            ec[u] = ld4(m.E + (size_t)cand[u] * D + 4 * lg);
+            bc[u] = m.b[cand[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // the next pass's ids and h rows (clamped: the request count does not depend on the pass)
+            const int rn = base + nwaves * RPW + u * GPW + grp;
+            const int rrn = rn < mb.R ? rn : last_row;
+            pi_n[u] = mb.out_idx[rrn];
+            ctr_n[u] = mb.ctr[rrn];
+            h_n[u] = ld4(blk.H + (size_t)rrn * D + 4 * lg);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pos[u] = bp[u] + group_allreduce<L>(dot4(h[u], ep[u]));
+            done[u] = false;
+            nj[u] = 0;
+            tries[u] = 0;
+            neg[u] = 0.0f;
+        }
         for (int k = 0; k < max_tries; ++k) {
             if (k > 0) {
-                if (__all(done)) break;
-                cand = spread ? (uint32_t)__shfl((int)draws, grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr, (uint32_t)k, m.num_items);
-                if (!done) {
-                    ec = ld4(m.E + (size_t)cand * D + 4 * lg);
-                    bc = m.b[cand];
+                bool all_done = true;
+#pragma unroll
+                for (int u = 0; u < U; ++u) all_done = all_done && done[u];
+                if (__all(all_done)) break;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cand[u] = spread ? (uint32_t)__shfl((int)draws[u], grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr[u], (uint32_t)k, m.num_items);
+                    if (!done[u]) {
+                        ec[u] = ld4(m.E + (size_t)cand[u] * D + 4 * lg);
+                        bc[u] = m.b[cand[u]];
+                    }
                 }
             }
-            const float s = bc + group_allreduce<L>(dot4(h, ec));
-            if (!done) {
-                nj = cand;
-                neg = s;
-                ++tries;
-                if (sbr_warp_violates(pos, s)) done = true;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float sc = bc[u] + group_allreduce<L>(dot4(h[u], ec[u]));
+                if (!done[u]) {
+                    nj[u] = cand[u];
+                    neg[u] = sc;
+                    ++tries[u];
+                    if (sbr_warp_violates(pos[u], sc)) done[u] = true;
+                }
             }
         }
-        float g, l;
-        if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
-        else l = sbr_loss_hinge(pos, neg, &g);
-        if (valid) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = base + u * GPW + grp;
+            float g, l;
+            if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos[u], neg[u], &g);
+            else l = sbr_loss_hinge(pos[u], neg[u], &g);
             // dloss/dh = g (E[neg] - E[pos]) is not written here: the backward kernels re-form it
             // from (neg, coef) with two row gathers, which keeps this kernel read-only on the table
-            if (lg == 0) {
-                blk.neg[r] = nj;
+            if (r < mb.R && lg == 0) {
+                blk.neg[r] = nj[u];
                 blk.coef[r] = g;
                 blk.in_idx[r] = mb.in_idx[r];
-                blk.out_idx[r] = pi;
+                blk.out_idx[r] = pi[u];
                 w.loss[r] = l;
-                w.tries[r] = tries;
+                w.tries[r] = tries[u];
                 loss_part += (double)l;
-                tries_part += tries;
+                tries_part += tries[u];
             }
         }
     }
@@ -1799,8 +1847,9 @@ __global__ __launch_bounds__(256, SBR_DW_WPE) void lstm_dw_full_kernel(ModelView
     // row (prev_row = -1) becomes an out-of-range offset, which reads as zeros.  Needs a 128-column tile to lie entirely
     // in the x or in the h half (D >= 128) and H below 2 GiB; otherwise the 64-bit per-lane addresses below.
     const bool small_h = !w.wide_addresses && (size_t)mb.R * D * 4 < ((size_t)1 << 31);  // byte offsets into H stay positive ints
-    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(w.dZ + (size_t)r0 * NGD), (short)0, SBR_DW_CHUNK_ROWS * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
     const int xrows = mb.R - r0 < SBR_DW_CHUNK_ROWS ? mb.R - r0 : SBR_DW_CHUNK_ROWS;
+    // the resources of X and dZ end at the chunk's last LIVE row: rows past R are out of range and read as zeros (no clearing launch)
+    const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)(w.dZ + (size_t)r0 * NGD), (short)0, xrows * NGD * 4, SBR_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rsXc = __builtin_amdgcn_make_buffer_rsrc((void*)(w.X + (size_t)r0 * D), (short)0, xrows * D * 4, SBR_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)blk.H, (short)0, small_h ? (int)((size_t)mb.R * D * 4) : 0, SBR_BUFFER_RSRC_FLAGS);
     auto fetch = [&](int slab) {
@@ -2807,8 +2856,18 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
 }
 
 #define SBR_SCORE_SINGLE_U 4 /* rows per lane group and pass of score_single_kernel */
+/* WARP: rows per lane group in flight — two below this many packed rows per launch (latency-bound launches), one above
+ * (bandwidth-bound; SBR_SCORE_U = 1 / 2 forces one form: the tests run both) */
+#ifndef SBR_SCORE_U2_MAX_ROWS
+#define SBR_SCORE_U2_MAX_ROWS 700000
+#endif
+static int score_warp_u(int rows) {
+    const char* e = std::getenv("SBR_SCORE_U"); /* read per call */
+    if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
+    return rows < SBR_SCORE_U2_MAX_ROWS ? 2 : 1;
+}
 static int score_grid(int d, int rows, bool single_negative) {
-    const int gpb = 4 * (64 / (d / 4)) * (single_negative ? SBR_SCORE_SINGLE_U : 1);  // rows per workgroup and pass
+    const int gpb = 4 * (64 / (d / 4)) * (single_negative ? SBR_SCORE_SINGLE_U : score_warp_u(rows));  // rows per workgroup and pass
     return grid_for_groups(rows, gpb);
 }
 
@@ -2816,8 +2875,12 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                   int rows_host, hipStream_t s) {
     if (rows_host > 0) {
         DISPATCH_D(m.d, {
-            if (m.loss == SBR_LOSS_WARP)
-                hipLaunchKernelGGL((score_kernel<DD>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+            if (m.loss == SBR_LOSS_WARP) {
+                if (score_warp_u(rows_host) == 2)
+                    hipLaunchKernelGGL((score_kernel<DD, 2>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                else
+                    hipLaunchKernelGGL((score_kernel<DD, 1>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+            }
             else
                 hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
                                    epoch_key);
@@ -2953,8 +3016,10 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
     if (!block_form) DISPATCH_D(m.d, {
         const unsigned grid = (unsigned)(((nch + 7) / 8) * tiles * 8); /* chunk groups of 8 (one chunk per XCD) x tiles */
         constexpr bool full4 = (2 * DD) % 128 == 0 && (4 * DD) % 128 == 0, full3 = (2 * DD) % 128 == 0 && (3 * DD) % 128 == 0;
-        /* the full-tile kernel reads dZ up to the end of the last chunk: those rows are cleared here */
-        const size_t pad_rows = (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
+        /* the full-tile kernel reads dZ up to the end of the last chunk: through buffer resources (d >= 128, H below 2 GiB) those rows
+         * are out of range and read as zeros; on its 64-bit address path they are cleared here */
+        const bool buffer_path = DD >= 128 && !w.wide_addresses && (size_t)rows_host * DD * 4 < ((size_t)1 << 31);
+        const size_t pad_rows = buffer_path ? 0 : (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
         /* SBR_DW_LDS_PAD: extra dynamic LDS per workgroup = a cap on the kernel's residency (20 KB static: 32 KB more leave
          * three workgroups per CU instead of four, and room for the sparse update's waves beside them) */
         static const int lds_pad = std::getenv("SBR_DW_LDS_PAD") ? std::atoi(std::getenv("SBR_DW_LDS_PAD")) : 0;

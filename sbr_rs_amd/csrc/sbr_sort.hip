@@ -46,7 +46,7 @@ constexpr int SORT_MAX_DIGIT_BITS = 11;
  * older and win the issue arbitration of every SIMD (MI355X_MICROARCH.md "VALU issue is arbitrated ... by priority, then age") —
  * a ~0.1 ms job then takes the whole backward pass.  A/B: profiles/r04_tail_experiments.md */
 #ifndef SBR_SORT_SETPRIO
-#define SBR_SORT_SETPRIO 0
+#define SBR_SORT_SETPRIO 1
 #endif
 #define SORT_PRIO() do { if (SBR_SORT_SETPRIO) __builtin_amdgcn_s_setprio(SBR_SORT_SETPRIO); } while (0)
 constexpr int SORT_WAVES = 4;                  // wave-tiles per workgroup

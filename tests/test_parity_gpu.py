@@ -129,9 +129,13 @@ def test_d256_bptt_both_forms(monkeypatch, kind, loss, min_tiles):
     assert_params_equal(g, o, kind, "after the step")
 
 
-def test_warp_retry_loop_all_trip_counts():
+@pytest.mark.parametrize("rows_per_group", ["1", "2", None])
+def test_warp_retry_loop_all_trip_counts(monkeypatch, rows_per_group):
     """sample_warp_negative (sequence_model.rs:47-68): every trip count 1..5 occurs, including
-    rows where no candidate violates and the 5th draw is used anyway."""
+    rows where no candidate violates and the 5th draw is used anyway.  Both forms of the score kernel: one row per lane
+    group in flight (bandwidth-bound launches) and two, their retry rounds in lockstep (latency-bound launches)."""
+    if rows_per_group:
+        monkeypatch.setenv("SBR_SCORE_U", rows_per_group)
     items, d, T = 400, 64, 24
     ptr, it = synthetic_interactions(80, items, T, seed=31)
     for kind in (ModelKind.EWMA, ModelKind.LSTM_NORMAL):

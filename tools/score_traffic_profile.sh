@@ -21,7 +21,7 @@ skip = int(skip)
 f = per_dispatch(fdb, "FETCH_SIZE", kernel)[skip:]
 w = per_dispatch(wdb, "WRITE_SIZE", kernel)[skip:]
 n = min(len(f), len(w))
-line = json.loads(open(log).read().strip().splitlines()[-1])
+line = json.loads([x for x in open(log).read().splitlines() if x.startswith('{"metric"')][-1])  # (rocprofv3 prints after the app)
 roof = line.get("roofline") or {}
 rows, k, d = roof.get("rows_per_launch"), roof.get("mean_negatives_scored"), line["config"]["dim"]
 entry = {"label": label, "kernel": kernel, "bench_args": args, "dispatches_averaged": n, "warmup_dispatches_skipped": skip,

@@ -280,6 +280,32 @@ struct SharedTable {
     }
 };
 
+/* Scratch of the prediction side (user_representation / mrr_score), kept for the life of the model: one device allocation that
+ * only grows, carved per call — a call used to make and free ~25 device allocations (a quarter of mrr_score's wall time at
+ * 8 192 users x 1e6 items went to the allocator and its implicit synchronisations). */
+struct DeviceArena {
+    uint8_t* base = nullptr;
+    size_t cap = 0, used = 0;
+    sbr_status reserve(size_t need) {
+        used = 0;
+        if (need <= cap) return SBR_OK;
+        if (base) (void)hipFree(base);
+        base = nullptr; cap = 0;
+        const size_t want = need + need / 8 + 4096;
+        if (hipMalloc(reinterpret_cast<void**>(&base), want) != hipSuccess) { base = nullptr; return SBR_ERR_OUT_OF_MEMORY; }
+        cap = want;
+        return SBR_OK;
+    }
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <typename T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + used);
+        used += padded((count ? count : 1) * sizeof(T));
+        return p;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; cap = used = 0; }
+};
+
 struct sbr_model {
     sbr_hparams hp;
     std::shared_ptr<SharedTable> shared; /* partitioned group: the table arrays belong to this object */
@@ -294,6 +320,7 @@ struct sbr_model {
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     float last_lagged_loss = 0.0f; /* what the reference's fit would have returned for the last sbr_model_fit / sbr_group_fit */
+    DeviceArena eval_arena;        /* prediction-side scratch (guarded by mu) */
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
@@ -761,6 +788,7 @@ void sbr_model_destroy(sbr_model* m) {
     hipFree(v.alpha); hipFree(v.alpha_acc);
     hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
+    m->eval_arena.release();
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
     if (m->sorter) { hipStreamSynchronize(m->sorter); hipStreamDestroy(m->sorter); }
@@ -2294,29 +2322,39 @@ sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, u
  * ------------------------------------------------------------------------------------------- */
 namespace {
 
-/* Runs the recurrent forward for a batch of histories and leaves the hidden states in *H_out
- * (device, caller frees); rep_row[i] = packed row of the final state of history i. */
+/* Runs the recurrent forward for a batch of histories; the hidden states are left in *H_out — memory of the model's eval arena,
+ * valid until the next arena.reserve — and rep_row[i] = packed row of the final state of history i.  `extra_bytes`: what the
+ * caller will carve from the arena afterwards (the rank kernels' arrays), reserved in the same allocation. */
+size_t arena_bytes_forward(const sbr_model* m, uint64_t R, uint64_t B, uint64_t noff) {
+    const uint64_t d = (uint64_t)m->d;
+    size_t n = 4 * DeviceArena::padded(R * 4) + DeviceArena::padded(noff * 4) + DeviceArena::padded(B * 4) + DeviceArena::padded(R * d * 4);
+    if (m->ng) n += 2 * DeviceArena::padded(R * d * 4) + DeviceArena::padded(R * d * 16);
+    return n + 4096;
+}
+
 sbr_status forward_histories(sbr_model* m, const std::vector<const uint32_t*>& first, const std::vector<int>& nsteps,
-                             float** H_out, std::vector<int>* rep_row) {
+                             float** H_out, std::vector<int>* rep_row, size_t extra_bytes) {
     Packed pk;
     pack_sequences(first, nsteps, false, nullptr, (int)m->hp.max_sequence_length, &pk);
+    DeviceArena& ar = m->eval_arena;
+    HIPCHK(hipStreamSynchronize(m->stream)); /* nothing of an earlier call may still read the arena */
+    SBRCHK(ar.reserve(arena_bytes_forward(m, (uint64_t)pk.R, (uint64_t)pk.B, pk.off.size()) + extra_bytes));
+    const uint64_t R = (uint64_t)pk.R, d = (uint64_t)m->d;
     DevicePacked dp;
+    dp.in_idx = ar.take<uint32_t>(R); dp.out_idx = ar.take<uint32_t>(R); dp.ctr = ar.take<uint32_t>(R);
+    dp.prev_row = ar.take<int>(R); dp.off = ar.take<int>(pk.off.size()); dp.steps = ar.take<int>((size_t)pk.B);
+    float* H = ar.take<float>(R * d);
     WorkBuffers wb;
-    float* H = nullptr;
-    sbr_status st = SBR_OK;
-    auto cleanup = [&]() { dp.release(); wb.release(); };
-    if ((st = dmalloc(&dp.in_idx, pk.R)) != SBR_OK || (st = dmalloc(&dp.out_idx, pk.R)) != SBR_OK ||
-        (st = dmalloc(&dp.ctr, pk.R)) != SBR_OK || (st = dmalloc(&dp.prev_row, pk.R)) != SBR_OK ||
-        (st = dmalloc(&dp.off, pk.off.size())) != SBR_OK || (st = dmalloc(&dp.steps, pk.B)) != SBR_OK ||
-        (st = alloc_work(m, pk.R, pk.B, false, &wb)) != SBR_OK || (st = dmalloc(&H, (uint64_t)pk.R * m->d)) != SBR_OK) {
-        cleanup();
-        hipFree(H);
-        return st;
+    wb.v.fold_max_tiles = std::getenv("SBR_FOLD_MAX_TILES") ? std::atoi(std::getenv("SBR_FOLD_MAX_TILES")) : SBR_FOLD_MAX_TILES_DEFAULT;
+    if (m->ng) {
+        wb.v.C = ar.take<float>(R * d);
+        wb.v.G = ar.take<float>(R * d * 4);
+        wb.v.X = ar.take<float>(R * d);
     }
-    hipMemcpy(dp.in_idx, pk.in_idx.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dp.prev_row, pk.prev_row.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dp.off, pk.off.data(), pk.off.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(dp.steps, pk.steps.data(), (size_t)pk.B * 4, hipMemcpyHostToDevice);
+    HIPCHK(hipMemcpyAsync(dp.in_idx, pk.in_idx.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(dp.prev_row, pk.prev_row.data(), (size_t)pk.R * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(dp.off, pk.off.data(), pk.off.size() * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(dp.steps, pk.steps.data(), (size_t)pk.B * 4, hipMemcpyHostToDevice, m->stream));
     sbr::MbView mv;
     mv.R = pk.R; mv.B = pk.B; mv.Tm = pk.Tm;
     mv.off = dp.off; mv.steps = dp.steps; mv.prev_row = dp.prev_row;
@@ -2325,9 +2363,8 @@ sbr_status forward_histories(sbr_model* m, const std::vector<const uint32_t*>& f
         ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)pk.Tm : 1);
         sbr::launch_recurrent_forward(m->mv, mv, H, wb.v, pk.Tm, pk.off.data(), m->stream);
     }
-    hipError_t e = hipStreamSynchronize(m->stream);
-    cleanup();
-    if (e != hipSuccess) { hipFree(H); return SBR_ERR_HIP; }
+    /* the host vectors of `pk` are read by the asynchronous copies above: drain them before pk goes out of scope */
+    HIPCHK(hipStreamSynchronize(m->stream));
     rep_row->assign(first.size(), 0);
     for (int b = 0; b < pk.B; ++b) (*rep_row)[pk.order[b]] = pk.off[pk.steps[b] - 1] + b;
     *H_out = H;
@@ -2350,9 +2387,8 @@ sbr_status sbr_user_representation(sbr_model* m, const uint32_t* item_ids, uint6
     std::vector<int> nsteps{(int)n};
     float* H = nullptr;
     std::vector<int> rep_row;
-    SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
+    SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row, 0));
     hipError_t e = hipMemcpy(out_dim, H + (size_t)rep_row[0] * m->d, (size_t)m->dl * 4, hipMemcpyDeviceToHost);
-    hipFree(H);
     return e == hipSuccess ? SBR_OK : SBR_ERR_HIP;
 }
 
@@ -2438,21 +2474,23 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         }
         float* H = nullptr;
         std::vector<int> rep_row;
-        SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row));
-        int* d_rep = nullptr;
-        uint32_t *d_test = nullptr, *d_tih = nullptr, *d_hist = nullptr, *d_ranks = nullptr, *d_flag = nullptr;
-        float* d_ts = nullptr;
-        uint64_t* d_hptr = nullptr;
+        const size_t rank_bytes = 6 * DeviceArena::padded(nu * 4) + DeviceArena::padded(hist_items.size() * 4 + 4) + DeviceArena::padded(4) +
+                                  DeviceArena::padded((nu + 1) * 8);
+        SBRCHK(forward_histories(m, first, nsteps, &H, &rep_row, rank_bytes));
+        DeviceArena& ar = m->eval_arena;
+        int* d_rep = ar.take<int>(nu);
+        uint32_t *d_test = ar.take<uint32_t>(nu), *d_tih = ar.take<uint32_t>(nu), *d_hist = ar.take<uint32_t>(hist_items.size()),
+                 *d_ranks = ar.take<uint32_t>(nu), *d_flag = ar.take<uint32_t>(1);
+        float* d_ts = ar.take<float>(nu);
+        uint64_t* d_hptr = ar.take<uint64_t>(nu + 1);
         sbr_status st = SBR_OK;
-        if ((st = dmalloc(&d_rep, nu)) == SBR_OK && (st = dmalloc(&d_test, nu)) == SBR_OK && (st = dmalloc(&d_tih, nu)) == SBR_OK &&
-            (st = dmalloc(&d_hist, hist_items.size())) == SBR_OK && (st = dmalloc(&d_ranks, nu)) == SBR_OK &&
-            (st = dmalloc(&d_flag, 1)) == SBR_OK && (st = dmalloc(&d_hptr, nu + 1)) == SBR_OK && (st = dmalloc(&d_ts, nu)) == SBR_OK) {
-            hipMemcpy(d_rep, rep_row.data(), nu * 4, hipMemcpyHostToDevice);
-            hipMemcpy(d_test, test_item.data(), nu * 4, hipMemcpyHostToDevice);
-            hipMemcpy(d_tih, test_in_hist.data(), nu * 4, hipMemcpyHostToDevice);
-            if (!hist_items.empty()) hipMemcpy(d_hist, hist_items.data(), hist_items.size() * 4, hipMemcpyHostToDevice);
-            hipMemcpy(d_hptr, hist_ptr.data(), (nu + 1) * 8, hipMemcpyHostToDevice);
-            hipMemset(d_flag, 0, 4);
+        {
+            hipMemcpyAsync(d_rep, rep_row.data(), nu * 4, hipMemcpyHostToDevice, m->stream);
+            hipMemcpyAsync(d_test, test_item.data(), nu * 4, hipMemcpyHostToDevice, m->stream);
+            hipMemcpyAsync(d_tih, test_in_hist.data(), nu * 4, hipMemcpyHostToDevice, m->stream);
+            if (!hist_items.empty()) hipMemcpyAsync(d_hist, hist_items.data(), hist_items.size() * 4, hipMemcpyHostToDevice, m->stream);
+            hipMemcpyAsync(d_hptr, hist_ptr.data(), (nu + 1) * 8, hipMemcpyHostToDevice, m->stream);
+            hipMemsetAsync(d_flag, 0, 4, m->stream);
             {
                 ScopedTimer t(m, SBR_K_RANK, 1);
                 sbr::launch_rank(m->mv, H, d_rep, (uint32_t)nu, d_test, d_tih, d_hptr, d_hist, d_ts, d_ranks, d_flag, m->stream);
@@ -2465,7 +2503,6 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
             else if (flag)
                 st = SBR_ERR_INVALID_PREDICTION; /* predict fails the call on a non-finite score */
         }
-        hipFree(H); hipFree(d_rep); hipFree(d_test); hipFree(d_tih); hipFree(d_hist); hipFree(d_ranks); hipFree(d_flag); hipFree(d_hptr); hipFree(d_ts);
         if (st != SBR_OK) return st;
     }
     float sum = 0.0f; /* evaluation.rs:47 — sequential f32 sum in user order */

@@ -146,8 +146,8 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // 50 000 sequences per step with U = 2, round 2).  U = 2 at small launches (the quality-neutral 8 192 sequences per step =
 // 256 K rows): a wave then walks ~18 passes of ~1.75 dependent memory round trips each and the kernel is THEIR LATENCY, not the
 // bytes — half the passes with twice the rows in flight.  Same arithmetic per row, same bits.
-template <int D, int U>
-__global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
+template <int D, int U, bool PF>
+__global__ __launch_bounds__(256, PF ? 1 : 7) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
                                                     uint64_t epoch_key) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
@@ -169,13 +169,15 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
     int base = wave * RPW;
     uint32_t pi_n[U], ctr_n[U];
     float4 h_n[U];
+    if constexpr (PF) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int r0 = base + u * GPW + grp;
-        const int rr0 = r0 < mb.R ? r0 : last_row;
-        pi_n[u] = mb.out_idx[rr0];
-        ctr_n[u] = mb.ctr[rr0];
-        h_n[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+        for (int u = 0; u < U; ++u) {
+            const int r0 = base + u * GPW + grp;
+            const int rr0 = r0 < mb.R ? r0 : last_row;
+            pi_n[u] = mb.out_idx[rr0];
+            ctr_n[u] = mb.ctr[rr0];
+            h_n[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+        }
     }
     for (; base < mb.R; base += nwaves * RPW) {
         float4 h[U], ep[U], ec[U];
@@ -184,9 +186,17 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
         bool done[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            h[u] = h_n[u];
-            pi[u] = pi_n[u];
-            ctr[u] = ctr_n[u];
+            if constexpr (PF) {
+                h[u] = h_n[u];
+                pi[u] = pi_n[u];
+                ctr[u] = ctr_n[u];
+            } else {  // (no ids a pass ahead: their registers are what lets seven waves per SIMD be resident at U = 2)
+                const int r0 = base + u * GPW + grp;
+                const int rr0 = r0 < mb.R ? r0 : last_row;
+                pi[u] = mb.out_idx[rr0];
+                ctr[u] = mb.ctr[rr0];
+                h[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+            }
             ep[u] = ld4(m.E + (size_t)pi[u] * D + 4 * lg);
             bp[u] = m.b[pi[u]];
             // WARP: lane lg of the group draws candidate lg & 7 — the five draws of the row cost one evaluation of the
@@ -197,13 +207,15 @@ __global__ __launch_bounds__(256) void score_kernel(ModelView m, MbView mb, Bloc
             ec[u] = ld4(m.E + (size_t)cand[u] * D + 4 * lg);
             bc[u] = m.b[cand[u]];
         }
+        if constexpr (PF) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {  // the next pass's ids and h rows (clamped: the request count does not depend on the pass)
-            const int rn = base + nwaves * RPW + u * GPW + grp;
-            const int rrn = rn < mb.R ? rn : last_row;
-            pi_n[u] = mb.out_idx[rrn];
-            ctr_n[u] = mb.ctr[rrn];
-            h_n[u] = ld4(blk.H + (size_t)rrn * D + 4 * lg);
+            for (int u = 0; u < U; ++u) {  // the next pass's ids and h rows (clamped: the request count does not depend on the pass)
+                const int rn = base + nwaves * RPW + u * GPW + grp;
+                const int rrn = rn < mb.R ? rn : last_row;
+                pi_n[u] = mb.out_idx[rrn];
+                ctr_n[u] = mb.ctr[rrn];
+                h_n[u] = ld4(blk.H + (size_t)rrn * D + 4 * lg);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2877,9 +2889,9 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
         DISPATCH_D(m.d, {
             if (m.loss == SBR_LOSS_WARP) {
                 if (score_warp_u(rows_host) == 2)
-                    hipLaunchKernelGGL((score_kernel<DD, 2>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                    hipLaunchKernelGGL((score_kernel<DD, 2, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
                 else
-                    hipLaunchKernelGGL((score_kernel<DD, 1>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                    hipLaunchKernelGGL((score_kernel<DD, 1, true>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
             }
             else
                 hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,

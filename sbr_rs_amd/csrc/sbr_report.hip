@@ -12,8 +12,8 @@
 //   total    = ((total + x_0) + x_1) + ...                   strictly sequential f32 chain over b
 //   node[s]  = sum of the last sequence of the run of length s
 // A length occurs in at most one run of a minibatch, so the x_b are independent of each other and only the chain over b is
-// sequential: ONE wave walks it, 64 values per coalesced load, v_readlane + v_add_f32 per value (a lone wave issues a
-// dependent VALU instruction every ~9 cycles: 50 000 sequences ~ 0.4 ms, on the sorter stream underneath BPTT).
+// sequential: ONE wave walks it, 64 values per load, v_readlane + v_add_f32 per value (a lone wave issues a dependent VALU
+// instruction every ~9 cycles), on the sorter stream underneath BPTT.
 // The CPU checker restates it sequentially (tests compare the two bit for bit).
 
 #include <hip/hip_runtime.h>
@@ -34,29 +34,57 @@ __global__ __launch_bounds__(256) void seq_loss_kernel(MbView mb, const float* l
 }
 
 // state[0] = the partition's accumulator (loss_value of sequence_model.rs:105), state[1 + s] = value left in the loss node of
-// a sequence with s + 1 steps.  One wave; `steps` / `seqsum` in global memory or LDS.
-__device__ __forceinline__ void lagged_chain(const int* steps, const float* seqsum, int B, float* state, int lane) {
+// a sequence with s + 1 steps.  One wave; `steps` / `seqsum` in global memory or LDS.  Tiles of LAG_TILE sequences: first the
+// tile's x values with all their loads in flight together (they do not depend on the chain; a chunk-at-a-time version paid two
+// dependent memory round trips per 64 sequences: 0.5 ms for 8 192 sequences), staged through `xs` (LDS, LAG_TILE floats); then
+// the chain, 64 values per LDS read; then the tile's node writes (a length's run is read at its first and written at its last
+// sequence, so reads of a tile come before its writes).
+#define LAG_TILE 4096
+__device__ __forceinline__ void lagged_chain(const int* steps, const float* seqsum, int B, float* state, int lane, float* xs) {
     float* node = state + 1;
     float acc = state[0];
-    for (int base = 0; base < B; base += 64) {
-        const int j = base + lane;
-        const bool live = j < B;
-        const int s = live ? steps[j] : 0;
-        const int sp = live && j > 0 ? steps[j - 1] : -1;
-        const int sn = live && j + 1 < B ? steps[j + 1] : -1;
-        float x = 0.0f, mine = 0.0f;
-        if (live) {
-            mine = seqsum[j];
-            x = sp != s ? node[s - 1] : seqsum[j - 1];
+    for (int tile0 = 0; tile0 < B; tile0 += LAG_TILE) {
+        const int n = B - tile0 < LAG_TILE ? B - tile0 : LAG_TILE;
+        const int nchunks = (n + 63) / 64;
+#pragma unroll 8
+        for (int c = 0; c < nchunks; ++c) {
+            const int j = tile0 + c * 64 + lane;
+            float x = 0.0f;
+            if (j < tile0 + n) {
+                const int s = steps[j];
+                const int sp = j > 0 ? steps[j - 1] : -1;
+                x = sp != s ? node[s - 1] : seqsum[j - 1];
+            }
+            xs[c * 64 + lane] = x;
         }
-        const int n = B - base < 64 ? B - base : 64;
-        if (n == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float v = xs[lane];
+        for (int c = 0; c < nchunks; ++c) {
+            const float vn = xs[(c + 1 < nchunks ? c + 1 : c) * 64 + lane];  // next chunk's values while this chunk's chain runs
+            const int cnt = n - c * 64 < 64 ? n - c * 64 : 64;
+            if (cnt == 64) {
 #pragma unroll
-            for (int l = 0; l < 64; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
-        } else {
-            for (int l = 0; l < n; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+                for (int l = 0; l < 64; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+            } else {
+                for (int l = 0; l < cnt; ++l) acc = acc + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+            }
+            v = vn;
         }
-        if (live && sn != s) node[s - 1] = mine; /* the run's last sequence: no later sequence of this minibatch reads this node */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+        for (int c = 0; c < nchunks; ++c) {  // the runs' last sequences leave their sums in the nodes
+            const int j = tile0 + c * 64 + lane;
+            if (j < tile0 + n) {
+                const int s = steps[j];
+                const int sn = j + 1 < B ? steps[j + 1] : -1;
+                if (sn != s) node[s - 1] = seqsum[j];
+            }
+        }
+        /* the next tile's node reads must see these writes: same wave, vector memory operations complete in order; the compiler
+         * keeps the order across the fence */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     if (lane == 0) state[0] = acc;
 }
@@ -64,8 +92,9 @@ __device__ __forceinline__ void lagged_chain(const int* steps, const float* seqs
 __global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, const float* seqsum, int B, float* state) {
     // one wave under BPTT's MFMA waves, which are older and win the SIMD's issue arbitration: at priority 0 the chain of 8 192
     // sequences took 0.44 ms of elapsed time for ~0.05 ms of dependent adds (profiles/r04_*kernel_stats*)
+    __shared__ float xs[LAG_TILE];
     __builtin_amdgcn_s_setprio(3);
-    lagged_chain(steps, seqsum, B, state, threadIdx.x);
+    lagged_chain(steps, seqsum, B, state, threadIdx.x, xs);
 }
 
 // header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction, compared with a tolerance) and
@@ -79,6 +108,7 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
     __shared__ unsigned int tpart[4];
     __shared__ float ssum[SBR_HEADER_LAG_MAX_B];
     __shared__ int ssteps[SBR_HEADER_LAG_MAX_B];
+    __shared__ float sx[SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B];
     double acc = 0.0;
     unsigned int tacc = 0;
     for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -128,7 +158,7 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
             ex_acc[2] += (unsigned long long)R;
         }
     }
-    if (lag_state && threadIdx.x < 64) lagged_chain(ssteps, ssum, mb.B, lag_state, threadIdx.x);
+    if (lag_state && threadIdx.x < 64) lagged_chain(ssteps, ssum, mb.B, lag_state, threadIdx.x, sx);
 }
 
 void launch_block_header_parts(uint32_t* header, int rows_host, const double* part_loss, const unsigned int* part_tries, int nparts,

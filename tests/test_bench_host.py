@@ -28,17 +28,24 @@ def test_workload_labels_follow_baseline_configs():
     assert bench.workload_label(_args(dim=64), 1) == "custom workload"
 
 
-def test_measured_traffic_is_printed_only_at_the_profiled_operating_point():
+def test_profiled_traffic_is_printed_only_at_a_profiled_operating_point():
+    """bench.py --traffic profile (the fallback of --traffic live): profiles/score_kernel_traffic.json holds one entry per profiled
+    operating point; an entry is used only for a run at that point — same dim and table, rows per launch and negatives per row
+    within 5 %."""
     prof = json.load(open(os.path.join(ROOT, "profiles", "score_kernel_traffic.json")))
     for which in ("warm", "cold"):
-        e = prof[which]
-        up, lo = bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], 128)
-        assert up == e["hbm_bytes_per_launch"] and lo == e["hbm_bytes_per_launch_lower"] and lo < up
-        assert 1.1 < lo / e["algorithmic_bytes_per_launch"] < up / e["algorithmic_bytes_per_launch"] < 1.4
-        assert bench.measured_traffic(which, e["rows_per_launch"] * 1.04, e["mean_negatives_scored"] * 0.97, 128)[0] == up
-        assert bench.measured_traffic(which, e["rows_per_launch"] * 1.08, e["mean_negatives_scored"], 128) == (None, None)
-        assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"] * 0.9, 128) == (None, None)
-        assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], 256) == (None, None)
+        assert len(prof[which]) >= 2
+        for e in prof[which]:
+            d, items = e.get("dim", 128), e.get("items")
+            up, lo = bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], d, items)
+            assert up is not None and lo < up
+            assert 1.0 < lo / e["algorithmic_bytes_per_launch"] < up / e["algorithmic_bytes_per_launch"] < 1.4
+            assert bench.measured_traffic(which, e["rows_per_launch"] * 1.08, e["mean_negatives_scored"] * 1.2, d, items) == (None, None)
+            assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], 64, items) == (None, None)
+            assert bench.measured_traffic(which, e["rows_per_launch"], e["mean_negatives_scored"], d, 12345) == (None, None)
+    # the headline's operating point (8 192 sequences per step) and the max-batch one (50 000) are both on file
+    rows = sorted(e["rows_per_launch"] for e in prof["warm"] if e.get("dim", 128) == 128)
+    assert rows[0] < 300_000 and rows[-1] > 1_500_000
     assert bench.measured_traffic("absent", 1.0, 1.0, 128) == (None, None)
 
 

@@ -534,6 +534,7 @@ struct sbr_fit_plan {
     unsigned long long* ex_acc = nullptr;
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
+    int dense_unreduced_chunks = 0; /* > 0: blk.dense is still that many chunk partials in wb.v.partials (one device: reduced by its consumer) */
     bool sort_off_stream = false; /* the step's key ordering ran on another stream than the main one: ev_sorted joins it */
     bool sorted_event_live = false; /* ev_sorted has been recorded at least once: the multi-device consumers wait on it whatever the
                                      * last step's placement was (a completed event costs nothing; the flag above belongs to ONE step) */
@@ -1337,6 +1338,16 @@ static sbr_status join_dense(sbr_fit_plan* p) {
     return SBR_OK;
 }
 
+/* blk.dense complete on the main stream: joins the GEMM and, if its chunk partials are still unreduced, reduces them */
+static sbr_status ensure_dense_reduced(sbr_fit_plan* p) {
+    SBRCHK(join_dense(p));
+    if (p->dense_unreduced_chunks > 0) {
+        sbr::launch_dense_reduce(p->m->mv, p->wb.v, p->dense_unreduced_chunks, block_view(p->m, p->block, p->rmax), p->m->stream);
+        p->dense_unreduced_chunks = 0;
+    }
+    return SBR_OK;
+}
+
 sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     if (!p || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
@@ -1368,12 +1379,23 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     hipStream_t sorter = place == SORT_OWN_STREAM ? m->sorter : m->stream;
     const bool early_sort = m->hp.loss != SBR_LOSS_WARP && !std::getenv("SBR_NO_EARLY_SORT"); /* the variable is the A/B switch */
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
+    /* WARP step with the ordering on its own stream: the per-sequence loss sums and the block header (row count, loss sum; the
+     * single-device accumulators) are queued on THAT stream, behind the score kernel's event and ahead of the ordering — between
+     * score and BPTT they were two launches and their gaps (~35 us of a 2.5 ms step) on the critical path for nobody's benefit.
+     * Their consumers (update / scatter / dense / fit_end) all join the ordering's stream first.  SBR_HEADER_ON_MAIN=1: the old place. */
+    static const bool header_on_main = std::getenv("SBR_HEADER_ON_MAIN") != nullptr;
+    const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM && !header_on_main;
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
              * itself, before it queues the backward pass) */
             if (early_sort) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
             HIPCHK(hipStreamWaitEvent(on, m->ev_scored, 0));
+        }
+        if (side_header) { /* the step's loss bookkeeping rides on the ordering's stream: nothing on the main stream waits for it */
+            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, on);
+            sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
+                                     p->header_accumulated ? p->ex_acc : nullptr, nullptr, on);
         }
         {
             ScopedTimer t(m, SBR_K_SPARSE_SORT, 1, on);
@@ -1408,25 +1430,29 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* the figure the reference's fit returns (sbr_report.hip): a small step folds it into the header launch; otherwise the
      * per-sequence sums come from a parallel kernel here and the sequential chain over the sequences runs as one wave on the
      * sorter stream (queued at the end of this call), off the critical path */
-    if (p->lag_busy) { /* the previous step's chain may still be running on the sorter stream: it owns lag_state / lag_seqsum */
-        HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
-        p->lag_busy = false;
-    }
-    const bool fuse_lag = !overlap && mb.B <= SBR_HEADER_LAG_MAX_B;
-    if (!fuse_lag) {
-        sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, m->stream);
-        if (overlap) HIPCHK(hipEventRecord(p->ev_seqsum, m->stream));
-    }
     /* single device: the loss accumulators take the block's header in the header kernel itself (one launch fewer per step) */
     p->header_accumulated = p->ndev == 1;
-    sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
-                             p->header_accumulated ? p->ex_acc : nullptr, fuse_lag ? p->lag_state : nullptr, m->stream);
+    const bool fuse_lag = !overlap && mb.B <= SBR_HEADER_LAG_MAX_B;
+    if (side_header) {
+        HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* right behind the score kernel */
+    } else {
+        if (p->lag_busy) { /* the previous step's chain may still be running on the sorter stream: it owns lag_state / lag_seqsum */
+            HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
+            p->lag_busy = false;
+        }
+        if (!fuse_lag) {
+            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, m->stream);
+            if (overlap) HIPCHK(hipEventRecord(p->ev_seqsum, m->stream));
+        }
+        sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
+                                 p->header_accumulated ? p->ex_acc : nullptr, fuse_lag ? p->lag_state : nullptr, m->stream);
+    }
     /* host order: with the ordering on its own stream the backward pass is queued FIRST — the ordering's up to nine short
      * launches would otherwise sit in the host's queue ahead of it (50 us at a few hundred sequences per step, as long as
      * the pass itself); ev_scored, recorded here, is what the ordering waits for either way */
     const bool sort_first = place == SORT_PRE;
     if (!early_sort && sort_first) SBRCHK(launch_sort(sorter));
-    if (!early_sort && place == SORT_OWN_STREAM) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
+    if (!early_sort && place == SORT_OWN_STREAM && !side_header) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
     if (ewma_fused < 2) {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
@@ -1440,15 +1466,17 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
     }
     {
+        /* one device: the ordered reduction of the chunk partials is left to the consumer — the optimiser step folds it into
+         * the dense update's launch (sbr_fit_step_apply); the exchange halves and the debug fetch reduce on demand */
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
-        sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side);
+        p->dense_unreduced_chunks = sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side, /*defer_reduce=*/p->ndev == 1);
     }
     if (!early_sort && place == SORT_POST) SBRCHK(launch_sort(m->stream));
     if (side != m->stream) HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = side != m->stream;
     if (!fuse_lag) {
         hipStream_t ls = overlap ? m->sorter : m->stream;
-        if (ls != m->stream) HIPCHK(hipStreamWaitEvent(ls, p->ev_seqsum, 0));
+        if (ls != m->stream && !side_header) HIPCHK(hipStreamWaitEvent(ls, p->ev_seqsum, 0)); /* (side_header: same stream as seq_loss) */
         sbr::launch_lagged_chain(mv, p->lag_seqsum, mb.B, p->lag_state, ls);
         if (ls != m->stream) {
             HIPCHK(hipEventRecord(p->ev_lagged, ls));
@@ -1479,7 +1507,12 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     SBRCHK(join_dense(p));
     {
         ScopedTimer t(m, SBR_K_DENSE_UPDATE, 1);
-        sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
+        if (p->dense_unreduced_chunks > 0) { /* ordered reduction of the chunk partials + dense update in ONE launch */
+            sbr::launch_dense_reduce_apply(m->mv, p->wb.v, p->dense_unreduced_chunks, block_view(m, p->block, p->rmax), m->stream);
+            p->dense_unreduced_chunks = 0;
+        } else {
+            sbr::launch_dense_apply(m->mv, all, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
+        }
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -1529,7 +1562,7 @@ sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out) {
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
-    SBRCHK(join_dense(p));
+    SBRCHK(ensure_dense_reduced(p));
     HIPCHK(hipMemcpyAsync(device_dense_out, bv.header, 32, hipMemcpyDeviceToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(device_dense_out) + 32, bv.dense, dense_count(m) * 4,
                           hipMemcpyDeviceToDevice, m->stream));
@@ -1702,6 +1735,7 @@ sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples)
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(hipStreamSynchronize(m->sorter)); /* a step's header launch may ride on the ordering's stream */
     double loss[17];
     unsigned long long ex[18];
     HIPCHK(hipMemcpy(loss, p->loss_acc, sizeof(loss), hipMemcpyDeviceToHost));
@@ -1741,6 +1775,7 @@ sbr_status sbr_fit_counters(sbr_fit_plan* p, uint64_t* out_examples, uint64_t* o
     if (!p) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(p->m));
     HIPCHK(hipStreamSynchronize(p->m->stream));
+    HIPCHK(hipStreamSynchronize(p->m->sorter));
     unsigned long long v[2] = {0, 0};
     HIPCHK(hipMemcpy(v, p->ex_acc, sizeof(v), hipMemcpyDeviceToHost));
     if (out_examples) *out_examples = v[0];
@@ -2288,7 +2323,8 @@ sbr_status sbr_fit_debug_fetch(sbr_fit_plan* p, int32_t which, void* host_out, u
     if (!p || !host_out || !p->last_block) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
-    SBRCHK(join_dense(p));
+    if (which == SBR_DBG_DENSE_GRAD) SBRCHK(ensure_dense_reduced(p));
+    else SBRCHK(join_dense(p));
     HIPCHK(hipStreamSynchronize(m->stream));
     const sbr::BlockView bv = block_view(m, const_cast<void*>(p->last_block), p->rmax);
     const uint64_t R = (uint64_t)p->last_R, d = (uint64_t)m->d;
@@ -2455,23 +2491,44 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         std::vector<const uint32_t*> first(nu);
         std::vector<int> nsteps(nu);
         std::vector<uint32_t> test_item(nu), test_in_hist(nu, 0), hist_items;
-        std::vector<uint64_t> hist_ptr(nu + 1, 0);
-        for (size_t i = 0; i < nu; ++i) {
-            const uint64_t u = users[c0 + i];
-            const uint32_t* it = item_ids + user_ptr[u];
-            const uint64_t n = user_ptr[u + 1] - user_ptr[u];
-            const uint64_t nh = n - 1; /* train_items = all but last (evaluation.rs:24) */
-            test_item[i] = it[n - 1];
-            const uint64_t keep = std::min(nh, T); /* last T items feed the state (sequence_model.rs:188) */
-            first[i] = it + (nh - keep);
-            nsteps[i] = (int)keep;
-            std::vector<uint32_t> h(it, it + nh); /* ALL history items are masked (evaluation.rs:30-32) */
-            std::sort(h.begin(), h.end());
-            h.erase(std::unique(h.begin(), h.end()), h.end());
-            test_in_hist[i] = std::binary_search(h.begin(), h.end(), test_item[i]) ? 1u : 0u;
-            hist_items.insert(hist_items.end(), h.begin(), h.end());
-            hist_ptr[i + 1] = hist_items.size();
+        std::vector<uint64_t> hist_ptr(nu + 1, 0), raw_ptr(nu + 1, 0);
+        for (size_t i = 0; i < nu; ++i) raw_ptr[i + 1] = raw_ptr[i] + (user_ptr[users[c0 + i] + 1] - user_ptr[users[c0 + i]] - 1);
+        hist_items.resize(raw_ptr[nu]);
+        std::vector<uint32_t> uniq_count(nu, 0);
+        /* ALL history items of a user are masked (evaluation.rs:30-32): sorted + de-duplicated in place inside one buffer (a vector
+         * per user was a third of mrr_score's host time at 8 192 users), a few host threads over user ranges */
+        auto prepare = [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1; ++i) {
+                const uint64_t u = users[c0 + i];
+                const uint32_t* it = item_ids + user_ptr[u];
+                const uint64_t n = user_ptr[u + 1] - user_ptr[u];
+                const uint64_t nh = n - 1; /* train_items = all but last (evaluation.rs:24) */
+                test_item[i] = it[n - 1];
+                const uint64_t keep = std::min(nh, T); /* last T items feed the state (sequence_model.rs:188) */
+                first[i] = it + (nh - keep);
+                nsteps[i] = (int)keep;
+                uint32_t* h = hist_items.data() + raw_ptr[i];
+                std::memcpy(h, it, nh * 4);
+                std::sort(h, h + nh);
+                uint32_t* e = std::unique(h, h + nh);
+                test_in_hist[i] = std::binary_search(h, e, test_item[i]) ? 1u : 0u;
+                uniq_count[i] = (uint32_t)(e - h);
+            }
+        };
+        {
+            const size_t nthreads = nu >= 2048 ? 8 : 1;
+            if (nthreads == 1) prepare(0, nu);
+            else {
+                std::vector<std::thread> workers;
+                for (size_t k = 0; k < nthreads; ++k) workers.emplace_back(prepare, nu * k / nthreads, nu * (k + 1) / nthreads);
+                for (auto& w : workers) w.join();
+            }
         }
+        for (size_t i = 0; i < nu; ++i) { /* close the gaps the de-duplication left */
+            if (hist_ptr[i] != raw_ptr[i]) std::memmove(hist_items.data() + hist_ptr[i], hist_items.data() + raw_ptr[i], (size_t)uniq_count[i] * 4);
+            hist_ptr[i + 1] = hist_ptr[i] + uniq_count[i];
+        }
+        hist_items.resize(hist_ptr[nu]);
         float* H = nullptr;
         std::vector<int> rep_row;
         const size_t rank_bytes = 6 * DeviceArena::padded(nu * 4) + DeviceArena::padded(hist_items.size() * 4 + 4) + DeviceArena::padded(4) +

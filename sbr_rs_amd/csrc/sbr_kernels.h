@@ -142,8 +142,11 @@ void launch_lagged_chain(const MbView& mb, const float* seqsum, int b_host, floa
  * it reads only dZ, X, H) */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                int tm_host, int rows_host, int b_host, const int* off_host, hipStream_t s);
-void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
-                           int b_host, hipStream_t s);
+/* returns the number of chunk partials left unreduced in w.partials (defer_reduce and more than one chunk), else 0 with blk.dense complete */
+int launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
+                          int b_host, hipStream_t s, bool defer_reduce = false);
+void launch_dense_reduce(const ModelView& m, const WorkView& w, int nchunks, const BlockView& blk, hipStream_t s);
+void launch_dense_reduce_apply(const ModelView& m, const WorkView& w, int nchunks, const BlockView& blk, hipStream_t s);
 /* dense: sum over device blocks in device order + Adagrad (+ repack of the LSTM weights) */
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
                         int ndev, hipStream_t s);

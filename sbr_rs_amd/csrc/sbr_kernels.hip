@@ -1978,12 +1978,29 @@ __device__ __forceinline__ size_t wtp_index(int k, int jcol, int D, int NG) {
     return ((((size_t)ct * (NGD / 16) + S) * 64 + lane) * 4 + sub);
 }
 
+// partials != nullptr (one device): the gradient is still `nchunks` chunk partials — their ordered sum (dense_reduce_local_kernel's
+// chain) is formed here, written to dense_out, and applied: one launch instead of two on the tail of the step
 __global__ void dense_apply_kernel(ModelView m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
-                                   int ndev, size_t n) {
+                                   int ndev, size_t n, const float* partials, int nchunks, float* dense_out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float g = reinterpret_cast<const float*>(all_blocks + dense_off)[i];
-    for (int q = 1; q < ndev; ++q) g = g + reinterpret_cast<const float*>(all_blocks + (size_t)q * block_bytes + dense_off)[i];
+    float g;
+    if (partials) {
+        g = partials[i];
+        int c = 1;
+        for (; c + 8 <= nchunks; c += 8) { /* loads run ahead of the ordered add chain */
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = partials[(size_t)(c + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g = g + v[j];
+        }
+        for (; c < nchunks; ++c) g = g + partials[(size_t)c * n + i];
+        dense_out[i] = g;
+    } else {
+        g = reinterpret_cast<const float*>(all_blocks + dense_off)[i];
+        for (int q = 1; q < ndev; ++q) g = g + reinterpret_cast<const float*>(all_blocks + (size_t)q * block_bytes + dense_off)[i];
+    }
     if (m.ng) {
         const int NGD = m.ng * m.d;
         const size_t nw = (size_t)2 * m.d * NGD;
@@ -3005,18 +3022,18 @@ void launch_recurrent_backward(const ModelView& m, const MbView& mb, const Block
     }
 }
 
-void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w_in, int rows_host,
-                           int b_host, hipStream_t s) {
-    if (rows_host == 0) return; /* the empty case is handled by launch_recurrent_backward */
+int launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w_in, int rows_host,
+                          int b_host, hipStream_t s, bool defer_reduce) {
+    if (rows_host == 0) return 0; /* the empty case is handled by launch_recurrent_backward */
     if (m.ng == 0) { /* EWMA: dalpha from the per-sequence partials the backward scan left in w.dab */
         const int nch = (b_host + EWMA_CHUNK_SEQS - 1) / EWMA_CHUNK_SEQS;
         if (nch == 1) {
             hipLaunchKernelGGL(ewma_dab_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.dab, b_host, m.d, m.alpha, blk.dense);
-            return;
+            return 0;
         }
         hipLaunchKernelGGL(ewma_dab_chunk_kernel, dim3(nch), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.dab, b_host, m.d, w_in.partials);
         hipLaunchKernelGGL(ewma_dense_final_kernel, dim3(1), dim3(m.d < 64 ? 64 : m.d), 0, s, w_in.partials, nch, m.d, m.alpha, blk.dense);
-        return;
+        return 0;
     }
     const int nch = (rows_host + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS;
     const int K2 = 2 * m.d, NGD = m.ng * m.d;
@@ -3051,15 +3068,31 @@ void launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView
             }
         }
     });
-    if (nch == 1) return;
-    const size_t n = (size_t)(K2 + 1) * NGD;
-    hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nch, n, blk.dense);
+    if (nch == 1) return 0;
+    if (defer_reduce) return nch; /* the consumer reduces: launch_dense_reduce, or launch_dense_reduce_apply in the optimiser step's launch */
+    launch_dense_reduce(m, w, nch, blk, s);
+    return 0;
+}
+
+/* ordered sum of `nchunks` chunk partials of the LSTM dense gradient into blk.dense */
+void launch_dense_reduce(const ModelView& m, const WorkView& w, int nchunks, const BlockView& blk, hipStream_t s) {
+    const size_t n = (size_t)(2 * m.d + 1) * m.ng * m.d;
+    hipLaunchKernelGGL(dense_reduce_local_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w.partials, nchunks, n, blk.dense);
 }
 
 void launch_dense_apply(const ModelView& m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
                         int ndev, hipStream_t s) {
     const size_t n = m.ng ? (size_t)(2 * m.d + 1) * m.ng * m.d : (size_t)m.d;
-    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, all_blocks, block_bytes, dense_off, ndev, n);
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, all_blocks, block_bytes, dense_off, ndev, n,
+                       (const float*)nullptr, 0, (float*)nullptr);
+}
+
+/* one device: ordered reduction of the chunk partials + optimiser update of the dense parameters in one launch (blk.dense is
+ * written as well: the debug fetch and the tests read it) */
+void launch_dense_reduce_apply(const ModelView& m, const WorkView& w, int nchunks, const BlockView& blk, hipStream_t s) {
+    const size_t n = (size_t)(2 * m.d + 1) * m.ng * m.d;
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m, (const uint8_t*)nullptr, (uint64_t)0, (uint64_t)0, 1, n,
+                       (const float*)w.partials, nchunks, blk.dense);
 }
 
 void launch_repack_lstm(const ModelView& m, hipStream_t s) {

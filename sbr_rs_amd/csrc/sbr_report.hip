@@ -62,6 +62,9 @@ __device__ __forceinline__ void lagged_chain(const int* steps, const float* seqs
         float v = xs[lane];
         for (int c = 0; c < nchunks; ++c) {
             const float vn = xs[(c + 1 < nchunks ? c + 1 : c) * 64 + lane];  // next chunk's values while this chunk's chain runs
+            // (a lane-to-lane form — one v_add_f32 with a wave_shr:1 DPP operand per element instead of v_readlane + v_add — was
+            // measured and is no faster: beside the GEMM's back-to-back 64-cycle MFMAs this wave's vector instructions wait for the
+            // pipe one MFMA pass at a time either way; profiles/r04_tail_experiments.md)
             const int cnt = n - c * 64 < 64 ? n - c * 64 : 64;
             if (cnt == 64) {
 #pragma unroll

@@ -576,6 +576,15 @@ def main():
     for _ in range(args.warmup):
         one_step(False)
     sync()
+    # SBR_BENCH_TIMERS = all | score | off: which kernel families are bracketed by HIP events inside the timed region (A/B of the
+    # events' own cost; the roofline needs the score family's)
+    # Inside the timed region only the roofline's kernel family is bracketed by HIP events: two event records per bracketed launch
+    # cost a 2.5 ms step of ~20 launches 1.5-2 % (profiles/r04_tail_experiments.md).  The per-family times of `kernels` /
+    # `roofline_mfma` come from a second pass of the same number of steps, same schedule, with every family bracketed — outside the
+    # timed region.  SBR_BENCH_TIMERS = all | score | off is the A/B switch.
+    timers = os.environ.get("SBR_BENCH_TIMERS", "score")
+    if hasattr(model, "timing_select"):
+        model.timing_select(None if timers == "all" else ["SCORE"] if timers == "score" else [])
     model.timing_enable(True)
     model.timing_read()  # reset
     ex0, neg0 = plan.counters()
@@ -603,6 +612,18 @@ def main():
         per_rank = [1e3 * elapsed / max(args.steps, 1)]
     timing = model.timing_read()
     ex1, neg1 = plan.counters()
+    score_timing = timing.get("SCORE")
+    rows_families = rows_timed
+    if timers != "all" and hasattr(model, "timing_select"):
+        # second pass, untimed for `value`: the same steps with every kernel family bracketed by events
+        model.timing_select(None)
+        rows_families = 0
+        for _ in range(args.steps):
+            rows_families += one_step(False)
+        sync()
+        timing = model.timing_read()
+        if score_timing and score_timing[1]:
+            timing["SCORE"] = score_timing  # the roofline kernel's time is the timed region's
     sparse_entries, sparse_unique = plan.sparse_stats() if hasattr(plan, "sparse_stats") else (0, 0)
     # Second, UNTIMED pass (single GPU): the same steps with the side-stream work queued on the main stream,
     # so that every kernel family runs alone — the times behind the per-kernel roofline figures below.  The
@@ -628,6 +649,8 @@ def main():
         for i in range(warm):
             lp.step(i % nmb)
         mdl.synchronize()
+        if hasattr(mdl, "timing_select"):
+            mdl.timing_select(["SCORE"])  # only the roofline kernel's launches are bracketed (as in the main timed region)
         mdl.timing_enable(timers)  # (the per-kernel events cost a small step a third of its time: off for those)
         mdl.timing_read()
         e0, n0 = be.plan.counters()
@@ -797,7 +820,7 @@ def main():
                                              ("RECURRENT_BWD", gemm, "sequence-resident BPTT (cell backward + dz W^T GEMM)"),
                                              ("DENSE_GRAD", gemm, "dense-gradient GEMM xh^T dz (runs on the side stream, overlapping the sparse update)")):
                 if fam in kernels:
-                    tf = flops_per_row * rows_timed / (kernels[fam]["ms_total"] * 1e-3) / 1e12
+                    tf = flops_per_row * rows_families / (kernels[fam]["ms_total"] * 1e-3) / 1e12
                     mfma.append({"kernel": fam, "what": what, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
                                  "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF})
         workload_tag = workload_label(args, world)
@@ -819,6 +842,9 @@ def main():
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
             "roofline": roofline, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
+            "kernels_source": ("HIP events on every family inside the timed region" if timers == "all" else
+                               f"SCORE: HIP events inside the timed region; the other families: a second pass of {args.steps} steps of the same schedule "
+                               "with every family bracketed (events cost the step 1.5-2 %, so the timed region brackets the roofline kernel only)"),
         }
         if sweep is not None:
             sweep.append({"batch_sequences": args.batch_sequences, "interactions_per_s": rows_total / elapsed,

@@ -307,6 +307,10 @@ typedef enum sbr_kernel_family {
     SBR_K_FAMILIES = 8
 } sbr_kernel_family;
 sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable);
+/* Which families' launches are bracketed by events while timing is enabled (bit f = sbr_kernel_family f; default: all).  Every
+ * bracketed launch costs two event records on its stream — a few microseconds each, which a 2.5 ms step of ~20 launches feels —
+ * so a throughput measurement that needs one kernel's duration selects that family alone. */
+sbr_status sbr_model_timing_select(sbr_model* m, uint32_t family_mask);
 /* enable = 0 queues the side-stream work (key sort, dense-gradient GEMM) on the main stream, so that every
  * kernel family is timed running alone; results are identical.  Default: overlap on. */
 sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable);

@@ -68,6 +68,7 @@ def load():
         "sbr_model_set_counters": [vp, C.c_uint64, C.c_uint64],
         "sbr_device_info": [C.c_char_p, C.c_uint64, u32p, u64p],
         "sbr_model_timing_enable": [vp, C.c_int32],
+        "sbr_model_timing_select": [vp, C.c_uint32],
         "sbr_model_set_overlap": [vp, C.c_int32],
         "sbr_model_timing_read": [vp, C.POINTER(C.c_double), u64p],
         "sbr_set_device": [C.c_int32],
@@ -121,7 +122,7 @@ DECLARED_SYMBOLS = [
     "sbr_fit_step_local", "sbr_fit_step_apply", "sbr_fit_step_scatter", "sbr_fit_step_dense", "sbr_fit_step_owner_reduce", "sbr_fit_step_owner_reduce_on", "sbr_fit_step_apply_table", "sbr_fit_step_apply_rows", "sbr_fit_step_apply_dense", "sbr_model_set_stream", "sbr_model_synchronize",
     "sbr_fit_debug_fetch", "sbr_user_representation", "sbr_predict", "sbr_mrr_score", "sbr_model_param_count",
     "sbr_model_get_param", "sbr_model_set_param", "sbr_model_get_param_rows", "sbr_model_get_epoch", "sbr_model_get_counters", "sbr_model_set_counters", "sbr_device_info", "sbr_status_string",
-    "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_set_overlap", "sbr_model_timing_read", "sbr_set_device", "sbr_group_fit", "sbr_device_count", "sbr_group_create", "sbr_model_is_partitioned", "sbr_model_create_partitioned", "sbr_partition_num_parts", "sbr_fit_exchange_export", "sbr_fit_exchange_import",
+    "sbr_abi_version", "sbr_model_timing_enable", "sbr_model_timing_select", "sbr_model_set_overlap", "sbr_model_timing_read", "sbr_set_device", "sbr_group_fit", "sbr_device_count", "sbr_group_create", "sbr_model_is_partitioned", "sbr_model_create_partitioned", "sbr_partition_num_parts", "sbr_fit_exchange_export", "sbr_fit_exchange_import",
     "sbr_fit_step_scatter_shared", "sbr_fit_step_owner_reduce_peers", "sbr_fit_step_apply_table_peers",
     "sbr_partition_part_info", "sbr_partition_export_part", "sbr_partition_import_part", "sbr_partition_finalize",
     "sbr_fit_lists_export", "sbr_fit_lists_import", "sbr_fit_step_reduce_own", "sbr_fit_step_owner_apply", "sbr_selftest_math",

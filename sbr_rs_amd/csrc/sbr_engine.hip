@@ -328,6 +328,7 @@ struct sbr_model {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scored = nullptr, ev_sorted = nullptr;
     std::mutex mu;
     bool timing = false;
+    uint32_t timing_mask = 0xffffffffu; /* kernel families whose launches are bracketed by events while `timing` is on */
     bool overlap = true; /* false: the side-stream work is queued on the main stream (standalone kernel timing) */
     std::vector<TimingPair> pending;
     double ms[SBR_K_FAMILIES] = {0};
@@ -342,7 +343,7 @@ struct ScopedTimer {
     bool on;
     hipStream_t st;
     ScopedTimer(sbr_model* model, int family, uint64_t launches, hipStream_t stream = nullptr)
-        : m(model), on(model->timing), st(stream ? stream : model->stream) {
+        : m(model), on(model->timing && ((model->timing_mask >> family) & 1u)), st(stream ? stream : model->stream) {
         if (!on) return;
         tp.family = family;
         tp.launches = launches;
@@ -607,7 +608,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 7; }
+uint32_t sbr_abi_version(void) { return 8; }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -988,6 +989,12 @@ sbr_status sbr_model_set_overlap(sbr_model* m, int32_t enable) {
 sbr_status sbr_model_timing_enable(sbr_model* m, int32_t enable) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
     m->timing = enable != 0;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_timing_select(sbr_model* m, uint32_t family_mask) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    m->timing_mask = family_mask;
     return SBR_OK;
 }
 

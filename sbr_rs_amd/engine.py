@@ -283,6 +283,11 @@ class Model:
     def timing_enable(self, on: bool = True):
         _check(self._L.sbr_model_timing_enable(self._h, 1 if on else 0))
 
+    def timing_select(self, families=None):
+        """Which kernel families are bracketed by events while timing is on (names of ``KernelFamily``; None = all)."""
+        mask = 0xFFFFFFFF if families is None else sum(1 << int(KernelFamily[f]) for f in families)
+        _check(self._L.sbr_model_timing_select(self._h, mask))
+
     def set_overlap(self, on: bool = True):
         """False: side-stream work runs on the main stream, so kernel families are timed standalone."""
         _check(self._L.sbr_model_set_overlap(self._h, 1 if on else 0))

@@ -72,6 +72,8 @@ def lib():
         L.orc_model_last_fit_lagged_loss.argtypes = [vp, fp]
         L.orc_fit_step_local_sample.argtypes = [vp, C.c_int, C.c_uint64, vp, C.c_uint32, vp, u32p, vp]
         L.orc_row_step.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, fp, fp]
+        L.orc_row_reduce.argtypes = [C.c_uint32, C.c_uint32, vp, vp, vp, vp, fp, C.POINTER(C.c_int32)]
+        L.orc_row_apply.argtypes = [vp, vp, C.c_float, C.c_int32, vp, vp, fp, fp]
         L.orc_dense_chain.argtypes = [vp, vp, C.c_uint64]
         L.orc_dense_chain.restype = C.c_float
         L.orc_model_apply_dense.argtypes = [vp, vp, C.c_uint64]
@@ -258,6 +260,18 @@ def dense_chain(a, dz) -> np.float32:
     return np.float32(lib().orc_dense_chain(_ptr(a) if a is not None else None, _ptr(dz), dz.size))
 
 
+def row_reduce(vecs, scale, has_bias):
+    """One DEVICE's gradient of one item-table row from its ordered entry list (the contract's chunked in-order sum):
+    (g [d], bias gradient, has_bias)."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+    scale = np.ascontiguousarray(scale, dtype=np.float32)
+    hb = np.ascontiguousarray(has_bias, dtype=np.uint8)
+    g = np.zeros(vecs.shape[1], dtype=np.float32)
+    gb, has = C.c_float(), C.c_int32()
+    _check(lib().orc_row_reduce(vecs.shape[1], scale.size, _ptr(vecs), _ptr(scale), _ptr(hb), _ptr(g), C.byref(gb), C.byref(has)))
+    return g, np.float32(gb.value), bool(has.value)
+
+
 class OracleModel:
     def __init__(self, hp: SbrHparams):
         self.hp = hp
@@ -335,6 +349,16 @@ class OracleModel:
         bb, ba = C.c_float(float(b)), C.c_float(float(bacc))
         assert vecs.shape == (scale.size, self.storage_dim) and w.size == acc.size == self.storage_dim
         _check(lib().orc_row_step(self._h, scale.size, _ptr(vecs), _ptr(scale), _ptr(hb), _ptr(w), _ptr(acc), C.byref(bb), C.byref(ba)))
+        return w, acc, np.float32(bb.value), np.float32(ba.value)
+
+    def row_apply(self, g, gb, has_bias, w, acc, b, bacc):
+        """The optimiser update (Adagrad with this model's hyper-parameters) of one item-table row from an explicit gradient:
+        returns (w, acc, b, bacc) after the step."""
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        w = np.array(w, dtype=np.float32, copy=True)
+        acc = np.array(acc, dtype=np.float32, copy=True)
+        bb, ba = C.c_float(float(b)), C.c_float(float(bacc))
+        _check(lib().orc_row_apply(self._h, _ptr(g), C.c_float(float(gb)), 1 if has_bias else 0, _ptr(w), _ptr(acc), C.byref(bb), C.byref(ba)))
         return w, acc, np.float32(bb.value), np.float32(ba.value)
 
     def apply_dense(self, dense):

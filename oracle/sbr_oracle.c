@@ -855,6 +855,41 @@ int orc_row_step(orc_model* m, uint32_t n, const float* vecs, const float* scale
     return SBR_OK;
 }
 
+/* The two halves of orc_row_step, for a row touched by SEVERAL devices (the multi-device optimiser step: every device reduces its
+ * own entries — orc_fit_scatter —, the owner adds the devices' sums in device order — orc_fit_owner_reduce: the first toucher
+ * initialises —, every replica applies one update — orc_fit_apply_table): orc_row_reduce = one device's chunked in-order sum,
+ * orc_row_apply = the optimiser update from an explicit gradient. */
+int orc_row_reduce(uint32_t d, uint32_t n, const float* vecs, const float* scale, const uint8_t* has_bias, float* g, float* gb,
+                   int32_t* has_b_out) {
+    if (n == 0 || !g || !gb || !has_b_out) return SBR_ERR_INVALID_ARGUMENT;
+    float* part = (float*)malloc(sizeof(float) * d);
+    float gbv = 0.0f; int has_b = 0, first_chunk = 1;
+    for (uint32_t c0 = 0; c0 < n; c0 += ORC_SEG_CHUNK) {
+        uint32_t c1 = c0 + ORC_SEG_CHUNK < n ? c0 + ORC_SEG_CHUNK : n;
+        float pb = 0.0f; int phb = 0, first = 1;
+        for (uint32_t e = c0; e < c1; ++e) {
+            const float* srcv = vecs + (size_t)e * d;
+            float sc = scale[e];
+            if (first) { for (uint32_t k = 0; k < d; ++k) part[k] = sc * srcv[k]; first = 0; }
+            else for (uint32_t k = 0; k < d; ++k) part[k] = part[k] + sc * srcv[k];
+            if (has_bias[e]) { pb = phb ? pb + sc : sc; phb = 1; }
+        }
+        if (first_chunk) { for (uint32_t k = 0; k < d; ++k) g[k] = part[k]; first_chunk = 0; }
+        else for (uint32_t k = 0; k < d; ++k) g[k] = g[k] + part[k];
+        if (phb) { gbv = has_b ? gbv + pb : pb; has_b = 1; }
+    }
+    free(part);
+    *gb = gbv; *has_b_out = has_b;
+    return SBR_OK;
+}
+int orc_row_apply(orc_model* m, const float* g, float gb, int32_t has_b, float* w, float* acc, float* b, float* bacc) {
+    if (!m || m->hp.optimizer != SBR_OPT_ADAGRAD) return SBR_ERR_INVALID_ARGUMENT;
+    float dummy = 0.0f;
+    for (int k = 0; k < m->d; ++k) orc_opt(m, &w[k], &acc[k], &dummy, g[k]);
+    if (has_b) orc_opt(m, b, bacc, &dummy, gb);
+    return SBR_OK;
+}
+
 /* One element of the dense gradient from its two operand columns over ALL packed rows, in the contract's order (orc_backward):
  * rows in chunks of ORC_DW_CHUNK_ROWS, inside a chunk a row-ascending fma chain from 0 (a == NULL: the bias row, a plain add
  * chain), chunk partials added in chunk order. */

@@ -135,3 +135,89 @@ def check_first_step(full, o, po, *, lstm: bool, nb: int, nsel=64, nrows=256, nd
         for p in (Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC):
             _same(g.get_param(p), o.get_param(p), f"{p.name} after the step")
     return {"rows": int(R), "sampled_sequences": int(sel.size), "sampled_rows": int(n), "sampled_items": int(items.size), "max_entries_per_item": int(max_entries)}
+
+
+def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=160, seed=0):
+    """The multi-device step (user-sharded data parallelism) at a size the oracle cannot run whole.
+    `full`: adapter of the side that runs `world` devices' first step — .world, .rows(q), .step_local_all(), .fetch(q, which),
+    .apply_all(), .model(q).  `o`, `po`: an oracle model with num_devices = world and its plan, epoch prepared, not stepped.
+      1. per device: a sample of its sequences against the oracle's restatement of that device's half-step (its partition, its
+         negative-draw key);
+      2. sampled item rows: every device's own entries reduced in the contract's order (oracle.row_reduce), the devices' sums added
+         in device order (the first toucher initialises), ONE optimiser update (oracle.row_apply) — against the row on the first
+         and on the last replica after the step;
+      3. (LSTM) the devices' dense-gradient blocks added in device order, the oracle's dense update of that sum — against the dense
+         parameters of the first and the last replica."""
+    from oracle.oracle import row_reduce
+
+    rs = np.random.RandomState(seed)
+    world = full.world
+    g0 = full.model(0)
+    d = g0.storage_dim
+    assert d == g0.dim
+    full.step_local_all()
+    per = []
+    for q in range(world):
+        R = full.rows(q)
+        sel = pick_sequences(nb, nsel, rs)
+        idx, _off = po.step_local_sample(0, sel, device=q)
+        n = idx.size
+        assert n > 0 and idx.max() < R
+        arr = {}
+        for w in [Debug.IN_IDX, Debug.OUT_IDX, Debug.HIDDEN, Debug.NEGATIVES, Debug.TRIES, Debug.COEF, Debug.LOSS, Debug.DINPUT]:
+            arr[w] = full.fetch(q, w)
+            _same(arr[w][idx], po.debug_fetch(w, n, device=q), f"device {q}: sampled sequences: {w.name}")
+        all_rows = np.stack([arr[Debug.IN_IDX], arr[Debug.OUT_IDX], arr[Debug.NEGATIVES]], axis=1).ravel()
+        order = np.argsort(all_rows, kind="stable")
+        per.append({"H": arr[Debug.HIDDEN], "dX": arr[Debug.DINPUT], "coef": arr[Debug.COEF], "all": all_rows, "order": order,
+                    "sorted": all_rows[order], "dense": full.fetch(q, Debug.DENSE_GRAD) if lstm else None})
+    # sampled items: touched by some device (a third each from inputs, targets, negatives of random devices)
+    picks = []
+    for k in range(3):
+        q = int(rs.randint(world))
+        rr = rs.choice(per[q]["all"].size // 3, size=nrows // 3, replace=False)
+        picks.append(per[q]["all"][3 * rr + k])
+    items = np.unique(np.concatenate(picks)).astype(np.uint32)
+    params = (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC)
+    before = {p: g0.get_param_rows(p, items) for p in params}
+    for p in params:
+        _same(before[p], o.get_param_rows(p, items), f"initial {p.name} rows")
+    full.apply_all()
+    touched_by = np.zeros(items.size, dtype=np.int64)
+    for i, item in enumerate(items):
+        g = gb = None
+        has_b = False
+        for q in range(world):
+            P = per[q]
+            lo, hi = np.searchsorted(P["sorted"], item, side="left"), np.searchsorted(P["sorted"], item, side="right")
+            if hi == lo:
+                continue
+            touched_by[i] += 1
+            e = P["order"][lo:hi]
+            r, kind = e // 3, e % 3
+            vecs = np.where((kind == 0)[:, None], P["dX"][r], P["H"][r]).astype(np.float32)
+            scale = np.where(kind == 0, np.float32(1.0), np.where(kind == 1, -P["coef"][r], P["coef"][r])).astype(np.float32)
+            gq, gbq, hbq = row_reduce(vecs, scale, kind != 0)
+            g = gq if g is None else (g + gq).astype(np.float32)   # device order; the first toucher initialises
+            if hbq:
+                gb = gbq if not has_b else np.float32(gb + gbq)
+                has_b = True
+        assert g is not None
+        w, acc, b, bacc = o.row_apply(g, gb if has_b else np.float32(0), has_b, before[Param.ITEM_EMBEDDING][i], before[Param.ITEM_EMBEDDING_ACC][i],
+                                      before[Param.ITEM_BIAS][i], before[Param.ITEM_BIAS_ACC][i])
+        for q in (0, world - 1):
+            m = full.model(q)
+            _same(m.get_param_rows(Param.ITEM_EMBEDDING, [item])[0], w, f"item {item} on replica {q}: embedding row after the step")
+            _same(m.get_param_rows(Param.ITEM_EMBEDDING_ACC, [item])[0], acc, f"item {item} on replica {q}: accumulator row")
+            _same(m.get_param_rows(Param.ITEM_BIAS, [item]), np.array([b]), f"item {item} on replica {q}: bias")
+            _same(m.get_param_rows(Param.ITEM_BIAS_ACC, [item]), np.array([bacc]), f"item {item} on replica {q}: bias accumulator")
+    if lstm:
+        dense = per[0]["dense"].copy()
+        for q in range(1, world):
+            dense = (dense + per[q]["dense"]).astype(np.float32)
+        o.apply_dense(dense)
+        for q in (0, world - 1):
+            for p in (Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC):
+                _same(full.model(q).get_param(p), o.get_param(p), f"{p.name} on replica {q} after the step")
+    return {"world": world, "sampled_items": int(items.size), "items_touched_by_several_devices": int(np.sum(touched_by > 1)),
+            "rows_per_device": [int(full.rows(q)) for q in range(world)]}

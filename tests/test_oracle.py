@@ -494,3 +494,31 @@ def test_sampled_step_checker_agrees_with_the_whole_step(oracle_lib, kind, loss,
     nb = min(B, count_subsequences(ptr, T))
     out = check_first_step(Full(), o, po, lstm=kind != ModelKind.EWMA, nb=nb, nsel=40, nrows=90, ndense=30)
     assert out["sampled_sequences"] >= 30 and out["max_entries_per_item"] > 256  # the chunked hot-row reduction is exercised
+
+
+@pytest.mark.parametrize("kind,loss,d,world", [(ModelKind.LSTM_NORMAL, LOSS_WARP, 16, 3), (ModelKind.EWMA, LOSS_HINGE, 32, 4)])
+def test_sampled_multi_device_checker_agrees_with_the_whole_step(oracle_lib, kind, loss, d, world):
+    """The multi-device variant of the sampled checker (per-device half-steps, device-ordered row sums, one update; dense blocks
+    added in device order) against the oracle's own multi-device step at a size it can run whole."""
+    from sampled_parity import check_first_step_multi, count_subsequences
+
+    items, T, B = 97, 9, 150
+    ptr, it = synthetic_interactions(700, items, T + 4, seed=8, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, B=B, epochs=1, ndev=world)
+    full_m, o = OracleModel(hp), OracleModel(hp)
+    pf, po = full_m.fit_begin(ptr, it), o.fit_begin(ptr, it)
+    assert pf.epoch_prepare() == po.epoch_prepare()
+
+    class Full:
+        pass
+
+    f = Full()
+    f.world = world
+    f.model = lambda q: full_m
+    f.rows = lambda q: pf.minibatch_rows(0, device=q)
+    f.step_local_all = lambda: [pf.compute_local(0, q) for q in range(world)]
+    f.fetch = lambda q, which: pf.debug_fetch(which, f.rows(q), device=q)
+    f.apply_all = lambda: pf.step(0)  # recomputes every device's half-step (deterministic) and applies the exchanged update
+    nb = min(B, count_subsequences(ptr, T) // world)
+    out = check_first_step_multi(f, o, po, lstm=kind != ModelKind.EWMA, nb=nb, nsel=12, nrows=60)
+    assert out["items_touched_by_several_devices"] > 10

@@ -1090,3 +1090,67 @@ def test_bench_regime_first_step_sampled_parity(name, kind, loss, d, users, item
     out = check_first_step(Full(), o, po, lstm=kind != ModelKind.EWMA, nb=nb)
     assert out["rows"] > 250_000 and out["sampled_sequences"] >= 60 and out["sampled_items"] >= 200, out
     pg.close(); po.close()
+
+
+def test_bench_regime_multi_device_first_step_sampled_parity():
+    """BASELINE configs[3] at full size — 1e6 users over 8 devices, 1e6 items, sequences to 128, d = 128, LSTM + WARP, 8 192
+    sequences per device and step — through the multi-GPU protocol's C-ABI halves (scatter into 8 per-owner chunks of 125 000
+    rows, owner reduce over 8 inputs, table update from 8 reduced chunks, dense update from 8 blocks) with eight simulated ranks on
+    ONE GPU and tensor copies in place of the collectives.  The first optimiser step is compared with the oracle by sampling
+    (tests/sampled_parity.py::check_first_step_multi): every device's half-step on a sample of its sequences, ~160 item rows'
+    device-ordered gradient sums and updates on the first and the last replica, and the dense parameters."""
+    import torch
+
+    import bench
+    from sampled_parity import check_first_step_multi, count_subsequences
+
+    world, users, items, T, d, B = 8, 125_000, 1_000_000, 128, 128, 8_192
+    ptr, it = bench.synthetic_csr(users * world, items, T)
+    kind, loss = ModelKind.LSTM_NORMAL, LOSS_WARP
+    models = [Model(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=q)) for q in range(world)]
+    plans = [m.fit_begin(ptr, it) for m in models]
+    o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=0))
+    po = o.fit_begin(ptr, it)
+    assert {p.epoch_prepare() for p in plans} == {po.epoch_prepare()}
+    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
+    u8 = dict(dtype=torch.uint8, device="cuda")
+
+    class Full:
+        pass
+
+    f = Full()
+    f.world = world
+    f.model = lambda q: models[q]
+    f.rows = lambda q: plans[q].minibatch_rows(0)
+    f.step_local_all = lambda: [plans[q].step_local(0) for q in range(world)]
+    f.fetch = lambda q, which: plans[q].debug_fetch(which, f.rows(q))
+
+    def apply_all():
+        send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
+        dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
+        recv = torch.zeros(world * chunk, **u8)
+        own = [torch.zeros(chunk, **u8) for _ in range(world)]
+        for q in range(world):
+            plans[q].step_scatter(0, send[q].data_ptr())
+            plans[q].step_dense(dense[q].data_ptr())
+            models[q].synchronize()
+        for q in range(world):  # all_to_all_single
+            for src in range(world):
+                recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
+            torch.cuda.synchronize()
+            plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
+            models[q].synchronize()
+        table = torch.cat(own)          # all_gather_into_tensor
+        dense_all = torch.cat(dense)
+        torch.cuda.synchronize()
+        for q in range(world):
+            plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
+            models[q].synchronize()
+
+    f.apply_all = apply_all
+    nb = min(B, count_subsequences(ptr, T) // world)
+    out = check_first_step_multi(f, o, po, lstm=True, nb=nb)
+    assert out["items_touched_by_several_devices"] > 50 and min(out["rows_per_device"]) > 400_000, out
+    for p in plans:
+        p.close()
+    po.close()

@@ -2184,6 +2184,58 @@ __device__ __forceinline__ void seg_accumulate(const BlockView& blk, const uint6
     *g_out = g; *gb_out = gb; *has_b_out = has_b;
 }
 
+// The same in-order sum for the chunks of LONG segments (hot rows: up to SBR_SEG_CHUNK entries per call): NB entries per batch
+// with their rows in flight together, and the NEXT batch's keys requested before this batch's rows are consumed — the short-segment
+// form above pays two dependent memory round trips (key, then row + coefficient) per four entries, which made a 256-entry chunk
+// 64 x ~2.5 us (Zipf(1) items at 8 192 sequences per step: 1 300 chunk units, seg_chunk_kernel 0.22 ms on the critical path).
+template <int D, int NB>
+__device__ __forceinline__ void seg_accumulate_long(const BlockView& blk, const uint64_t* keys, uint64_t begin, uint64_t end, int lg,
+                                                    float4* g_out, float* gb_out, bool* has_b_out) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gb = 0.0f;
+    bool has_b = false, first = true;
+    uint32_t src_n[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) src_n[i] = begin + i < end ? (uint32_t)keys[begin + i] : 0u;
+    for (uint64_t e = begin; e < end; e += NB) {
+        float4 v[NB];
+        float sc[NB];
+        uint32_t kind[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t src = src_n[i];
+            const uint32_t r = src / 3;
+            kind[i] = src % 3;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sc[i] = 0.0f;
+            if (e + i < end) {
+                v[i] = ld4((kind[i] == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
+                sc[i] = blk.coef[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) src_n[i] = e + NB + i < end ? (uint32_t)keys[e + NB + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (e + i < end) {
+                const float s = kind[i] == 0 ? 1.0f : (kind[i] == 1 ? -sc[i] : sc[i]);
+                if (first) {
+                    g = make_float4(s * v[i].x, s * v[i].y, s * v[i].z, s * v[i].w);
+                    first = false;
+                } else {
+                    g.x = g.x + s * v[i].x; g.y = g.y + s * v[i].y;
+                    g.z = g.z + s * v[i].z; g.w = g.w + s * v[i].w;
+                }
+                if (kind[i] != 0) {
+                    gb = has_b ? gb + s : s;
+                    has_b = true;
+                }
+            }
+        }
+    }
+    *g_out = g; *gb_out = gb; *has_b_out = has_b;
+}
+
 // first position in [lo, hi) whose row differs from `row` (keys are sorted by row)
 __device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, uint64_t hi, uint32_t row) {
     while (lo < hi) {
@@ -2243,12 +2295,12 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
             float4 g;
             float gb;
             bool has_b;
-            seg_accumulate<D>(blk, keys, p, p + SBR_SEG_CHUNK, lg, &g, &gb, &has_b);
+            seg_accumulate_long<D, 8>(blk, keys, p, p + SBR_SEG_CHUNK, lg, &g, &gb, &has_b);
             for (uint64_t q = p + SBR_SEG_CHUNK; q < p + len; q += SBR_SEG_CHUNK) {
                 float4 v;
                 float vb;
                 bool vh;
-                seg_accumulate<D>(blk, keys, q, q + SBR_SEG_CHUNK < p + len ? q + SBR_SEG_CHUNK : p + len, lg, &v, &vb, &vh);
+                seg_accumulate_long<D, 8>(blk, keys, q, q + SBR_SEG_CHUNK < p + len ? q + SBR_SEG_CHUNK : p + len, lg, &v, &vb, &vh);
                 g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w;
                 if (vh) {
                     gb = has_b ? gb + vb : vb;
@@ -2363,7 +2415,7 @@ __global__ __launch_bounds__(256) void seg_chunk_kernel(BlockView blk, const uin
         float4 g;
         float gb;
         bool has_b;
-        seg_accumulate<D>(blk, keys, begin, end, lg, &g, &gb, &has_b);
+        seg_accumulate_long<D, 16>(blk, keys, begin, end, lg, &g, &gb, &has_b);
         st4(sc.P + u * D + 4 * lg, g);
         if (lg == 0) {
             sc.Pb[u] = gb;

@@ -117,7 +117,7 @@ def measured_traffic(which, rows_per_launch, k_mean, d, items=None):
     return None, None
 
 
-def live_traffic(kernel, warmup_dispatches, timeout_s=240):
+def live_traffic(kernel, warmup_dispatches, timeout_s=150):
     """HBM bytes per launch of `kernel` at THIS run's operating point, measured now: two rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, only --kernel-trace beside them — MI355X_MICROARCH.md "HBM") around a child run of this
     command line (same workload, batch, steps; extras off), the timed dispatches only.  Corrections as calibrated in

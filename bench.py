@@ -117,7 +117,7 @@ def measured_traffic(which, rows_per_launch, k_mean, d, items=None):
     return None, None
 
 
-def live_traffic(kernel, warmup_dispatches, timeout_s=150):
+def live_traffic(kernel, warmup_dispatches, timed_dispatches, timeout_s=150):
     """HBM bytes per launch of `kernel` at THIS run's operating point, measured now: two rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, only --kernel-trace beside them — MI355X_MICROARCH.md "HBM") around a child run of this
     command line (same workload, batch, steps; extras off), the timed dispatches only.  Corrections as calibrated in
@@ -160,7 +160,9 @@ def live_traffic(kernel, warmup_dispatches, timeout_s=150):
             dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
             if res.returncode != 0 or not dbs:
                 return None
-            vals[counter] = per_dispatch(dbs[0], counter, kernel)[warmup_dispatches:]
+            # the timed region's dispatches only (the child goes on with the second, all-timers pass and the model keeps learning:
+            # later launches try more negatives per row)
+            vals[counter] = per_dispatch(dbs[0], counter, kernel)[warmup_dispatches:warmup_dispatches + timed_dispatches]
             line = json.loads([x for x in res.stdout.splitlines() if x.startswith('{"metric"')][-1])
         n = min(len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"]))
         if n == 0 or not line or not line.get("roofline"):
@@ -755,7 +757,7 @@ def main():
             traffic_source = None
             pmc_kernel = "ewma_seq_kernel" if model_kind == 2 and loss_kind != 2 else "score_kernel" if loss_kind == 2 else "score_single_kernel"
             if args.traffic == "live" and world == 1 and not args.force_exchange:
-                lt = live_traffic(pmc_kernel, args.warmup)
+                lt = live_traffic(pmc_kernel, args.warmup, args.steps)
                 # the child's operating point must be this run's (same command line): rows per launch and negatives per row within 5 %
                 if lt and abs(lt["rows_per_launch"] / max(rows_per_launch, 1) - 1) <= 0.05 and abs(lt["mean_negatives_scored"] / max(k_mean, 1e-9) - 1) <= 0.05:
                     traffic, traffic_lower = lt["hbm_bytes_per_launch"], lt["hbm_bytes_per_launch_lower"]

@@ -738,10 +738,9 @@ def main():
             if n:
                 kernels[name] = {"ms_total": ms, "launches": int(n), "ms_per_launch": ms / n}
         if "SPARSE_SORT" in kernels and world == 1 and loss_kind == 2:
-            kernels["SPARSE_SORT"]["note"] = ("elapsed on its own stream from the end of the score kernel, underneath the backward pass whose workgroups "
-                                              "it yields to (A/B on one box, 3 runs each: 13.34 ms per step this way, 13.54 with the ordering on the main "
-                                              "stream before BPTT where it reads 0.28 ms, 13.52 after BPTT); alone: kernels_standalone; it ends before BPTT "
-                                              "does and the update starts 0.02 ms after BPTT (profiles/r03_step_timeline.txt)")
+            kernels["SPARSE_SORT"]["note"] = ("elapsed on its own stream from the end of the score kernel, underneath the backward pass whose MFMA waves it "
+                                              "yields to (wave priority 1; placement and priority A/B: profiles/r04_tail_experiments.md); alone: "
+                                              "kernels_standalone; the step's loss bookkeeping (seq_loss, block_header) rides on the same stream")
         # roofline of the gather + WARP-score kernel: algorithmic bytes per packed row:
         # (2+k)*4d for h, the positive row and k negative rows, (1+k)*4 for their biases
         score = kernels.get("SCORE")

@@ -2188,15 +2188,21 @@ __device__ __forceinline__ void seg_accumulate(const BlockView& blk, const uint6
 // with their rows in flight together, and the NEXT batch's keys requested before this batch's rows are consumed — the short-segment
 // form above pays two dependent memory round trips (key, then row + coefficient) per four entries, which made a 256-entry chunk
 // 64 x ~2.5 us (Zipf(1) items at 8 192 sequences per step: 1 300 chunk units, seg_chunk_kernel 0.22 ms on the critical path).
+// The chunk kernel takes NB = 4 at 80 registers (the short-segment kernel's budget): it is launched on every step, beside the
+// dense-gradient GEMM whose four workgroups per CU leave 64-176 registers per SIMD lane free — at NB = 16 (256 registers) or NB = 8
+// (140) its workgroups could not become resident until the GEMM's tail even when there was nothing for them to do (uniform items:
+// 1.85 ms of elapsed time for an empty launch at 50 000 sequences per step), and 1 024 workgroups took four rounds.
 template <int D, int NB>
 __device__ __forceinline__ void seg_accumulate_long(const BlockView& blk, const uint64_t* keys, uint64_t begin, uint64_t end, int lg,
                                                     float4* g_out, float* gb_out, bool* has_b_out) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     float gb = 0.0f;
     bool has_b = false, first = true;
+    const uint32_t* klo = reinterpret_cast<const uint32_t*>(keys);  // the low word of a key is its source (3 x packed row + kind)
     uint32_t src_n[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) src_n[i] = begin + i < end ? (uint32_t)keys[begin + i] : 0u;
+    for (int i = 0; i < NB; ++i) src_n[i] = begin + i < end ? klo[2 * (begin + i)] : 0u;
+#pragma unroll 1
     for (uint64_t e = begin; e < end; e += NB) {
         float4 v[NB];
         float sc[NB];
@@ -2214,7 +2220,7 @@ __device__ __forceinline__ void seg_accumulate_long(const BlockView& blk, const 
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) src_n[i] = e + NB + i < end ? (uint32_t)keys[e + NB + i] : 0u;
+        for (int i = 0; i < NB; ++i) src_n[i] = e + NB + i < end ? klo[2 * (e + NB + i)] : 0u;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (e + i < end) {
@@ -2396,7 +2402,7 @@ __global__ void seg_units_kernel(SegScratch sc) {
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void seg_chunk_kernel(BlockView blk, const uint64_t* keys, SegScratch sc) {
+__global__ __launch_bounds__(256, 6) void seg_chunk_kernel(BlockView blk, const uint64_t* keys, SegScratch sc) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
@@ -2415,7 +2421,7 @@ __global__ __launch_bounds__(256) void seg_chunk_kernel(BlockView blk, const uin
         float4 g;
         float gb;
         bool has_b;
-        seg_accumulate_long<D, 16>(blk, keys, begin, end, lg, &g, &gb, &has_b);
+        seg_accumulate_long<D, 4>(blk, keys, begin, end, lg, &g, &gb, &has_b);
         st4(sc.P + u * D + 4 * lg, g);
         if (lg == 0) {
             sc.Pb[u] = gb;

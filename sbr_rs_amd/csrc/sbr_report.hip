@@ -24,6 +24,7 @@ namespace sbr {
 
 // one thread per sequence: the summed loss node of the sequence, t ascending
 __global__ __launch_bounds__(256) void seq_loss_kernel(MbView mb, const float* loss, float* seqsum) {
+    __builtin_amdgcn_s_setprio(3); /* rides the ordering's stream underneath BPTT's older MFMA waves, like the ordering itself */
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= mb.B) return;
     const int n = mb.steps[b];
@@ -107,11 +108,18 @@ __global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, cons
 __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
                                                           const unsigned int* part_tries, int nparts, double* loss_acc,
                                                           unsigned long long* ex_acc, MbView mb, const float* loss, float* lag_state) {
+    /* one workgroup, usually underneath BPTT on the ordering's stream: at priority 0 it took 1.5 ms of elapsed time at 50 000
+     * sequences per step (every instruction waits for an MFMA pass of the older waves) and held the key ordering up by as much */
+    __builtin_amdgcn_s_setprio(3);
     __shared__ double part[4];
     __shared__ unsigned int tpart[4];
-    __shared__ float ssum[SBR_HEADER_LAG_MAX_B];
-    __shared__ int ssteps[SBR_HEADER_LAG_MAX_B];
-    __shared__ float sx[SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B];
+    /* the lagged figure's staging (24 KB) is DYNAMIC shared memory, asked for only by the small-step launch that uses it: as static
+     * memory it kept the header launch of a 50 000-sequence step off the chip until a BPTT workgroup retired (64-sequence tiles
+     * leave less than 24 KB of LDS per CU) — 1.5 ms during which the key ordering behind it on the stream could not start */
+    extern __shared__ float lag_lds[];
+    float* ssum = lag_lds;
+    int* ssteps = reinterpret_cast<int*>(lag_lds + SBR_HEADER_LAG_MAX_B);
+    float* sx = lag_lds + 2 * SBR_HEADER_LAG_MAX_B;
     double acc = 0.0;
     unsigned int tacc = 0;
     for (int i = threadIdx.x; i < nparts; i += 256) {
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
 void launch_block_header_parts(uint32_t* header, int rows_host, const double* part_loss, const unsigned int* part_tries, int nparts,
                                double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
                                hipStream_t s) {
-    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), 0, s, header, rows_host, part_loss, part_tries, nparts, loss_acc, ex_acc,
+    const size_t lds = lag_state ? (size_t)(2 * SBR_HEADER_LAG_MAX_B + (SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B)) * 4 : 0;
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), lds, s, header, rows_host, part_loss, part_tries, nparts, loss_acc, ex_acc,
                        mb, loss, lag_state);
 }
 

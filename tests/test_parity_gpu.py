@@ -1194,3 +1194,57 @@ def test_bench_regime_whole_steps_full_parity(name, kind, loss, d, items, users,
     assert bits(np.float32(pg.end_lagged())) == bits(np.float32(po.end_lagged()))
     assert_params_equal(g, o, kind, f"{name}: after {steps} whole steps")
     pg.close(); po.close()
+
+
+def test_bench_regime_two_devices_whole_step_full_parity():
+    """The multi-GPU step at configs[3]'s per-GPU size with no sampling: two devices x 125 000 users, sequences to 128, d = 128,
+    LSTM + WARP, 8 192 sequences per device — one whole optimiser step through the protocol's C-ABI halves (two simulated ranks on
+    one GPU, tensor copies for the collectives: scatter into two 500 000-row owner chunks, owner reduce, table update, dense
+    update), then every parameter and accumulator of BOTH replicas against the oracle with num_devices = 2.  The eight-device
+    step of the full configs[3] is compared by sampling above (its whole step is ~80 s of oracle time)."""
+    import torch
+
+    import bench
+
+    world, users, items, T, d, B = 2, 125_000, 1_000_000, 128, 128, 8_192
+    kind, loss = ModelKind.LSTM_NORMAL, LOSS_WARP
+    ptr, it = bench.synthetic_csr(users * world, items, T)
+    models = [Model(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=q)) for q in range(world)]
+    plans = [m.fit_begin(ptr, it) for m in models]
+    o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=0))
+    po = o.fit_begin(ptr, it)
+    assert {p.epoch_prepare() for p in plans} == {po.epoch_prepare()}
+    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
+    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
+    recv = torch.zeros(world * chunk, **u8)
+    own = [torch.zeros(chunk, **u8) for _ in range(world)]
+    rows = 0
+    for q in range(world):
+        rows += plans[q].minibatch_rows(0)
+        plans[q].step_local(0)
+        plans[q].step_scatter(0, send[q].data_ptr())
+        plans[q].step_dense(dense[q].data_ptr())
+        models[q].synchronize()
+    assert rows > 900_000
+    for q in range(world):  # all_to_all_single
+        for src in range(world):
+            recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
+        torch.cuda.synchronize()
+        plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
+        models[q].synchronize()
+    table, dense_all = torch.cat(own), torch.cat(dense)  # all_gather_into_tensor
+    torch.cuda.synchronize()
+    for q in range(world):
+        plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
+        models[q].synchronize()
+    po.step(0)
+    lo, eo = po.end()
+    for q in range(world):
+        assert_params_equal(models[q], o, kind, f"two devices, whole step, rank {q}")
+        lg, eg = plans[q].end()
+        assert eg == eo == rows and lg == pytest.approx(lo, rel=1e-6)
+    for p in plans:
+        p.close()
+    po.close()

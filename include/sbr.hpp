@@ -199,6 +199,7 @@ class Interaction {
 };
 
 class CompressedInteractions;
+class TripletInteractions;
 
 /// A collection of individual interactions (data.rs:92-211).
 class Interactions {
@@ -234,6 +235,7 @@ class Interactions {
         return {std::move(head), std::move(tail)};
     }
     inline CompressedInteractions to_compressed() const;
+    inline TripletInteractions to_triplet() const;
     std::size_t num_users() const { return num_users_; }
     std::size_t num_items() const { return num_items_; }
     std::pair<std::size_t, std::size_t> shape() const { return {num_users_, num_items_}; }
@@ -379,6 +381,81 @@ class CompressedInteractions {
 };
 
 inline CompressedInteractions Interactions::to_compressed() const { return CompressedInteractions::from(*this); }
+
+/// A minibatch of triplet interactions: views into the three arrays (data.rs:502-520).
+struct TripletMinibatch {
+    const UserId* user_ids;
+    const ItemId* item_ids;
+    const Timestamp* timestamps;
+    std::size_t size;
+    std::size_t len() const { return size; }
+    bool is_empty() const { return size == 0; }
+};
+
+/// Interactions in COO form (data.rs:435-481).  Not consumed by the sequence models; kept for API parity.
+class TripletInteractions {
+  public:
+    /// Minibatches of exactly minibatch_size interactions over [idx, stop_idx): a shorter remainder is never
+    /// yielded (data.rs:522-545).  next() returns false at the end.
+    class MinibatchIterator {
+      public:
+        MinibatchIterator(const TripletInteractions* interactions, std::size_t idx, std::size_t stop_idx, std::size_t minibatch_size)
+            : interactions_(interactions), idx_(idx), stop_idx_(stop_idx), minibatch_size_(minibatch_size) {}
+        /// The same data and minibatch size over [start, stop) (data.rs:491-499).
+        MinibatchIterator slice(std::size_t start, std::size_t stop) const { return {interactions_, start, stop, minibatch_size_}; }
+        bool next(TripletMinibatch& out) {
+            const std::size_t start = idx_, stop = idx_ + minibatch_size_;
+            idx_ = stop;
+            if (stop > stop_idx_) return false;
+            out = {interactions_->user_ids_.data() + start, interactions_->item_ids_.data() + start,
+                   interactions_->timestamps_.data() + start, minibatch_size_};
+            return true;
+        }
+
+      private:
+        const TripletInteractions* interactions_;
+        std::size_t idx_, stop_idx_, minibatch_size_;
+    };
+
+    /// `impl From<&Interactions>` (data.rs:558-575): the interactions' own order.
+    static TripletInteractions from(const Interactions& interactions) {
+        TripletInteractions out;
+        out.num_users_ = interactions.num_users();
+        out.num_items_ = interactions.num_items();
+        out.user_ids_.reserve(interactions.len());
+        out.item_ids_.reserve(interactions.len());
+        out.timestamps_.reserve(interactions.len());
+        for (const auto& x : interactions.data()) {
+            out.user_ids_.push_back(x.user_id());
+            out.item_ids_.push_back(x.item_id());
+            out.timestamps_.push_back(x.timestamp());
+        }
+        return out;
+    }
+    std::size_t len() const { return user_ids_.size(); }
+    bool is_empty() const { return user_ids_.empty(); }
+    MinibatchIterator iter_minibatch(std::size_t minibatch_size) const { return {this, 0, len(), minibatch_size}; }
+    /// num_partitions iterators over consecutive slices of len / num_partitions interactions (integer division:
+    /// the remainder belongs to no partition, data.rs:463-475).
+    std::vector<MinibatchIterator> iter_minibatch_partitioned(std::size_t minibatch_size, std::size_t num_partitions) const {
+        const MinibatchIterator iterator = iter_minibatch(minibatch_size);
+        const std::size_t chunk_size = len() / num_partitions;
+        std::vector<MinibatchIterator> out;
+        for (std::size_t x = 0; x < num_partitions; ++x) out.push_back(iterator.slice(x * chunk_size, (x + 1) * chunk_size));
+        return out;
+    }
+    std::size_t num_users() const { return num_users_; }
+    std::size_t num_items() const { return num_items_; }
+    std::pair<std::size_t, std::size_t> shape() const { return {num_users_, num_items_}; }
+
+  private:
+    std::size_t num_users_ = 0, num_items_ = 0;
+    std::vector<UserId> user_ids_;
+    std::vector<ItemId> item_ids_;
+    std::vector<Timestamp> timestamps_;
+};
+
+inline TripletInteractions Interactions::to_triplet() const { return TripletInteractions::from(*this); }
 
 } // namespace data
 

@@ -174,6 +174,10 @@ class Interactions:
     def to_compressed(self) -> "CompressedInteractions":
         return CompressedInteractions.from_interactions(self)
 
+    def to_triplet(self) -> "TripletInteractions":
+        """COO form (data.rs:132-134, 558-575): three parallel arrays in the interactions' order."""
+        return TripletInteractions(self._num_users, self._num_items, self._users, self._items, self._timestamps)
+
 
 def train_test_split(interactions: Interactions, rng: XorShiftRng, test_fraction: float):
     """Random split (data.rs:54-64): shuffle in place, the first ``test_fraction`` is the test set."""
@@ -272,3 +276,78 @@ class CompressedInteractions:
         counts = np.diff(self.user_pointers.astype(np.int64))
         users = np.repeat(np.arange(self._num_users, dtype=np.uint64), counts)
         return Interactions.from_arrays(users, self.item_ids, self.timestamps, self._num_users, self._num_items)
+
+
+class TripletMinibatch:
+    """A minibatch of triplet interactions: views of the three arrays (data.rs:502-520)."""
+
+    def __init__(self, user_ids: np.ndarray, item_ids: np.ndarray, timestamps: np.ndarray):
+        self.user_ids, self.item_ids, self.timestamps = user_ids, item_ids, timestamps
+
+    def len(self) -> int:
+        return int(self.user_ids.shape[0])
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return self.item_ids.shape[0] == 0
+
+
+class TripletMinibatchIterator:
+    """Minibatches of exactly ``minibatch_size`` interactions over [idx, stop_idx): a shorter remainder is never yielded
+    (data.rs:522-545)."""
+
+    def __init__(self, interactions: "TripletInteractions", idx: int, stop_idx: int, minibatch_size: int):
+        self._interactions, self._idx, self._stop_idx, self._minibatch_size = interactions, int(idx), int(stop_idx), int(minibatch_size)
+
+    def slice(self, start: int, stop: int) -> "TripletMinibatchIterator":
+        """An iterator over [start, stop) of the same data with the same minibatch size (data.rs:491-499)."""
+        return TripletMinibatchIterator(self._interactions, start, stop, self._minibatch_size)
+
+    def __iter__(self) -> "TripletMinibatchIterator":
+        return self
+
+    def __next__(self) -> TripletMinibatch:
+        start, stop = self._idx, self._idx + self._minibatch_size
+        self._idx = stop
+        if stop > self._stop_idx:
+            raise StopIteration
+        t = self._interactions
+        return TripletMinibatch(t.user_ids[start:stop], t.item_ids[start:stop], t.timestamps[start:stop])
+
+
+class TripletInteractions:
+    """Interactions in COO form (data.rs:435-481).  Not consumed by the sequence models; kept for API parity."""
+
+    def __init__(self, num_users: int, num_items: int, user_ids, item_ids, timestamps):
+        self._num_users, self._num_items = int(num_users), int(num_items)
+        self.user_ids = np.ascontiguousarray(user_ids, dtype=np.uint64)
+        self.item_ids = np.ascontiguousarray(item_ids, dtype=np.uint64)
+        self.timestamps = np.ascontiguousarray(timestamps, dtype=np.uint64)
+
+    def len(self) -> int:
+        return int(self.user_ids.shape[0])
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return self.len() == 0
+
+    def iter_minibatch(self, minibatch_size: int) -> TripletMinibatchIterator:
+        return TripletMinibatchIterator(self, 0, self.len(), minibatch_size)
+
+    def iter_minibatch_partitioned(self, minibatch_size: int, num_partitions: int) -> List[TripletMinibatchIterator]:
+        """``num_partitions`` iterators over consecutive slices of len / num_partitions interactions (integer division: the
+        remainder belongs to no partition, data.rs:463-475)."""
+        iterator = self.iter_minibatch(minibatch_size)
+        chunk_size = self.len() // num_partitions
+        return [iterator.slice(x * chunk_size, (x + 1) * chunk_size) for x in range(num_partitions)]
+
+    def num_users(self) -> int:
+        return self._num_users
+
+    def num_items(self) -> int:
+        return self._num_items
+
+    def shape(self) -> Tuple[int, int]:
+        return (self._num_users, self._num_items)

@@ -109,6 +109,33 @@ static void test_chunk_iterator() {
     std::printf("chunks=%zu\n", chunks.size());
 }
 
+// ---- data.rs:435-575: COO form and its minibatch iterators (same cases as tests/test_oracle.py) --------
+static void triplet_minibatches() {
+    const std::size_t users[] = {3, 1, 2, 1, 0, 3, 2};
+    Interactions all(4, 20);
+    for (std::size_t i = 0; i < 7; ++i) all.push(Interaction(users[i], 10 + i, 7 - i));
+    const data::TripletInteractions t = all.to_triplet();
+    CHECK(t.len() == 7 && !t.is_empty() && t.num_users() == 4 && t.num_items() == 20 && t.shape().second == 20);
+    auto collect = [](data::TripletInteractions::MinibatchIterator it) {
+        std::vector<std::vector<std::size_t>> out;
+        data::TripletMinibatch b;
+        while (it.next(b)) out.emplace_back(b.item_ids, b.item_ids + b.len());
+        return out;
+    };
+    using V = std::vector<std::vector<std::size_t>>;
+    CHECK((collect(t.iter_minibatch(3)) == V{{10, 11, 12}, {13, 14, 15}}));  // the 7th interaction is never yielded
+    CHECK(collect(t.iter_minibatch(8)).empty());
+    const auto parts = t.iter_minibatch_partitioned(2, 2);  // chunk_size = 7 / 2 = 3
+    CHECK(parts.size() == 2 && (collect(parts[0]) == V{{10, 11}}) && (collect(parts[1]) == V{{13, 14}}));
+    CHECK(collect(t.iter_minibatch(7).slice(2, 6)).empty());
+    CHECK((collect(t.iter_minibatch(2).slice(1, 6)) == V{{11, 12}, {13, 14}}));
+    data::TripletMinibatch b;
+    auto it = t.iter_minibatch(3);
+    CHECK(it.next(b) && b.user_ids[0] == 3 && b.timestamps[2] == 5 && !b.is_empty());
+    CHECK(Interactions(3, 3).to_triplet().is_empty());
+    std::printf("triplets=%zu\n", t.len());
+}
+
 // ---- streams the Python host layer must reproduce (tests/test_cpp_facade.py) --------------------
 static void streams() {
     XorShiftRng rng = XorShiftRng::from_seed(seed42());
@@ -394,6 +421,7 @@ int main(int argc, char** argv) {
     try {
         if (which == "to_compressed") to_compressed();
         else if (which == "test_chunk_iterator") test_chunk_iterator();
+        else if (which == "triplet_minibatches") triplet_minibatches();
         else if (which == "streams") streams();
         else if (which == "split") split(arg);
         else if (which == "no_device") no_device();

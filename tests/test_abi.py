@@ -72,7 +72,7 @@ def test_python_surface_mirrors_reference_names():
         assert callable(getattr(h, setter)), setter
     assert callable(sbr.lstm.Hyperparameters.random) and callable(sbr.ewma.Hyperparameters.random)
     assert not hasattr(sbr.ewma.Hyperparameters.new(10, 8), "lstm_variant")
-    for name in ("user_based_split", "train_test_split", "Interaction", "Interactions", "CompressedInteractions"):
+    for name in ("user_based_split", "train_test_split", "Interaction", "Interactions", "CompressedInteractions", "TripletInteractions"):
         assert hasattr(sbr.data, name)
     assert callable(sbr.evaluation.mrr_score)
     assert issubclass(sbr.FittingError.NoInteractions, sbr.FittingError)

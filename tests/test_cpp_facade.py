@@ -63,6 +63,7 @@ def movielens_csv(tmp_path_factory):
 def test_reference_data_tests_in_cpp(facade):
     run(facade, "to_compressed")        # data.rs:587-627
     run(facade, "test_chunk_iterator")  # data.rs:629-660
+    run(facade, "triplet_minibatches")  # data.rs:435-575
 
 
 def test_streams_match_python_host_layer(facade):

@@ -56,6 +56,26 @@ def test_to_compressed_split_conserves_interactions():
     assert not set(np.unique(tr.arrays()[0])) & set(np.unique(te.arrays()[0]))  # no user in both
 
 
+def test_triplet_minibatches_follow_the_reference():
+    """TripletInteractions (data.rs:435-575): COO arrays in the interactions' order; an iterator yields only whole minibatches;
+    the partitioned form slices len / n interactions per partition and drops the remainder."""
+    inter = Interactions.from_arrays([3, 1, 2, 1, 0, 3, 2], [10, 11, 12, 13, 14, 15, 16], [7, 6, 5, 4, 3, 2, 1], 4, 20)
+    t = inter.to_triplet()
+    assert t.len() == 7 and not t.is_empty() and t.shape() == (4, 20) and t.num_users() == 4 and t.num_items() == 20
+    assert list(t.user_ids) == [3, 1, 2, 1, 0, 3, 2] and list(t.item_ids) == [10, 11, 12, 13, 14, 15, 16]
+    batches = list(t.iter_minibatch(3))
+    assert [list(b.item_ids) for b in batches] == [[10, 11, 12], [13, 14, 15]]          # the 7th interaction is never yielded
+    assert all(b.len() == 3 and not b.is_empty() for b in batches)
+    assert [list(b.timestamps) for b in batches] == [[7, 6, 5], [4, 3, 2]]
+    assert list(t.iter_minibatch(8)) == []
+    parts = t.iter_minibatch_partitioned(2, 2)                                           # chunk_size = 7 // 2 = 3
+    assert [[list(b.item_ids) for b in p] for p in parts] == [[[10, 11]], [[13, 14]]]
+    assert [list(b.user_ids) for b in t.iter_minibatch(7).slice(2, 6)] == []             # 7 > 4: no whole minibatch
+    assert [list(b.user_ids) for b in t.iter_minibatch(2).slice(1, 6)] == [[1, 2], [1, 0]]
+    empty = Interactions(3, 3).to_triplet()
+    assert empty.is_empty() and list(empty.iter_minibatch(1)) == []
+
+
 def test_compressed_sort_is_stable_on_timestamp_ties():
     inter = Interactions.from_arrays([1, 0, 1, 1, 0], [10, 11, 12, 13, 14], [5, 7, 5, 1, 7])
     comp = inter.to_compressed()

@@ -864,6 +864,12 @@ def main():
                                           "batch_sequences_per_gpu": MAX_BATCH, "score_kernel_roofline": top[0].get("score_kernel"),
                                           "note": "two optimiser steps per epoch of this workload: the hardware's throughput regime; at equal epochs the "
                                                   "LSTM's test MRR is a quarter lower there (DESIGN.md section 3), so it is not the headline"}
+                if top[0].get("score_kernel") and isinstance(out.get("roofline"), dict) and args.batch_sequences != MAX_BATCH:
+                    # the same kernel where its launch is long enough to be bytes-bound: at the headline's ~256 K rows a launch is
+                    # ~20 us of fixed cost (dispatch, ramp, drain) + rows at 0.62 of the peak (profiles/r04_tail_experiments.md)
+                    out["roofline"]["at_max_batch"] = {k: top[0]["score_kernel"][k] for k in ("achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                                                                                "algorithmic_bytes_per_launch") if k in top[0]["score_kernel"]}
+                    out["roofline"]["at_max_batch"]["batch_sequences_per_gpu"] = MAX_BATCH
         if small is not None:
             out["small_steps"] = small
         if crc_ranks:

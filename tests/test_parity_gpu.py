@@ -939,7 +939,8 @@ def test_full_size_properties():
 
 @pytest.mark.parametrize("kind,d,T", [(ModelKind.LSTM_NORMAL, 128, 300), (ModelKind.EWMA, 32, 300), (ModelKind.LSTM_COUPLED, 256, 300),
                                       (ModelKind.LSTM_NORMAL, 128, 256), (ModelKind.LSTM_COUPLED, 64, 200), (ModelKind.LSTM_NORMAL, 32, 257),
-                                      (ModelKind.LSTM_NORMAL, 16, 1024), (ModelKind.LSTM_COUPLED, 16, 1030)])
+                                      (ModelKind.LSTM_NORMAL, 16, 1024), (ModelKind.LSTM_COUPLED, 16, 1030),
+                                      (ModelKind.LSTM_NORMAL, 64, 1100), (ModelKind.LSTM_COUPLED, 128, 1040)])  # d > 32 beyond 1 024: the tile path's per-step kernels
 def test_long_sequences(kind, d, T):
     """max_sequence_length up to 1030 with users of up to 700 (T <= 300) or 2 500 interactions: several chunks per
     user (short chunk first, data.rs:406-431), minibatches whose tiles differ in length by two orders of magnitude.

@@ -293,6 +293,12 @@ sbr_status sbr_device_info(char* device_name, uint64_t name_bytes, uint32_t* out
 const char* sbr_status_string(sbr_status s);
 uint32_t sbr_abi_version(void);
 
+/* Scratch of a fit call (device and pinned-host blocks up to 64 MiB, at most 768 MiB of each kind per process) is kept for the
+ * next call instead of going back to the driver: the reference's own bench re-fits one model in a loop
+ * (benches/benchmark.rs:40-42) and ~50 allocations per call cost more than its kernels.  This returns everything that is idle
+ * to the driver (a long-lived host process that is done fitting). */
+void sbr_release_cached_memory(void);
+
 /* Kernel timing hook for bench.py: wall time (ms, HIP events on the engine stream) and launch
  * count accumulated per kernel family since the last reset.  Families: see sbr_kernel_family. */
 typedef enum sbr_kernel_family {

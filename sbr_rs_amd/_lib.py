@@ -108,6 +108,8 @@ def load():
     L.sbr_status_string.restype = C.c_char_p
     L.sbr_abi_version.argtypes = []
     L.sbr_abi_version.restype = C.c_uint32
+    L.sbr_release_cached_memory.argtypes = []
+    L.sbr_release_cached_memory.restype = None
     if L.sbr_abi_version() != ABI_VERSION:
         raise EngineUnavailable("libsbr_hip.so ABI version mismatch; rebuild with `python -m sbr_rs_amd.build`")
     _lib = L
@@ -126,5 +128,5 @@ DECLARED_SYMBOLS = [
     "sbr_fit_step_scatter_shared", "sbr_fit_step_owner_reduce_peers", "sbr_fit_step_apply_table_peers",
     "sbr_partition_part_info", "sbr_partition_export_part", "sbr_partition_import_part", "sbr_partition_finalize",
     "sbr_fit_lists_export", "sbr_fit_lists_import", "sbr_fit_step_reduce_own", "sbr_fit_step_owner_apply", "sbr_selftest_math",
-    "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort",
+    "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort", "sbr_release_cached_memory",
 ]

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/sbr_hip.h"
@@ -42,13 +44,105 @@ namespace {
         if (_s != SBR_OK) return _s;     \
     } while (0)
 
+/* Scratch of a fit call recycled across calls.  The reference's own bench re-fits one model in a loop (benches/benchmark.rs:40-42:
+ * 10 000 interactions, three epochs per call): ~40 hipMalloc + 10 hipHostMalloc at sbr_fit_begin and as many frees at the end
+ * cost 4-18 ms per call there — more than the call's kernels.  Blocks up to 64 MiB go back to this process-wide cache (768 MiB at
+ * most, per kind) instead of the driver and are handed out again to requests of at most twice... the same size class; anything
+ * larger takes the driver's path as before.  A block is cached only after the streams that used it were synchronised
+ * (sbr_fit_plan_destroy, sbr_model_destroy), and nothing relies on fresh memory being zero.  sbr_release_cached_memory() empties it. */
+struct ScratchCache {
+    static constexpr size_t kMaxBlock = 64ull << 20, kMaxTotal = 768ull << 20;
+    struct Blk { void* p; size_t bytes; int device; bool host; };
+    std::mutex mu;
+    std::vector<Blk> idle;
+    std::unordered_map<void*, Blk> live;
+    size_t cached[2] = {0, 0}; /* device, pinned host */
+    static bool enabled() {
+        static const bool on = !std::getenv("SBR_NO_SCRATCH_CACHE"); /* A/B switch */
+        return on;
+    }
+    hipError_t get(void** out, size_t bytes, bool host) {
+        *out = nullptr;
+        bytes = (bytes + 255) & ~(size_t)255;
+        int device = 0;
+        if (!host) (void)hipGetDevice(&device);
+        if (enabled() && bytes <= kMaxBlock) {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i) {
+                const Blk& b = idle[i];
+                if (b.host != host || (!host && b.device != device) || b.bytes < bytes || b.bytes > 2 * bytes + 4096) continue;
+                if (best == idle.size() || b.bytes < idle[best].bytes) best = i;
+            }
+            if (best != idle.size()) {
+                const Blk b = idle[best];
+                idle[best] = idle.back();
+                idle.pop_back();
+                cached[host] -= b.bytes;
+                live[b.p] = b;
+                *out = b.p;
+                return hipSuccess;
+            }
+        }
+        const hipError_t e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            if (e == hipErrorOutOfMemory && cached[0] + cached[1]) { /* give the cache back and try once more */
+                trim();
+                return host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+            }
+            return e;
+        }
+        if (enabled() && bytes <= kMaxBlock) {
+            std::lock_guard<std::mutex> g(mu);
+            live[*out] = Blk{*out, bytes, device, host};
+        }
+        return hipSuccess;
+    }
+    void put(void* p, bool host) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = live.find(p);
+            if (it != live.end()) {
+                const Blk b = it->second;
+                live.erase(it);
+                if (b.host == host && cached[host] + b.bytes <= kMaxTotal) {
+                    idle.push_back(b);
+                    cached[host] += b.bytes;
+                    return;
+                }
+            }
+        }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+    void trim() {
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            drop.swap(idle);
+            cached[0] = cached[1] = 0;
+        }
+        for (const Blk& b : drop) {
+            if (b.host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
+        }
+    }
+};
+ScratchCache& scratch_cache() {
+    static ScratchCache* c = new ScratchCache; /* never destroyed: the HIP runtime may be gone before static destructors run */
+    return *c;
+}
+
 template <typename T>
 sbr_status dmalloc(T** p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    HIPCHK(scratch_cache().get(reinterpret_cast<void**>(p), count * sizeof(T), false));
     return SBR_OK;
 }
+inline void dfree(void* p) { scratch_cache().put(p, false); }
+template <typename T>
+hipError_t hmalloc(T** p, size_t bytes) { return scratch_cache().get(reinterpret_cast<void**>(p), bytes, true); }
+inline void hfree(void* p) { scratch_cache().put(p, true); }
 
 int dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
@@ -325,6 +419,8 @@ struct sbr_model {
     bool own_stream = false;
     hipStream_t side = nullptr;          /* second stream: dense-gradient GEMM runs beside the sparse update */
     hipStream_t sorter = nullptr;        /* third stream: key sort of the sparse update, underneath the backward pass */
+    hipStream_t copier = nullptr;        /* uploads of the packed epochs; created at the first fit, kept (creating and destroying a
+                                          * stream costs 1.5 + 1.3 ms — as much as a whole small fit call's kernels) */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_scored = nullptr, ev_sorted = nullptr;
     std::mutex mu;
     bool timing = false;
@@ -440,7 +536,7 @@ struct DevicePacked { /* device image of one or more Packed, concatenated */
     int* prev_row = nullptr;
     uint32_t *in_idx = nullptr, *out_idx = nullptr, *ctr = nullptr;
     void release() {
-        hipFree(off); hipFree(steps); hipFree(prev_row); hipFree(in_idx); hipFree(out_idx); hipFree(ctr);
+        dfree(off); dfree(steps); dfree(prev_row); dfree(in_idx); dfree(out_idx); dfree(ctr);
         off = steps = prev_row = nullptr;
         in_idx = out_idx = ctr = nullptr;
     }
@@ -449,8 +545,8 @@ struct DevicePacked { /* device image of one or more Packed, concatenated */
 struct WorkBuffers {
     sbr::WorkView v{};
     void release() {
-        hipFree(v.C); hipFree(v.G); hipFree(v.dH); hipFree(v.dZ); hipFree(v.X); hipFree(v.zeros); hipFree(v.dHrec); hipFree(v.dCrec); hipFree(v.dab);
-        hipFree(v.partials); hipFree(v.loss); hipFree(v.tries); hipFree(v.part_loss); hipFree(v.part_tries);
+        dfree(v.C); dfree(v.G); dfree(v.dH); dfree(v.dZ); dfree(v.X); dfree(v.zeros); dfree(v.dHrec); dfree(v.dCrec); dfree(v.dab);
+        dfree(v.partials); dfree(v.loss); dfree(v.tries); dfree(v.part_loss); dfree(v.part_tries);
         v = sbr::WorkView{};
     }
 };
@@ -608,7 +704,9 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 8; }
+uint32_t sbr_abi_version(void) { return 9; }
+
+void sbr_release_cached_memory(void) { scratch_cache().trim(); }
 
 const char* sbr_status_string(sbr_status s) {
     switch (s) {
@@ -783,17 +881,20 @@ sbr_status sbr_model_create(const sbr_hparams* hp, sbr_model** out) {
 void sbr_model_destroy(sbr_model* m) {
     if (!m) return;
     hipSetDevice(m->device);
-    if (m->stream) hipStreamSynchronize(m->stream);
+    hipStreamSynchronize(m->stream); /* every stream that may still touch the arrays: they go back to the scratch cache, not the driver */
+    if (m->side) hipStreamSynchronize(m->side);
+    if (m->sorter) hipStreamSynchronize(m->sorter);
     sbr::ModelView& v = m->mv;
-    if (!m->shared) { hipFree(v.E); hipFree(v.Eacc); hipFree(v.b); hipFree(v.bacc); hipFree(v.Em); hipFree(v.bm); }
-    hipFree(v.W); hipFree(v.Wacc); hipFree(v.bW); hipFree(v.bWacc); hipFree(v.Wp); hipFree(v.WTp);
-    hipFree(v.alpha); hipFree(v.alpha_acc);
-    hipFree(v.Wm); hipFree(v.bWm); hipFree(v.alpha_m);
+    if (!m->shared) { dfree(v.E); dfree(v.Eacc); dfree(v.b); dfree(v.bacc); dfree(v.Em); dfree(v.bm); }
+    dfree(v.W); dfree(v.Wacc); dfree(v.bW); dfree(v.bWacc); dfree(v.Wp); dfree(v.WTp);
+    dfree(v.alpha); dfree(v.alpha_acc);
+    dfree(v.Wm); dfree(v.bWm); dfree(v.alpha_m);
     for (auto& tp : m->pending) { hipEventDestroy(tp.a); hipEventDestroy(tp.b); }
     m->eval_arena.release();
     if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
     if (m->side) { hipStreamSynchronize(m->side); hipStreamDestroy(m->side); }
     if (m->sorter) { hipStreamSynchronize(m->sorter); hipStreamDestroy(m->sorter); }
+    if (m->copier) { hipStreamSynchronize(m->copier); hipStreamDestroy(m->copier); }
     if (m->ev_fork) hipEventDestroy(m->ev_fork);
     if (m->ev_join) hipEventDestroy(m->ev_join);
     if (m->ev_scored) hipEventDestroy(m->ev_scored);
@@ -1028,6 +1129,14 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
                          sbr_fit_plan** out) {
     if (!m || !user_ptr || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
+    static const bool prof = std::getenv("SBR_PROF_FIT") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fit_begin] %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     SBRCHK(ensure_device(m));
     const uint64_t T = m->hp.max_sequence_length;
     for (uint64_t u = 0; u < num_users; ++u)
@@ -1070,11 +1179,14 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         sbr_xs_seed(&p->part_rng[q], seed);
         p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
     }
+    tick("host lists");
     p->items.assign(item_ids, item_ids + nnz);
     p->bmax = m->hp.batch_sequences;
     p->rmax = p->bmax * (T - 1);
     if (3 * p->rmax >= (1ull << 32) || part * T >= (1ull << 32)) { delete p; return SBR_ERR_INVALID_ARGUMENT; }
+    tick("plan host");
     sbr_status st = alloc_work(m, p->rmax, p->bmax, true, &p->wb);
+    tick("alloc_work");
     if (st == SBR_OK) { p->block_bytes = block_bytes_for(m, p->rmax); st = dmalloc(&p->block, p->block_bytes); }
     const uint64_t max_entries = 3 * p->rmax; /* only a device's own entries are ever sorted */
     int item_bits = 1;
@@ -1110,7 +1222,10 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         if (st == SBR_OK) st = dmalloc(&p->seg.head_pos, max_entries + 1);
         if (st == SBR_OK) st = dmalloc(&p->seg.nheads, 1);
     }
-    if (st == SBR_OK && hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
+    tick("allocs");
+    if (st == SBR_OK && !m->copier && hipStreamCreateWithFlags(&m->copier, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
+    p->copy_stream = m->copier;
+    tick("copy stream");
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + T);
@@ -1124,24 +1239,36 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     hipMemsetAsync(p->loss_acc, 0, 17 * sizeof(double), m->stream);
     hipMemsetAsync(p->ex_acc, 0, 18 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
+    tick("events+memsets");
     *out = p;
     return SBR_OK;
 }
 
 void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     if (!p) return;
+    static const bool prof = std::getenv("SBR_PROF_FIT") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!prof) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[plan_destroy] %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     hipSetDevice(p->m->device);
     if (p->pending) { p->worker.join(); p->pending = false; }
     hipStreamSynchronize(p->m->side);
     hipStreamSynchronize(p->m->sorter);
     hipStreamSynchronize(p->m->stream);
+    tick("join+sync");
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
         if (p->ep[i].free_event) hipEventDestroy(p->ep[i].free_event);
-        hipHostFree(p->ep[i].h_in); hipHostFree(p->ep[i].h_out); hipHostFree(p->ep[i].h_ctr);
-        hipHostFree(p->ep[i].h_prev); hipHostFree(p->ep[i].h_steps);
+        hfree(p->ep[i].h_in); hfree(p->ep[i].h_out); hfree(p->ep[i].h_ctr);
+        hfree(p->ep[i].h_prev); hfree(p->ep[i].h_steps);
     }
-    if (p->copy_stream) hipStreamDestroy(p->copy_stream);
+    tick("epoch buffers");
+    if (p->copy_stream) hipStreamSynchronize(p->copy_stream); /* the model's: stays */
+    tick("copy stream");
     p->wb.release();
     for (auto& px : p->xchg_peer) for (auto& b : px) b.release();
     for (auto& b : p->xchg_own) b.release();
@@ -1150,17 +1277,19 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
         for (auto& b : p->own_x) b.release();
         p->keys_sorted = nullptr; p->glist = p->gblist = nullptr; p->gfl = nullptr;
     }
-    hipFree(p->block); hipFree(p->keys); hipFree(p->keys_sorted); hipFree(p->sort_temp);
-    hipFree(p->loss_acc); hipFree(p->ex_acc);
-    hipFree(p->lag_state); hipFree(p->lag_seqsum);
+    dfree(p->block); dfree(p->keys); dfree(p->keys_sorted); dfree(p->sort_temp);
+    dfree(p->loss_acc); dfree(p->ex_acc);
+    dfree(p->lag_state); dfree(p->lag_seqsum);
     if (p->ev_seqsum) hipEventDestroy(p->ev_seqsum);
     if (p->ev_lagged) hipEventDestroy(p->ev_lagged);
-    hipFree(p->seg.counters); hipFree(p->seg.long_start); hipFree(p->seg.long_end); hipFree(p->seg.unit_base);
-    hipFree(p->seg.P); hipFree(p->seg.Pb); hipFree(p->seg.Pf);
-    hipFree(p->seg.head_pos); hipFree(p->seg.nheads);
-    hipFree(p->glist); hipFree(p->gblist); hipFree(p->gfl); hipFree(p->bounds_dev);
-    hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
+    dfree(p->seg.counters); dfree(p->seg.long_start); dfree(p->seg.long_end); dfree(p->seg.unit_base);
+    dfree(p->seg.P); dfree(p->seg.Pb); dfree(p->seg.Pf);
+    dfree(p->seg.head_pos); dfree(p->seg.nheads);
+    dfree(p->glist); dfree(p->gblist); dfree(p->gfl); dfree(p->bounds_dev);
+    dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp);
+    tick("frees");
     delete p;
+    tick("delete");
 }
 
 /* Host side of one epoch: ≙ thread_rng.shuffle(partition) (sequence_model.rs:109) for every
@@ -1194,15 +1323,12 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
     uint64_t total_rows = 0;
     for (uint64_t i = 0; i < p->part_len; ++i) total_rows += ln[i] - 1;
     if (total_rows > e.h_rows_cap || p->part_len > e.h_seq_cap) {
-        hipHostFree(e.h_in); hipHostFree(e.h_out); hipHostFree(e.h_ctr); hipHostFree(e.h_prev); hipHostFree(e.h_steps);
+        hfree(e.h_in); hfree(e.h_out); hfree(e.h_ctr); hfree(e.h_prev); hfree(e.h_steps);
         e.h_in = e.h_out = e.h_ctr = nullptr; e.h_prev = e.h_steps = nullptr;
         e.h_rows_cap = e.h_seq_cap = 0;
         const size_t rb = (size_t)(total_rows ? total_rows : 1) * 4, sb = (size_t)(p->part_len ? p->part_len : 1) * 4;
-        if (hipHostMalloc(reinterpret_cast<void**>(&e.h_in), rb, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&e.h_out), rb, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&e.h_ctr), rb, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&e.h_prev), rb, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&e.h_steps), sb, hipHostMallocDefault) != hipSuccess)
+        if (hmalloc(&e.h_in, rb) != hipSuccess || hmalloc(&e.h_out, rb) != hipSuccess || hmalloc(&e.h_ctr, rb) != hipSuccess ||
+            hmalloc(&e.h_prev, rb) != hipSuccess || hmalloc(&e.h_steps, sb) != hipSuccess)
             return SBR_ERR_OUT_OF_MEMORY;
         e.h_rows_cap = total_rows; e.h_seq_cap = p->part_len;
     }
@@ -1693,7 +1819,7 @@ static sbr_status merge_capacity(sbr_fit_plan* p, uint64_t total) {
     if (total <= p->mcap) return SBR_OK;
     sbr_model* m = p->m;
     HIPCHK(hipStreamSynchronize(m->stream));
-    hipFree(p->mkeys); hipFree(p->mkeys_sorted); hipFree(p->msort_temp);
+    dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp);
     p->mkeys = p->mkeys_sorted = nullptr; p->msort_temp = nullptr; p->mcap = 0;
     const uint64_t cap = total + total / 4 + 1024;
     SBRCHK(dmalloc(&p->mkeys, cap));
@@ -2011,7 +2137,7 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
         for (uint32_t r = 0; r < n; ++r) {
             Dev& v = dev[r];
             hipSetDevice(models[r]->device);
-            hipFree(v.send); hipFree(v.dense); hipFree(v.recv); hipFree(v.own); hipFree(v.table); hipFree(v.dense_all);
+            dfree(v.send); dfree(v.dense); dfree(v.recv); dfree(v.own); dfree(v.table); dfree(v.dense_all);
             if (v.scattered) hipEventDestroy(v.scattered);
             if (v.reduced) hipEventDestroy(v.reduced);
             if (v.applied) hipEventDestroy(v.applied);
@@ -2453,7 +2579,7 @@ sbr_status sbr_predict(sbr_model* m, const float* user_dim, const uint32_t* item
         if (hipStreamSynchronize(m->stream) != hipSuccess || hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
             st = SBR_ERR_HIP;
     }
-    hipFree(d_user); hipFree(d_items); hipFree(d_out);
+    dfree(d_user); dfree(d_items); dfree(d_out);
     if (st != SBR_OK) return st;
     for (uint64_t i = 0; i < n; ++i)
         if (!std::isfinite(out[i])) return SBR_ERR_INVALID_PREDICTION; /* sequence_model.rs:225-229 */
@@ -2590,7 +2716,7 @@ sbr_status sbr_selftest_math(const float* x, uint64_t n, float* out_cell_h, floa
     HIPCHK(hipMemcpy(out_cell_h, de, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_sig, ds, n * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_tanh, dt, n * 4, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(de); hipFree(ds); hipFree(dt);
+    dfree(dx); dfree(de); dfree(ds); dfree(dt);
     return SBR_OK;
 }
 
@@ -2605,7 +2731,7 @@ sbr_status sbr_selftest_dot_tree(const float* x, const float* y, uint32_t d, uin
     sbr::launch_selftest_dot_tree(dx, dy, (int)d, nrows, dout, nullptr);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout, nrows * 4, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dy); hipFree(dout);
+    dfree(dx); dfree(dy); dfree(dout);
     return SBR_OK;
 }
 
@@ -2629,7 +2755,7 @@ sbr_status sbr_selftest_mfma(const float* a, const float* b, const float* c0, ui
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, dout, 256 * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out32, dout32, 1024 * 4, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dc); hipFree(dout); hipFree(da32); hipFree(db32); hipFree(dout32);
+    dfree(da); dfree(db); dfree(dc); dfree(dout); dfree(da32); dfree(db32); dfree(dout32);
     return SBR_OK;
 }
 
@@ -2653,7 +2779,7 @@ sbr_status sbr_selftest_sort(const uint32_t* rows, uint64_t n, uint32_t row_bits
     HIPCHK(hipMemcpy(out_keys, dout, n * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_nheads, dn, 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(out_head_pos, dheads, ((uint64_t)*out_nheads + 1) * 4, hipMemcpyDeviceToHost));
-    hipFree(drows); hipFree(dheads); hipFree(dn); hipFree(dtmp); hipFree(dout); hipFree(temp);
+    dfree(drows); dfree(dheads); dfree(dn); dfree(dtmp); dfree(dout); dfree(temp);
     return SBR_OK;
 }
 

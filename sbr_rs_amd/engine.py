@@ -348,3 +348,8 @@ class Model:
             self.close()
         except Exception:
             pass
+
+
+def release_cached_memory() -> None:
+    """Hand the engine's idle fit scratch (device and pinned-host blocks kept between fit calls) back to the driver."""
+    _lib.load().sbr_release_cached_memory()

@@ -64,6 +64,10 @@ struct EngineError : std::runtime_error {
         : std::runtime_error(where + ": " + sbr_status_string(st)), status(st) {}
 };
 
+/// The engine keeps the scratch of a fit call (device and pinned-host blocks up to 64 MiB) for the next call — the reference's
+/// own bench re-fits one model in a loop (benches/benchmark.rs:40-42).  A long-lived process that is done fitting gives it back.
+inline void release_cached_memory() { sbr_release_cached_memory(); }
+
 /// Minimal Result: holds either a value or an error enum.
 template <class T, class E>
 class Result {

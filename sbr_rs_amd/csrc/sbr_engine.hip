@@ -1518,6 +1518,11 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * Their consumers (update / scatter / dense / fit_end) all join the ordering's stream first.  SBR_HEADER_ON_MAIN=1: the old place. */
     static const bool header_on_main = std::getenv("SBR_HEADER_ON_MAIN") != nullptr;
     const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM && !header_on_main;
+    /* ONE subsequence per step at d <= 32 (the reference's own schedule): header, lagged loss figure and the ordering of the step's
+     * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
+    static const char* ewma_env0 = std::getenv("SBR_EWMA_FUSED");
+    const bool ewma_seq_pass = !m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0 && (ewma_env0 ? std::atoi(ewma_env0) : SBR_EWMA_FUSED_DEFAULT) != 0;
+    const bool small_tail = !overlap && p->ndev == 1 && !ewma_seq_pass && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
@@ -1542,7 +1547,14 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         }
         return SBR_OK;
     };
-    if (early_sort) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
+    if (early_sort && !small_tail) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
+    if (small_tail) {
+        if (p->lag_busy) { /* an earlier step's chain on the ordering's stream still owns lag_state */
+            HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
+            p->lag_busy = false;
+        }
+        p->sort_off_stream = false;
+    }
     /* EWMA + single-negative loss (BASELINE configs[4]): scan and score in one pass per sequence, optionally the backward scan too
      * (SBR_EWMA_FUSED = 0: three launches / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
     static const char* ewma_env = std::getenv("SBR_EWMA_FUSED");
@@ -1557,7 +1569,10 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         }
         {
             ScopedTimer t(m, SBR_K_SCORE, 1);
-            sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream);
+            p->header_accumulated = p->ndev == 1;
+            const sbr::SmallTail tail{bv.header, p->header_accumulated ? p->loss_acc : nullptr, p->header_accumulated ? p->ex_acc : nullptr,
+                                      p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
+            sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream, small_tail ? &tail : nullptr);
         }
     }
     /* the figure the reference's fit returns (sbr_report.hip): a small step folds it into the header launch; otherwise the
@@ -1566,7 +1581,9 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* single device: the loss accumulators take the block's header in the header kernel itself (one launch fewer per step) */
     p->header_accumulated = p->ndev == 1;
     const bool fuse_lag = !overlap && mb.B <= SBR_HEADER_LAG_MAX_B;
-    if (side_header) {
+    if (small_tail) {
+        /* done by the score launch */
+    } else if (side_header) {
         HIPCHK(hipEventRecord(m->ev_scored, m->stream)); /* right behind the score kernel */
     } else {
         if (p->lag_busy) { /* the previous step's chain may still be running on the sorter stream: it owns lag_state / lag_seqsum */
@@ -1584,7 +1601,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * launches would otherwise sit in the host's queue ahead of it (50 us at a few hundred sequences per step, as long as
      * the pass itself); ev_scored, recorded here, is what the ordering waits for either way */
     const bool sort_first = place == SORT_PRE;
-    if (!early_sort && sort_first) SBRCHK(launch_sort(sorter));
+    if (!early_sort && sort_first && !small_tail) SBRCHK(launch_sort(sorter));
     if (!early_sort && place == SORT_OWN_STREAM && !side_header) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
     if (ewma_fused < 2) {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
@@ -1604,7 +1621,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
         p->dense_unreduced_chunks = sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side, /*defer_reduce=*/p->ndev == 1);
     }
-    if (!early_sort && place == SORT_POST) SBRCHK(launch_sort(m->stream));
+    if (!early_sort && place == SORT_POST && !small_tail) SBRCHK(launch_sort(m->stream));
     if (side != m->stream) HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = side != m->stream;
     if (!fuse_lag) {

@@ -114,8 +114,22 @@ bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView&
 bool launch_wave_dense_gradient(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int rows_host,
                                 hipStream_t s);
 /* gather + negative sampling + loss + dloss/dh; also copies in/out idx into the block */
+/* A step of ONE subsequence (the reference's own schedule, sequence_model.rs:111-169) at d <= 32: what follows the score pass —
+ * block header + loss accumulators, the lagged loss figure, the (row, entry) ordering of the step's 3 R keys and its segment
+ * heads — runs at the end of the score launch itself (one workgroup) instead of in three more launches of ~5 us each. */
+#define SBR_SMALL_TAIL_MAX_ROWS 255
+struct SmallTail {
+    uint32_t* header;
+    double* loss_acc;            /* may be null (several devices: the header travels) */
+    unsigned long long* ex_acc;
+    float* lag_state;            /* [accumulator | loss-node value per sequence length] */
+    uint64_t* keys_sorted;
+    uint32_t* head_pos;
+    uint32_t* nheads;
+};
+bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
-                  int rows_host, hipStream_t s);
+                  int rows_host, hipStream_t s, const SmallTail* tail = nullptr);
 /* EWMA with a single-negative loss (hinge / BPR): forward scan + scoring in ONE pass per sequence (replaces launch_recurrent_forward
  * + launch_score; same outputs bit for bit); whole = true: the backward scan of the sequence in the same pass as well (replaces
  * launch_recurrent_backward's scan; the dalpha reduction stays launch_dense_gradient's) */

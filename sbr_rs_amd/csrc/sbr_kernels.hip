@@ -147,16 +147,14 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // 256 K rows): a wave then walks ~18 passes of ~1.75 dependent memory round trips each and the kernel is THEIR LATENCY, not the
 // bytes — half the passes with twice the rows in flight.  Same arithmetic per row, same bits.
 template <int D, int U, bool PF>
-__global__ __launch_bounds__(256, PF ? 1 : 7) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w,
-                                                    uint64_t epoch_key) {
+__device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                                                uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     constexpr int RPW = GPW * U;  // rows per wave and pass
     const int lane = threadIdx.x & 63;
     const int lg = lane % L;
     const int grp = lane / L;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
     static_assert(SBR_WARP_MAX_TRIES <= 8, "one candidate per lane of an 8-lane group");
     const bool spread = L >= 8 && max_tries > 1;
@@ -271,8 +269,17 @@ __global__ __launch_bounds__(256, PF ? 1 : 7) void score_kernel(ModelView m, MbV
             }
         }
     }
+    *loss_out = loss_part;
+    *tries_out = tries_part;
+}
+
+// the workgroup's share of the reported loss / tries (order-free sums) -> part_loss / part_tries [block]; thread 0 returns the sums
+template <bool ALL>  // ALL: every thread gets the sums (the small tail follows); otherwise thread 0 only, as the store needs them
+__device__ __forceinline__ void score_partials(const WorkView& w, int block, double loss_part, unsigned int tries_part, double* lsum,
+                                               unsigned int* tsum) {
     __shared__ double s_loss[4];
     __shared__ unsigned int s_tries[4];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         loss_part += __shfl_xor(loss_part, off, 64);
@@ -283,10 +290,129 @@ __global__ __launch_bounds__(256, PF ? 1 : 7) void score_kernel(ModelView m, MbV
         s_tries[threadIdx.x >> 6] = tries_part;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
-        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
+    if (ALL || threadIdx.x == 0) {
+        *lsum = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        *tsum = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
     }
+    if (threadIdx.x == 0) {
+        w.part_loss[block] = *lsum;
+        w.part_tries[block] = *tsum;
+    }
+}
+
+// ---- the tail of a ONE-sequence step (SmallTail, sbr_kernels.h): one workgroup of 256 threads, after its score pass ----
+// header + accumulators (block_header_kernel), the lagged loss figure of the one sequence (lagged_chain with B = 1: the node of
+// its length is read, then takes the sequence's t-ascending loss sum), and the step's 3 R keys in (row, entry) order with the
+// list of segment heads.  The keys are distinct (the entry number is their low word), so ranking every key among all of them
+// IS the stable order by row that small_sort_kernel produces: integer work, identical output.
+__device__ __forceinline__ void small_tail(const MbView& mb, const BlockView& blk, const WorkView& w, const SmallTail& t, double lsum,
+                                           unsigned int tsum) {
+    constexpr int NT = 256, NMAX = 3 * SBR_SMALL_TAIL_MAX_ROWS;
+    __shared__ uint64_t ka[NMAX], kb[NMAX];
+    __shared__ uint32_t s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = mb.R;
+    const uint32_t n = 3u * (uint32_t)R;
+    /* the rows this workgroup's lanes have just written (ids, negatives, losses) are read by other lanes from here on */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (wave == 0) {
+        const int ns = mb.steps[0];
+        float sum = 0.0f;
+        for (int base = 0; base < ns; base += 64) {
+            const int tt = base + lane;
+            const float v = tt < ns ? w.loss[mb.off[tt]] : 0.0f;
+            const int cnt = ns - base < 64 ? ns - base : 64;
+            for (int l = 0; l < cnt; ++l) sum = sum + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+        }
+        if (lane == 0) {
+            t.header[0] = (uint32_t)R;
+            t.header[1] = tsum;
+            t.header[2] = t.header[3] = 0;
+            *reinterpret_cast<double*>(t.header + 4) = lsum;
+            *reinterpret_cast<unsigned long long*>(t.header + 6) = (unsigned long long)R;
+            if (t.loss_acc) {
+                t.loss_acc[0] += lsum;
+                t.loss_acc[1] += lsum;
+                t.ex_acc[0] += (unsigned long long)R;
+                t.ex_acc[1] += tsum;
+                t.ex_acc[2] += (unsigned long long)R;
+            }
+            float* node = t.lag_state + 1;
+            const float acc = t.lag_state[0];
+            const float x = node[ns - 1];
+            t.lag_state[0] = acc + x;
+            node[ns - 1] = sum;
+        }
+    }
+    for (uint32_t e = tid; e < n; e += NT) {
+        const uint32_t r = e / 3u, kind = e - 3u * r;
+        const uint32_t* a = kind == 0 ? blk.in_idx : (kind == 1 ? blk.out_idx : blk.neg);
+        ka[e] = ((uint64_t)a[r] << 32) | e;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < n; e += NT) {
+        const uint64_t k = ka[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += ka[j] < k ? 1u : 0u;
+        kb[rank] = k;
+    }
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t base_heads = 0;
+    for (uint32_t p0 = 0; p0 < n; p0 += NT) {  // workgroup-uniform trip count
+        const uint32_t p = p0 + tid;
+        const bool valid = p < n;
+        const bool head = valid && (p == 0 || (uint32_t)(kb[p] >> 32) != (uint32_t)(kb[p - 1] >> 32));
+        if (valid) t.keys_sorted[p] = kb[p];
+        const uint64_t mm = __ballot(head);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mm);
+        __syncthreads();
+        uint32_t off = base_heads, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            if (w2 < wave) off += s_cnt[w2];
+            total += s_cnt[w2];
+        }
+        if (head) t.head_pos[off + (uint32_t)__popcll(mm & lt)] = p;
+        base_heads += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *t.nheads = base_heads;
+        t.head_pos[base_heads] = n;
+    }
+}
+
+// (seven waves per SIMD = 72 registers is what the d = 128 rows need in flight; below that a row is 64-256 B, the two-row form
+// wants 73-80 registers, and a scratch reload inside the pass loop would wait for every gather outstanding: six waves there)
+template <int D, int U, bool PF>
+__global__ __launch_bounds__(256, PF ? 1 : (D >= 128 ? 7 : 6)) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+    double loss_part, lsum = 0.0;
+    unsigned int tries_part, tsum = 0;
+    score_warp_rows<D, U, PF>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
+                              &loss_part, &tries_part);
+    score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
+}
+template <int D, int U>
+__device__ __forceinline__ void score_single_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                                                  uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out);
+#define SBR_SCORE_SINGLE_U 4 /* rows per lane group and pass of score_single_kernel */
+template <int D>
+__device__ __forceinline__ void score_single_rows_fwd(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                                                      uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
+    score_single_rows<D, SBR_SCORE_SINGLE_U>(m, mb, blk, w, epoch_key, wave, nwaves, loss_out, tries_out);
+}
+// one workgroup: the score pass of a one-sequence step, then its SmallTail
+template <int D>
+__global__ __launch_bounds__(256) void score_tail_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+    double loss_part, lsum = 0.0;
+    unsigned int tries_part, tsum = 0;
+    if (m.loss == SBR_LOSS_WARP) score_warp_rows<D, 2, false>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), 4, &loss_part, &tries_part);
+    else score_single_rows_fwd<D>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), 4, &loss_part, &tries_part);
+    score_partials<true>(w, 0, loss_part, tries_part, &lsum, &tsum);
+    small_tail(mb, blk, w, tail, lsum, tsum);
 }
 
 // Single-negative losses (hinge, BPR: one candidate, no retry loop): U rows per lane group and pass, all their gathers
@@ -295,15 +421,14 @@ __global__ __launch_bounds__(256, PF ? 1 : 7) void score_kernel(ModelView m, MbV
 // parallelism: 1.25 -> 1.1 ms at d = 256 against a 10 M-row table.  (With WARP's retry rounds in lockstep the same
 // idea loses — more rounds per row than a two-row group needs — so WARP keeps score_kernel.)
 template <int D, int U>
-__global__ __launch_bounds__(256) void score_single_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+__device__ __forceinline__ void score_single_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
+                                                  uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     constexpr int RPW = GPW * U;  // rows per wave and pass
     const int lane = threadIdx.x & 63;
     const int lg = lane % L;
     const int grp = lane / L;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int R = mb.R, last = mb.R - 1;
     const float* E = launder(m.E);
     const float* bias = launder(m.b);
@@ -367,22 +492,16 @@ __global__ __launch_bounds__(256) void score_single_kernel(ModelView m, MbView m
             }
         }
     }
-    __shared__ double s_loss[4];
-    __shared__ unsigned int s_tries[4];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        loss_part += __shfl_xor(loss_part, off, 64);
-        tries_part += __shfl_xor(tries_part, off, 64);
-    }
-    if (lane == 0) {
-        s_loss[threadIdx.x >> 6] = loss_part;
-        s_tries[threadIdx.x >> 6] = tries_part;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
-        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
-    }
+    *loss_out = loss_part;
+    *tries_out = tries_part;
+}
+template <int D, int U>
+__global__ __launch_bounds__(256) void score_single_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+    double loss_part, lsum = 0.0;
+    unsigned int tries_part, tsum = 0;
+    score_single_rows<D, U>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
+                            &loss_part, &tries_part);
+    score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
 }
 
 // dloss/dh of packed row r, elements u..u+3:  g*E[neg] - g*E[pos]  (two rounded products, one
@@ -2942,7 +3061,6 @@ void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, co
     }
 }
 
-#define SBR_SCORE_SINGLE_U 4 /* rows per lane group and pass of score_single_kernel */
 /* WARP: rows per lane group in flight — two below this many packed rows per launch (latency-bound launches), one above
  * (bandwidth-bound; SBR_SCORE_U = 1 / 2 forces one form: the tests run both) */
 #ifndef SBR_SCORE_U2_MAX_ROWS
@@ -2958,10 +3076,21 @@ static int score_grid(int d, int rows, bool single_negative) {
     return grid_for_groups(rows, gpb);
 }
 
+bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host) {
+    static const bool off = std::getenv("SBR_NO_SMALL_TAIL") != nullptr; /* A/B switch */
+    return !off && sequences_host == 1 && rows_host > 0 && rows_host <= SBR_SMALL_TAIL_MAX_ROWS && (m.d == 16 || m.d == 32);
+}
+
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
-                  int rows_host, hipStream_t s) {
+                  int rows_host, hipStream_t s, const SmallTail* tail) {
     if (rows_host > 0) {
         DISPATCH_D(m.d, {
+            if constexpr (DD <= 32) {
+                if (tail) { /* one workgroup: its score pass, then the step's bookkeeping and key ordering (SmallTail) */
+                    hipLaunchKernelGGL((score_tail_kernel<DD>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail);
+                    return;
+                }
+            }
             if (m.loss == SBR_LOSS_WARP) {
                 if (score_warp_u(rows_host) == 2)
                     hipLaunchKernelGGL((score_kernel<DD, 2, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);

@@ -631,6 +631,8 @@ struct sbr_fit_plan {
     unsigned long long* ex_acc = nullptr;
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
+    bool fuse_back = false;     /* sbr_fit_step: the step's optimiser half may take the single-launch form (sbr::launch_small_back) */
+    bool dw_deferred = false;   /* ... and step_local left the dense gradient to it */
     int dense_unreduced_chunks = 0; /* > 0: blk.dense is still that many chunk partials in wb.v.partials (one device: reduced by its consumer) */
     bool sort_off_stream = false; /* the step's key ordering ran on another stream than the main one: ev_sorted joins it */
     bool sorted_event_live = false; /* ev_sorted has been recorded at least once: the multi-device consumers wait on it whatever the
@@ -1615,7 +1617,9 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
         HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
     }
-    {
+    p->dw_deferred = p->fuse_back && !overlap && p->ndev == 1 && sbr::small_back_shape_ok(m->mv, (int)mb.R);
+    if (p->dw_deferred) p->dense_unreduced_chunks = 0;
+    if (!p->dw_deferred) {
         /* one device: the ordered reduction of the chunk partials is left to the consumer — the optimiser step folds it into
          * the dense update's launch (sbr_fit_step_apply); the exchange halves and the debug fetch reduce on demand */
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
@@ -1648,6 +1652,15 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     begin_optimizer_step(m);
     if (!p->header_accumulated) sbr::launch_accumulate_loss(all, p->block_bytes, 1, p->loss_acc, p->ex_acc, m->stream);
     p->header_accumulated = false;
+    if (p->dw_deferred) { /* small LSTM step: dense gradient + dense update + sparse update in one launch */
+        p->dw_deferred = false;
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
+        sbr::launch_small_back(m->mv, mb_view(p, minibatch), block_view(m, p->block, p->rmax), p->wb.v, p->ep[p->cur].rows_of_dev[minibatch],
+                               p->keys_sorted, p->seg, m->stream);
+        HIPCHK(hipGetLastError());
+        return SBR_OK;
+    }
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
@@ -1671,7 +1684,10 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch) {
     if (!p) return SBR_ERR_INVALID_ARGUMENT;
     if (p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT; /* multi-device: the owner-reduce halves below, driven by the host */
-    SBRCHK(sbr_fit_step_local(p, minibatch));
+    p->fuse_back = true; /* nobody looks at the block between the two halves */
+    const sbr_status st = sbr_fit_step_local(p, minibatch);
+    p->fuse_back = false;
+    SBRCHK(st);
     return sbr_fit_step_apply(p, minibatch);
 }
 

@@ -128,6 +128,11 @@ struct SmallTail {
     uint32_t* nheads;
 };
 bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
+/* The optimiser half of a small single-device LSTM step at d <= 32 (one dense-gradient chunk, single-launch sparse update) in ONE
+ * launch: dense gradient (per-element row chains) + dense update + sparse update, instead of three. */
+bool small_back_shape_ok(const ModelView& m, int rows_host);
+void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
+                       const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s, const SmallTail* tail = nullptr);
 /* EWMA with a single-negative loss (hinge / BPR): forward scan + scoring in ONE pass per sequence (replaces launch_recurrent_forward

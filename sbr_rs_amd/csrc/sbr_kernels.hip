@@ -305,11 +305,12 @@ __device__ __forceinline__ void score_partials(const WorkView& w, int block, dou
 // its length is read, then takes the sequence's t-ascending loss sum), and the step's 3 R keys in (row, entry) order with the
 // list of segment heads.  The keys are distinct (the entry number is their low word), so ranking every key among all of them
 // IS the stable order by row that small_sort_kernel produces: integer work, identical output.
+template <int NT>
 __device__ __forceinline__ void small_tail(const MbView& mb, const BlockView& blk, const WorkView& w, const SmallTail& t, double lsum,
                                            unsigned int tsum) {
-    constexpr int NT = 256, NMAX = 3 * SBR_SMALL_TAIL_MAX_ROWS;
+    constexpr int NMAX = 3 * SBR_SMALL_TAIL_MAX_ROWS, NW = NT / 64;
     __shared__ uint64_t ka[NMAX], kb[NMAX];
-    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_cnt[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int R = mb.R;
     const uint32_t n = 3u * (uint32_t)R;
@@ -371,7 +372,7 @@ __device__ __forceinline__ void small_tail(const MbView& mb, const BlockView& bl
         __syncthreads();
         uint32_t off = base_heads, total = 0;
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
+        for (int w2 = 0; w2 < NW; ++w2) {
             if (w2 < wave) off += s_cnt[w2];
             total += s_cnt[w2];
         }
@@ -405,14 +406,36 @@ __device__ __forceinline__ void score_single_rows_fwd(const ModelView& m, const 
     score_single_rows<D, SBR_SCORE_SINGLE_U>(m, mb, blk, w, epoch_key, wave, nwaves, loss_out, tries_out);
 }
 // one workgroup: the score pass of a one-sequence step, then its SmallTail
-template <int D>
-__global__ __launch_bounds__(256) void score_tail_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
-    double loss_part, lsum = 0.0;
-    unsigned int tries_part, tsum = 0;
-    if (m.loss == SBR_LOSS_WARP) score_warp_rows<D, 2, false>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), 4, &loss_part, &tries_part);
-    else score_single_rows_fwd<D>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), 4, &loss_part, &tries_part);
-    score_partials<true>(w, 0, loss_part, tries_part, &lsum, &tsum);
-    small_tail(mb, blk, w, tail, lsum, tsum);
+// (NT = 256 up to 64 rows; sixteen waves beyond: up to 128 rows are then ONE pass of the score loop and the ranking of the keys
+// takes a quarter of the time — but a 1 024-thread workgroup costs ~3 us more to start and drain, which a ten-row step notices)
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+    constexpr int NW = NT / 64;
+    double loss_part;
+    unsigned int tries_part;
+    if (m.loss == SBR_LOSS_WARP) score_warp_rows<D, 1, false>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), NW, &loss_part, &tries_part);
+    else score_single_rows_fwd<D>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), NW, &loss_part, &tries_part);
+    __shared__ double s_loss[NW];
+    __shared__ unsigned int s_tries[NW];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        loss_part += __shfl_xor(loss_part, off, 64);
+        tries_part += __shfl_xor(tries_part, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_loss[threadIdx.x >> 6] = loss_part;
+        s_tries[threadIdx.x >> 6] = tries_part;
+    }
+    __syncthreads();
+    double lsum = s_loss[0];
+    unsigned int tsum = s_tries[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) { lsum += s_loss[i]; tsum += s_tries[i]; }
+    if (threadIdx.x == 0) {
+        w.part_loss[0] = lsum;
+        w.part_tries[0] = tsum;
+    }
+    small_tail<NT>(mb, blk, w, tail, lsum, tsum);
 }
 
 // Single-negative losses (hinge, BPR: one candidate, no retry loop): U rows per lane group and pass, all their gathers
@@ -2097,6 +2120,7 @@ __device__ __forceinline__ size_t wtp_index(int k, int jcol, int D, int NG) {
     return ((((size_t)ct * (NGD / 16) + S) * 64 + lane) * 4 + sub);
 }
 
+__device__ __forceinline__ void dense_apply_element(const ModelView& m, size_t i, float g);
 // partials != nullptr (one device): the gradient is still `nchunks` chunk partials — their ordered sum (dense_reduce_local_kernel's
 // chain) is formed here, written to dense_out, and applied: one launch instead of two on the tail of the step
 __global__ void dense_apply_kernel(ModelView m, const uint8_t* all_blocks, uint64_t block_bytes, uint64_t dense_off,
@@ -2120,6 +2144,10 @@ __global__ void dense_apply_kernel(ModelView m, const uint8_t* all_blocks, uint6
         g = reinterpret_cast<const float*>(all_blocks + dense_off)[i];
         for (int q = 1; q < ndev; ++q) g = g + reinterpret_cast<const float*>(all_blocks + (size_t)q * block_bytes + dense_off)[i];
     }
+    dense_apply_element(m, i, g);
+}
+// optimiser update of element i of the dense parameters (LSTM: [W | bW], re-emitting the packed weight copies; EWMA: alpha)
+__device__ __forceinline__ void dense_apply_element(const ModelView& m, size_t i, float g) {
     if (m.ng) {
         const int NGD = m.ng * m.d;
         const size_t nw = (size_t)2 * m.d * NGD;
@@ -2380,13 +2408,12 @@ __device__ __forceinline__ uint64_t seg_end(const uint64_t* keys, uint64_t lo, u
 // INLINE_LONG (small key counts: launch_seg_reduce): a segment of more than SBR_SEG_CHUNK entries is reduced right here by
 // its lane group, chunk partial by chunk partial in the contract's order, instead of being registered for the three
 // kernels of the chunked path — four launches fewer per step where a step is a handful of microseconds.
-template <int D, class Emit, bool INLINE_LONG = false>
-__global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
+template <int D, class Emit, bool INLINE_LONG>
+__device__ __forceinline__ void seg_short_rows(const BlockView& blk, const uint64_t* keys, uint64_t n, const SegScratch& sc, const Emit& emit,
+                                               uint32_t wave, uint32_t nwaves) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const uint32_t wave = (uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6);
-    const uint32_t nwaves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
     const int gbase = grp * L;
     const uint32_t nheads = *sc.nheads;
     const uint32_t stride = nwaves * GPW;
@@ -2494,6 +2521,64 @@ __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uin
         }
         emit.template row<D>(row, p, lg, g, has_b, gb, pre);
     }
+}
+template <int D, class Emit, bool INLINE_LONG = false>
+__global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
+    seg_short_rows<D, Emit, INLINE_LONG>(blk, keys, n, sc, emit, (uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6),
+                                         (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6));
+}
+
+// ---- the optimiser half of a SMALL single-device LSTM step at d <= 32 in ONE launch (launch_small_back) ----
+// Workgroups 0 .. dw_blocks-1: one thread per element of the dense gradient — its chain over the step's packed rows in row
+// order (what a v_mfma_f32_32x32x2 accumulator of lstm_dw_block_kernel holds: fma per row from +0; the bias row is the add
+// chain over dz) and, the gradient being elementwise, the element's optimiser update right behind it: dense-gradient launch
+// and dense-update launch become none.  The remaining workgroups: the sparse update's segments (seg_short_rows), which do
+// not depend on the dense half.  A single chunk only (<= SBR_DW_CHUNK_ROWS rows), so the chain IS the gradient.
+template <int D>
+__global__ __launch_bounds__(256) void small_back_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, const uint64_t* keys, uint64_t nkeys,
+                                                         SegScratch sc, int dw_blocks) {
+    if ((int)blockIdx.x >= dw_blocks) {
+        seg_short_rows<D, EmitApply, true>(blk, keys, nkeys, sc, EmitApply{m}, (uint32_t)((((uint64_t)blockIdx.x - dw_blocks) * 256 + threadIdx.x) >> 6),
+                                           (uint32_t)((((uint64_t)gridDim.x - dw_blocks) * 256) >> 6));
+        return;
+    }
+    const int NGD = m.ng * D, K2 = 2 * D, R = mb.R;
+    const size_t n = (size_t)(K2 + 1) * NGD;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = (int)(i / NGD), j = (int)(i % NGD);
+    const float* dz = w.dZ + j;
+    float acc = 0.0f;
+    if (k < K2) {
+        for (int r0 = 0; r0 < R; r0 += 8) {  // eight rows' operands in flight; the chain itself is one dependent fma per row
+            float a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q < R ? r0 + q : R - 1;
+                b[q] = dz[(size_t)r * NGD];
+                if (k < D) {
+                    a[q] = w.X[(size_t)r * D + k];
+                } else {
+                    const int pr = mb.prev_row[r];
+                    a[q] = pr >= 0 ? blk.H[(size_t)pr * D + (k - D)] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < R) acc = sbr_fma(a[q], b[q], acc);
+        }
+    } else {
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            float b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = dz[(size_t)(r0 + q < R ? r0 + q : R - 1) * NGD];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < R) acc = acc + b[q];
+        }
+    }
+    blk.dense[i] = acc;
+    dense_apply_element(m, i, acc);
 }
 
 // prefix of the long segments' chunk counts (a few thousand entries at most: one workgroup)
@@ -3087,7 +3172,8 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
         DISPATCH_D(m.d, {
             if constexpr (DD <= 32) {
                 if (tail) { /* one workgroup: its score pass, then the step's bookkeeping and key ordering (SmallTail) */
-                    hipLaunchKernelGGL((score_tail_kernel<DD>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail);
+                    if (rows_host <= 64) hipLaunchKernelGGL((score_tail_kernel<DD, 256>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail);
+                    else hipLaunchKernelGGL((score_tail_kernel<DD, 1024>), dim3(1), dim3(1024), 0, s, m, mb, blk, w, epoch_key, *tail);
                     return;
                 }
             }
@@ -3318,6 +3404,30 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
         hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
         hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
         hipLaunchKernelGGL((seg_finish_kernel<DD, Emit>), dim3(64), dim3(256), 0, s, keys_sorted, sc, emit);
+    });
+}
+
+#ifndef SBR_SMALL_BACK_MAX_ROWS
+#define SBR_SMALL_BACK_MAX_ROWS 128
+#endif
+bool small_back_shape_ok(const ModelView& m, int rows_host) {
+    static const bool off = std::getenv("SBR_NO_SMALL_BACK") != nullptr; /* A/B switch */
+    /* up to 128 rows: a row costs every element's thread one dependent fma and a pair of loads — ms per fit of the reference's
+     * Criterion bench (2 352 / 588 / 147 / 37 steps of ~9 / 36 / 150 / 600 rows), this form against the three launches:
+     * 74.5 / 90.1, 34.6 / 37.6, 14.6 / 13.7, 7.7 / 5.6 */
+    return !off && m.ng != 0 && (m.d == 16 || m.d == 32) && rows_host > 0 && rows_host <= SBR_SMALL_BACK_MAX_ROWS;
+}
+void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
+                       const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s) {
+    const size_t n = (size_t)(2 * m.d + 1) * m.ng * m.d;
+    const int dw_blocks = (int)((n + 255) / 256);
+    const uint64_t total = 3ull * rows_host;
+    DISPATCH_D(m.d, {
+        if constexpr (DD <= 32) {
+            const int gpb = 4 * (64 / (DD / 4));
+            const int seg_blocks = grid_for_groups((long long)total / 2 + 1, gpb);
+            hipLaunchKernelGGL((small_back_kernel<DD>), dim3(dw_blocks + seg_blocks), dim3(256), 0, s, m, mb, blk, w, keys_sorted, total, sc, dw_blocks);
+        }
     });
 }
 

@@ -1249,3 +1249,53 @@ def test_bench_regime_two_devices_whole_step_full_parity():
     for p in plans:
         p.close()
     po.close()
+
+
+@pytest.mark.parametrize("kind,loss,d,opt,T,items", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 0, 12, 300),          # ~10-row steps: the 256-thread tail
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 32, 0, 128, 1683),       # the reference's bench shape; rows beyond 64: the 1 024-thread tail
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, OPT_ADAM, 90, 500),
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 32, OPT_ADAM, 200, 40),  # 40 items: rows repeated many times inside a step
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 16, 0, 300, 97),          # beyond 255 rows: the step falls back to the separate launches
+    (ModelKind.EWMA, LOSS_WARP, 32, 0, 100, 211),                # EWMA + WARP takes the score launch's tail, not the fused update
+])
+@pytest.mark.parametrize("fused", ["on", "off"])
+def test_one_sequence_steps_fused_launches(monkeypatch, kind, loss, d, opt, T, items, fused):
+    """One subsequence per optimiser step (the reference's own schedule, sequence_model.rs:111-169) at d <= 32 runs as four
+    launches: forward, score + [header, lagged loss figure, key ordering] (sbr::SmallTail), backward, and [dense gradient + dense
+    update + sparse update] (launch_small_back: the dense gradient as per-element row chains on the vector ALU instead of MFMA
+    accumulators).  Whole fits against the oracle, bit for bit, with the fused forms and (fused = off, SBR_NO_SMALL_TAIL /
+    SBR_NO_SMALL_BACK) with the eight separate launches they replace."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, "tests")
+        import numpy as np
+        from helpers import hparams, synthetic_interactions
+        from oracle.oracle import OracleModel
+        from sbr_rs_amd._abi import Param
+        from sbr_rs_amd.engine import Model
+        ptr, it = synthetic_interactions(14, {items}, {T} + 30, seed=31, min_len=3, zipf=True)
+        hp = hparams({items}, {T}, {d}, {int(kind)}, {loss}, B=1, epochs=2, opt={opt}, lr={0.02 if opt else 0.16})
+        g, o = Model(hp), OracleModel(hp)
+        lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+        assert abs(lg - lo) <= 1e-6 * abs(lo), (lg, lo)
+        assert np.float32(g.last_fit_lagged_loss()).tobytes() == np.float32(o.last_fit_lagged_loss()).tobytes()
+        params = [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC]
+        params += [Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC] if {int(kind)} == 2 else [Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC]
+        for q in params:
+            a, b = g.get_param(q), o.get_param(q)
+            assert a.tobytes() == b.tobytes(), q
+        hist = it[int(ptr[2]):int(ptr[3])]
+        assert g.user_representation(hist).tobytes() == o.user_representation(hist).tobytes()   # (the packed weight copies were re-emitted)
+        print("ok")
+    """)
+    env = dict(__import__("os").environ)
+    if fused == "off":  # the switches are read once per process
+        env["SBR_NO_SMALL_TAIL"] = env["SBR_NO_SMALL_BACK"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-800:] + r.stderr[-1500:]

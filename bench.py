@@ -244,6 +244,35 @@ def cpu_movielens_batch1(workers):
     return out
 
 
+def reference_criterion_bench(samples: int = 5):
+    """benches/benchmark.rs:16-71 through the Python host mirror (tools/criterion_bench.py): `fit` on 10 000 sampled MovieLens-100K
+    interactions, max_sequence_length 128, dim 32, hinge, Adagrad, three epochs per call, re-fitting one model; the reference's
+    schedule (one subsequence per optimiser step) and 16 subsequences per step; the C oracle's time for the same call on one host
+    core beside it (profiles/r04_criterion_bench.md)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import criterion_bench as cb
+    from oracle.oracle import OracleModel
+
+    data = cb.sample_data(10_000)
+    out = {"config": "benches/benchmark.rs: fit on 10 000 sampled MovieLens-100K interactions, max_sequence_length 128, dim 32, hinge, Adagrad, "
+                     "3 epochs per call, 1 worker; ms per fit call, mean of %d calls on one model after a warm-up call" % samples}
+    for kind in ("lstm", "ewma"):
+        for batch in (1, 16):
+            model = cb.build(kind, data.num_items(), batch)
+            model.fit(data)
+            t0 = time.perf_counter()
+            for _ in range(samples):
+                model.fit(data)
+            out[f"{kind}_batch_sequences_{batch}_ms"] = 1e3 * (time.perf_counter() - t0) / samples
+            if batch == 1:
+                o = OracleModel(model.params.hp)
+                t0 = time.perf_counter()
+                o.fit(data.user_pointers, data.item_ids)
+                out[f"{kind}_c_oracle_one_core_ms"] = 1e3 * (time.perf_counter() - t0)
+                o.close()
+    return out
+
+
 def movielens_mrr():
     """BASELINE.json configs[1] (untimed): MovieLens-100K, LSTM Normal, dim 32, WARP, Adagrad,
     10 epochs under the reference protocol (lstm.rs:427-448, 498-520) — at batch_sequences 1, the
@@ -891,6 +920,10 @@ def main():
                 out["test_mrr"] = movielens_mrr()
             except Exception as e:  # the throughput line must survive a fixture problem
                 out["test_mrr"] = {"error": repr(e)}
+            try:  # the reference's own Criterion bench (benches/benchmark.rs:16-71; no published number): ms per fit call
+                out["reference_criterion_bench"] = reference_criterion_bench()
+            except Exception as e:
+                out["reference_criterion_bench"] = {"error": repr(e)}
         line = json.dumps(out)
     backend.close()
     # RCCL writes a version banner through C stdio, which is only flushed at exit when stdout is a pipe:

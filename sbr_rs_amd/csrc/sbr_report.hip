@@ -105,14 +105,15 @@ __global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, cons
 // example count.  loss_acc / ex_acc non-null (single device): the plan's accumulators take the header in the same launch.
 // lag_state non-null (a small step, everything on one stream): the lagged figure of up to SBR_HEADER_LAG_MAX_B sequences in the
 // same launch as well — a small step is a chain of ~5 us launches and cannot afford two more.
-__global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
+__global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, int R, const double* part_loss,
                                                           const unsigned int* part_tries, int nparts, double* loss_acc,
                                                           unsigned long long* ex_acc, MbView mb, const float* loss, float* lag_state) {
     /* one workgroup, usually underneath BPTT on the ordering's stream: at priority 0 it took 1.5 ms of elapsed time at 50 000
      * sequences per step (every instruction waits for an MFMA pass of the older waves) and held the key ordering up by as much */
     __builtin_amdgcn_s_setprio(3);
-    __shared__ double part[4];
-    __shared__ unsigned int tpart[4];
+    __shared__ double part[16];
+    __shared__ unsigned int tpart[16];
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6; /* 256, or 1 024 when several sequences' loss chains are walked here */
     /* the lagged figure's staging (24 KB) is DYNAMIC shared memory, asked for only by the small-step launch that uses it: as static
      * memory it kept the header launch of a 50 000-sequence step off the chip until a BPTT workgroup retired (64-sequence tiles
      * leave less than 24 KB of LDS per CU) — 1.5 ms during which the key ordering behind it on the stream could not start */
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
     float* sx = lag_lds + 2 * SBR_HEADER_LAG_MAX_B;
     double acc = 0.0;
     unsigned int tacc = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) {
+    for (int i = threadIdx.x; i < nparts; i += nthreads) {
         acc += part_loss[i];
         tacc += part_tries[i];
     }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
     if (lag_state) { /* a wave per sequence, 64 loss terms per coalesced load, then the t-ascending chain by v_readlane: one
                       * sequence per step (the reference's schedule) must not wait for ~100 dependent load-add pairs */
         const int lane = threadIdx.x & 63;
-        for (int b = threadIdx.x >> 6; b < mb.B; b += 4) {
+        for (int b = threadIdx.x >> 6; b < mb.B; b += nwaves) {
             const int n = mb.steps[b];
             float s = 0.0f;
             for (int base = 0; base < n; base += 64) {
@@ -156,9 +157,11 @@ __global__ __launch_bounds__(256) void block_header_kernel(uint32_t* header, int
     __syncthreads();
     if (threadIdx.x == 0) {
         header[0] = (uint32_t)R;
-        header[1] = tpart[0] + tpart[1] + tpart[2] + tpart[3]; /* negatives scored in this minibatch (reporting only) */
+        unsigned int tsum = tpart[0];
+        double lsum = part[0];
+        for (int i = 1; i < nwaves; ++i) { tsum += tpart[i]; lsum += part[i]; }
+        header[1] = tsum; /* negatives scored in this minibatch (reporting only) */
         header[2] = header[3] = 0;
-        const double lsum = part[0] + part[1] + part[2] + part[3];
         *reinterpret_cast<double*>(header + 4) = lsum;
         *reinterpret_cast<unsigned long long*>(header + 6) = (unsigned long long)R;
         if (loss_acc) { /* single device: the plan's accumulators take the header here (accumulate_loss_kernel with one block) */
@@ -176,7 +179,10 @@ void launch_block_header_parts(uint32_t* header, int rows_host, const double* pa
                                double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
                                hipStream_t s) {
     const size_t lds = lag_state ? (size_t)(2 * SBR_HEADER_LAG_MAX_B + (SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B)) * 4 : 0;
-    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(256), lds, s, header, rows_host, part_loss, part_tries, nparts, loss_acc, ex_acc,
+    /* a small step walks its sequences' loss chains here, a wave per sequence: sixteen waves when there are more than four sequences
+     * (MovieLens-100K at 16 sequences per step: 16 -> 6 us of a 266 us step) */
+    const int threads = lag_state && mb.B > 4 ? 1024 : 256;
+    hipLaunchKernelGGL(block_header_kernel, dim3(1), dim3(threads), lds, s, header, rows_host, part_loss, part_tries, nparts, loss_acc, ex_acc,
                        mb, loss, lag_state);
 }
 

@@ -146,7 +146,10 @@ __device__ __forceinline__ float dot4(float4 x, float4 y) {
 // 50 000 sequences per step with U = 2, round 2).  U = 2 at small launches (the quality-neutral 8 192 sequences per step =
 // 256 K rows): a wave then walks ~18 passes of ~1.75 dependent memory round trips each and the kernel is THEIR LATENCY, not the
 // bytes — half the passes with twice the rows in flight.  Same arithmetic per row, same bits.
-template <int D, int U, bool PF>
+// SPEC (the one-workgroup launch of a one-sequence step): all of a row's candidates are gathered together and then tested in
+// order — the launch is a handful of dependent memory round trips and nothing else, and WARP's retries were up to four of them
+// (~6 us of a 19 us launch); the extra rows are a few KB.  Same tests in the same order on the same values.
+template <int D, int U, bool PF, bool SPEC = false>
 __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                                 uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
     constexpr int L = D / 4;
@@ -223,6 +226,38 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
             tries[u] = 0;
             neg[u] = 0.0f;
         }
+        if constexpr (SPEC) {
+            float4 ecs[U][SBR_WARP_MAX_TRIES];
+            float bcs[U][SBR_WARP_MAX_TRIES];
+            uint32_t cds[U][SBR_WARP_MAX_TRIES];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                cds[u][0] = cand[u];
+                ecs[u][0] = ec[u];
+                bcs[u][0] = bc[u];
+#pragma unroll
+                for (int k = 1; k < SBR_WARP_MAX_TRIES; ++k) {
+                    cds[u][k] = spread ? (uint32_t)__shfl((int)draws[u], grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr[u], (uint32_t)k, m.num_items);
+                    ecs[u][k] = ld4(m.E + (size_t)cds[u][k] * D + 4 * lg);
+                    bcs[u][k] = m.b[cds[u][k]];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SBR_WARP_MAX_TRIES; ++k) {
+                if (k < max_tries) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float sc = bcs[u][k] + group_allreduce<L>(dot4(h[u], ecs[u][k]));
+                        if (!done[u]) {
+                            nj[u] = cds[u][k];
+                            neg[u] = sc;
+                            ++tries[u];
+                            if (sbr_warp_violates(pos[u], sc)) done[u] = true;
+                        }
+                    }
+                }
+            }
+        } else
         for (int k = 0; k < max_tries; ++k) {
             if (k > 0) {
                 bool all_done = true;
@@ -413,7 +448,7 @@ __global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, 
     constexpr int NW = NT / 64;
     double loss_part;
     unsigned int tries_part;
-    if (m.loss == SBR_LOSS_WARP) score_warp_rows<D, 1, false>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), NW, &loss_part, &tries_part);
+    if (m.loss == SBR_LOSS_WARP) score_warp_rows<D, 1, false, true>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), NW, &loss_part, &tries_part);
     else score_single_rows_fwd<D>(m, mb, blk, w, epoch_key, (int)(threadIdx.x >> 6), NW, &loss_part, &tries_part);
     __shared__ double s_loss[NW];
     __shared__ unsigned int s_tries[NW];
@@ -2545,37 +2580,39 @@ __global__ __launch_bounds__(256) void small_back_kernel(ModelView m, MbView mb,
     const int NGD = m.ng * D, K2 = 2 * D, R = mb.R;
     const size_t n = (size_t)(K2 + 1) * NGD;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // operands through LDS: dZ of the whole step (<= 128 rows x <= 128 columns) and the xh columns of this workgroup's gradient rows,
+    // requested by all threads at once — read straight from memory, eight rows at a time, every batch was a ~1 us round trip ahead
+    // of its eight fmas (13 us per launch at ~105 rows)
+    extern __shared__ __attribute__((aligned(16))) float sb_lds[];
+    float* zs = sb_lds;                  // [R][NGD]
+    float* xs = zs + (size_t)R * NGD;    // [nk][R]
+    const int kmin = (int)(((size_t)blockIdx.x * 256) / NGD);
+    const int klast = (int)(((size_t)blockIdx.x * 256 + 255) / NGD);
+    const int nk = (klast < K2 ? klast : K2 - 1) - kmin + 1;  // (row K2 is the bias row: no xh operand)
+    for (int idx = threadIdx.x; idx < R * NGD / 4; idx += 256) st4(zs + 4 * (size_t)idx, ld4(w.dZ + 4 * (size_t)idx));
+    for (int idx = threadIdx.x; idx < nk * R; idx += 256) {
+        const int kk = kmin + idx / R, r = idx % R;
+        float v;
+        if (kk < D) {
+            v = w.X[(size_t)r * D + kk];
+        } else {
+            const int pr = mb.prev_row[r];
+            v = pr >= 0 ? blk.H[(size_t)pr * D + (kk - D)] : 0.0f;
+        }
+        xs[idx] = v;
+    }
+    __syncthreads();
     if (i >= n) return;
     const int k = (int)(i / NGD), j = (int)(i % NGD);
-    const float* dz = w.dZ + j;
+    const float* zc = zs + j;
     float acc = 0.0f;
     if (k < K2) {
-        for (int r0 = 0; r0 < R; r0 += 8) {  // eight rows' operands in flight; the chain itself is one dependent fma per row
-            float a[8], b[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = r0 + q < R ? r0 + q : R - 1;
-                b[q] = dz[(size_t)r * NGD];
-                if (k < D) {
-                    a[q] = w.X[(size_t)r * D + k];
-                } else {
-                    const int pr = mb.prev_row[r];
-                    a[q] = pr >= 0 ? blk.H[(size_t)pr * D + (k - D)] : 0.0f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (r0 + q < R) acc = sbr_fma(a[q], b[q], acc);
-        }
+        const float* xc = xs + (size_t)(k - kmin) * R;
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) acc = sbr_fma(xc[r], zc[(size_t)r * NGD], acc);
     } else {
-        for (int r0 = 0; r0 < R; r0 += 8) {
-            float b[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) b[q] = dz[(size_t)(r0 + q < R ? r0 + q : R - 1) * NGD];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (r0 + q < R) acc = acc + b[q];
-        }
+#pragma unroll 8
+        for (int r = 0; r < R; ++r) acc = acc + zc[(size_t)r * NGD];
     }
     blk.dense[i] = acc;
     dense_apply_element(m, i, acc);
@@ -3408,7 +3445,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
 }
 
 #ifndef SBR_SMALL_BACK_MAX_ROWS
-#define SBR_SMALL_BACK_MAX_ROWS 128
+#define SBR_SMALL_BACK_MAX_ROWS 256
 #endif
 bool small_back_shape_ok(const ModelView& m, int rows_host) {
     static const bool off = std::getenv("SBR_NO_SMALL_BACK") != nullptr; /* A/B switch */
@@ -3426,7 +3463,16 @@ void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& bl
         if constexpr (DD <= 32) {
             const int gpb = 4 * (64 / (DD / 4));
             const int seg_blocks = grid_for_groups((long long)total / 2 + 1, gpb);
-            hipLaunchKernelGGL((small_back_kernel<DD>), dim3(dw_blocks + seg_blocks), dim3(256), 0, s, m, mb, blk, w, keys_sorted, total, sc, dw_blocks);
+            const size_t lds = ((size_t)rows_host * m.ng * DD + (size_t)(256 / (m.ng * DD) + 2) * rows_host) * 4;
+            static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            dev = dev >= 0 && dev < 64 ? dev : 0;
+            if (lds > granted[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(small_back_kernel<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                granted[dev] = lds;
+            }
+            hipLaunchKernelGGL((small_back_kernel<DD>), dim3(dw_blocks + seg_blocks), dim3(256), lds, s, m, mb, blk, w, keys_sorted, total, sc, dw_blocks);
         }
     });
 }

@@ -1524,7 +1524,8 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
     static const char* ewma_env0 = std::getenv("SBR_EWMA_FUSED");
     const bool ewma_seq_pass = !m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0 && (ewma_env0 ? std::atoi(ewma_env0) : SBR_EWMA_FUSED_DEFAULT) != 0;
-    const bool small_tail = !overlap && p->ndev == 1 && !ewma_seq_pass && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
+    const bool small_tail = !overlap && p->ndev == 1 && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
+    (void)ewma_seq_pass;
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
@@ -1560,10 +1561,14 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* EWMA + single-negative loss (BASELINE configs[4]): scan and score in one pass per sequence, optionally the backward scan too
      * (SBR_EWMA_FUSED = 0: three launches / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
     static const char* ewma_env = std::getenv("SBR_EWMA_FUSED");
-    const int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? (ewma_env ? std::atoi(ewma_env) : SBR_EWMA_FUSED_DEFAULT) : 0;
+    int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? (ewma_env ? std::atoi(ewma_env) : SBR_EWMA_FUSED_DEFAULT) : 0;
+    if (ewma_fused && small_tail) ewma_fused = 2; /* a one-sequence step: the backward scan rides along as well */
     if (ewma_fused) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
-        sbr::launch_ewma_forward_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, ewma_fused >= 2, m->stream);
+        p->header_accumulated = p->ndev == 1;
+        const sbr::SmallTail tail{bv.header, p->header_accumulated ? p->loss_acc : nullptr, p->header_accumulated ? p->ex_acc : nullptr,
+                                  p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
+        sbr::launch_ewma_forward_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, ewma_fused >= 2, m->stream, small_tail ? &tail : nullptr);
     } else {
         {
             ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
@@ -1617,7 +1622,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
         HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
     }
-    p->dw_deferred = p->fuse_back && !overlap && p->ndev == 1 && sbr::small_back_shape_ok(m->mv, (int)mb.R);
+    p->dw_deferred = p->fuse_back && !overlap && p->ndev == 1 && sbr::small_back_shape_ok(m->mv, (int)mb.R) && (m->ng || mb.B <= 256);
     if (p->dw_deferred) p->dense_unreduced_chunks = 0;
     if (!p->dw_deferred) {
         /* one device: the ordered reduction of the chunk partials is left to the consumer — the optimiser step folds it into

@@ -733,8 +733,9 @@ __device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbVi
     st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
 }
 
-template <int D, bool WHOLE>
-__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
+// TAIL (one workgroup, a one-sequence step): the step's SmallTail follows in the same launch
+template <int D, bool WHOLE, bool TAIL = false>
+__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
@@ -820,9 +821,14 @@ __global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, B
         s_tries[threadIdx.x >> 6] = tries_part;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        w.part_loss[blockIdx.x] = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
-        w.part_tries[blockIdx.x] = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
+    if (TAIL || threadIdx.x == 0) {
+        const double lsum = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+        const unsigned int tsum = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
+        if (threadIdx.x == 0) {
+            w.part_loss[blockIdx.x] = lsum;
+            w.part_tries[blockIdx.x] = tsum;
+        }
+        if constexpr (TAIL) small_tail<256>(mb, blk, w, tail, lsum, tsum);
     }
 }
 
@@ -2577,6 +2583,17 @@ __global__ __launch_bounds__(256) void small_back_kernel(ModelView m, MbView mb,
                                            (uint32_t)((((uint64_t)gridDim.x - dw_blocks) * 256) >> 6));
         return;
     }
+    if (m.ng == 0) { /* EWMA (one dense workgroup): dalpha = ordered sum of the sequences' partials (ewma_dab_final_kernel), then its update */
+        const int k = threadIdx.x;
+        if (k >= D) return;
+        float pc = 0.0f;
+        for (int b = 0; b < mb.B; ++b) pc = pc + w.dab[(size_t)b * D + k];
+        const float a = sbr_sigmoidf(m.alpha[k]);
+        const float g = pc * (a * (1.0f - a));
+        blk.dense[k] = g;
+        dense_apply_element(m, (size_t)k, g);
+        return;
+    }
     const int NGD = m.ng * D, K2 = 2 * D, R = mb.R;
     const size_t n = (size_t)(K2 + 1) * NGD;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -3230,12 +3247,19 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
 /* EWMA + single-negative loss: scan and score in one pass per sequence (ewma_seq_kernel); whole = the backward scan too.  The
  * grid is launch_score's, so that launch_block_header finds the same number of loss partials. */
 void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
-                               int rows_host, bool whole, hipStream_t s) {
+                               int rows_host, bool whole, hipStream_t s, const SmallTail* tail) {
     if (rows_host <= 0) return;
+    const SmallTail none{};
     DISPATCH_D(m.d, {
+        if constexpr (DD <= 32) {
+            if (tail) { /* one sequence: scan, score, backward scan and the step's bookkeeping + key ordering in one workgroup's launch */
+                hipLaunchKernelGGL((ewma_seq_kernel<DD, true, true>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail);
+                return;
+            }
+        }
         const int grid = score_grid(DD, rows_host, true);
-        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
+        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
     });
 }
 
@@ -3452,18 +3476,21 @@ bool small_back_shape_ok(const ModelView& m, int rows_host) {
     /* up to 128 rows: a row costs every element's thread one dependent fma and a pair of loads — ms per fit of the reference's
      * Criterion bench (2 352 / 588 / 147 / 37 steps of ~9 / 36 / 150 / 600 rows), this form against the three launches:
      * 74.5 / 90.1, 34.6 / 37.6, 14.6 / 13.7, 7.7 / 5.6 */
-    return !off && m.ng != 0 && (m.d == 16 || m.d == 32) && rows_host > 0 && rows_host <= SBR_SMALL_BACK_MAX_ROWS;
+    if (off || (m.d != 16 && m.d != 32) || rows_host <= 0) return false;
+    if (m.ng == 0) return 3ull * (uint64_t)rows_host <= SBR_SEG_INLINE_MAX_KEYS; /* EWMA: dalpha + its update + the sparse update; the caller checks
+                                                                                    * that the sequences fit one dalpha chunk */
+    return rows_host <= SBR_SMALL_BACK_MAX_ROWS;
 }
 void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
                        const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s) {
-    const size_t n = (size_t)(2 * m.d + 1) * m.ng * m.d;
+    const size_t n = m.ng ? (size_t)(2 * m.d + 1) * m.ng * m.d : (size_t)m.d;
     const int dw_blocks = (int)((n + 255) / 256);
     const uint64_t total = 3ull * rows_host;
     DISPATCH_D(m.d, {
         if constexpr (DD <= 32) {
             const int gpb = 4 * (64 / (DD / 4));
             const int seg_blocks = grid_for_groups((long long)total / 2 + 1, gpb);
-            const size_t lds = ((size_t)rows_host * m.ng * DD + (size_t)(256 / (m.ng * DD) + 2) * rows_host) * 4;
+            const size_t lds = m.ng ? ((size_t)rows_host * m.ng * DD + (size_t)(256 / (m.ng * DD) + 2) * rows_host) * 4 : 0;
             static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
             int dev = 0;
             (void)hipGetDevice(&dev);

@@ -1257,14 +1257,17 @@ def test_bench_regime_two_devices_whole_step_full_parity():
     (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, OPT_ADAM, 90, 500),
     (ModelKind.LSTM_COUPLED, LOSS_WARP, 32, OPT_ADAM, 200, 40),  # 40 items: rows repeated many times inside a step
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 16, 0, 300, 97),          # beyond 255 rows: the step falls back to the separate launches
-    (ModelKind.EWMA, LOSS_WARP, 32, 0, 100, 211),                # EWMA + WARP takes the score launch's tail, not the fused update
+    (ModelKind.EWMA, LOSS_WARP, 32, 0, 100, 211),                # EWMA + WARP: scan, then the score launch with the tail
+    (ModelKind.EWMA, LOSS_HINGE, 32, 0, 128, 1683),              # the reference's ewma bench: scan + score + backward scan + tail in one launch
+    (ModelKind.EWMA, LOSS_BPR, 16, OPT_ADAM, 60, 50),
 ])
 @pytest.mark.parametrize("fused", ["on", "off"])
 def test_one_sequence_steps_fused_launches(monkeypatch, kind, loss, d, opt, T, items, fused):
     """One subsequence per optimiser step (the reference's own schedule, sequence_model.rs:111-169) at d <= 32 runs as four
     launches: forward, score + [header, lagged loss figure, key ordering] (sbr::SmallTail), backward, and [dense gradient + dense
     update + sparse update] (launch_small_back: the dense gradient as per-element row chains on the vector ALU instead of MFMA
-    accumulators).  Whole fits against the oracle, bit for bit, with the fused forms and (fused = off, SBR_NO_SMALL_TAIL /
+    accumulators); EWMA with a single-negative loss as two: [scan + score + backward scan + tail] and [dalpha + its update +
+    sparse update].  Whole fits against the oracle, bit for bit, with the fused forms and (fused = off, SBR_NO_SMALL_TAIL /
     SBR_NO_SMALL_BACK) with the eight separate launches they replace."""
     import subprocess
     import sys

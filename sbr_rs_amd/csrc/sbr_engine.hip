@@ -631,6 +631,9 @@ struct sbr_fit_plan {
     unsigned long long* ex_acc = nullptr;
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
+    bool hot_prelisted = false; /* this step's long segments (hot rows) were listed behind the ordering: their chunks are reduced on the
+                                 * ordering's stream beside the short-segment pass (sbr_fit_step_apply) */
+    hipEvent_t ev_hot = nullptr;
     bool fuse_back = false;     /* sbr_fit_step: the step's optimiser half may take the single-launch form (sbr::launch_small_back) */
     bool dw_deferred = false;   /* ... and step_local left the dense gradient to it */
     int dense_unreduced_chunks = 0; /* > 0: blk.dense is still that many chunk partials in wb.v.partials (one device: reduced by its consumer) */
@@ -1233,7 +1236,8 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + T);
     if (st == SBR_OK) st = dmalloc(&p->lag_seqsum, p->bmax);
     if (st == SBR_OK && (hipEventCreateWithFlags(&p->ev_seqsum, hipEventDisableTiming) != hipSuccess ||
-                         hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess)) st = SBR_ERR_HIP;
+                         hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&p->ev_hot, hipEventDisableTiming) != hipSuccess)) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
     if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
@@ -1284,6 +1288,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     dfree(p->lag_state); dfree(p->lag_seqsum);
     if (p->ev_seqsum) hipEventDestroy(p->ev_seqsum);
     if (p->ev_lagged) hipEventDestroy(p->ev_lagged);
+    if (p->ev_hot) hipEventDestroy(p->ev_hot);
     dfree(p->seg.counters); dfree(p->seg.long_start); dfree(p->seg.long_end); dfree(p->seg.unit_base);
     dfree(p->seg.P); dfree(p->seg.Pb); dfree(p->seg.Pf);
     dfree(p->seg.head_pos); dfree(p->seg.nheads);
@@ -1547,9 +1552,19 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         if (p->sort_off_stream) {
             HIPCHK(hipEventRecord(m->ev_sorted, on));
             p->sorted_event_live = true;
+            /* single device: the hot rows (segments of more than SBR_SEG_CHUNK entries: a skewed catalogue) are listed and their
+             * chunk units counted HERE, still underneath BPTT — registering them during the short-segment pass put their three
+             * launches behind it on the update's critical path (Zipf(1) items at 8 192 sequences per step: 0.13 of 2.66 ms).
+             * (after ev_sorted: the short-segment pass does not wait for the list)  SBR_NO_HOT_PRELIST=1: the old order. */
+            static const bool no_prelist = std::getenv("SBR_NO_HOT_PRELIST") != nullptr;
+            if (p->ndev == 1 && overlap && !no_prelist && 3ull * (uint64_t)mb.R > 4096) {
+                sbr::launch_seg_prelist(p->seg, on);
+                p->hot_prelisted = true;
+            }
         }
         return SBR_OK;
     };
+    p->hot_prelisted = false;
     if (early_sort && !small_tail) SBRCHK(launch_sort(overlap ? m->sorter : m->stream));
     if (small_tail) {
         if (p->lag_busy) { /* an earlier step's chain on the ordering's stream still owns lag_state */
@@ -1669,8 +1684,18 @@ sbr_status sbr_fit_step_apply(sbr_fit_plan* p, uint64_t minibatch) {
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
         if (p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
-        sbr::launch_seg_apply(m->mv, block_view(m, p->block, p->rmax), p->ep[p->cur].rows_of_dev[minibatch], p->keys_sorted, p->seg,
-                              m->stream);
+        sbr::SegScratch sc = p->seg;
+        sc.prelisted = p->hot_prelisted ? 1u : 0u;
+        const sbr::BlockView bv = block_view(m, p->block, p->rmax);
+        sbr::launch_seg_apply(m->mv, bv, p->ep[p->cur].rows_of_dev[minibatch], p->keys_sorted, sc, m->stream);
+        if (p->hot_prelisted) { /* the listed hot rows: chunk partials + ordered finish on the ordering's stream (behind the list, and
+                                 * behind BPTT: ev_fork), beside the short segments' pass — disjoint table rows */
+            p->hot_prelisted = false;
+            HIPCHK(hipStreamWaitEvent(m->sorter, m->ev_fork, 0));
+            sbr::launch_seg_hot_apply(m->mv, bv, p->keys_sorted, sc, m->sorter);
+            HIPCHK(hipEventRecord(p->ev_hot, m->sorter));
+            HIPCHK(hipStreamWaitEvent(m->stream, p->ev_hot, 0));
+        }
     }
     SBRCHK(join_dense(p));
     {

@@ -90,7 +90,14 @@ struct SegScratch {
      * the sentinel head_pos[*nheads] = number of keys; produced right after the sort, on its stream */
     uint32_t* head_pos;
     uint32_t* nheads;
+    uint32_t prelisted;   /* 1: the long segments were listed and their chunk units counted right after the ordering (launch_seg_prelist):
+                           * the short-segment pass skips them, their chunks are reduced beside it on another stream */
 };
+/* single device, large step: the hot rows' part of the sparse update off the update's critical path.  launch_seg_prelist (the
+ * ordering's stream, underneath BPTT) lists the segments of more than SBR_SEG_CHUNK entries and counts their chunk units;
+ * launch_seg_apply then runs the short segments only, and launch_seg_hot_apply reduces and applies the listed ones on another stream
+ * (disjoint table rows). */
+void launch_seg_prelist(const SegScratch& sc, hipStream_t s);
 
 /* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
 struct PeerLists {
@@ -131,6 +138,7 @@ bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
 /* The optimiser half of a small single-device LSTM step at d <= 32 (one dense-gradient chunk, single-launch sparse update) in ONE
  * launch: dense gradient (per-element row chains) + dense update + sparse update, instead of three. */
 bool small_back_shape_ok(const ModelView& m, int rows_host);
+void launch_seg_hot_apply(const ModelView& m, const BlockView& blk, const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
 void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
                        const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,

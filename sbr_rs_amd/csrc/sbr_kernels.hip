@@ -2503,8 +2503,8 @@ __device__ __forceinline__ void seg_short_rows(const BlockView& blk, const uint6
             emit.template row<D>(row, p, lg, g, has_b, gb, pre);
             continue;
         }
-        if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path */
-            if (lg == 0) {
+        if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path (or listed already: seg_long_list_kernel) */
+            if (lg == 0 && !sc.prelisted) {
                 const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
                 if (slot < sc.cap) {
                     sc.long_start[slot] = (uint32_t)p;
@@ -2633,6 +2633,22 @@ __global__ __launch_bounds__(256) void small_back_kernel(ModelView m, MbView mb,
     }
     blk.dense[i] = acc;
     dense_apply_element(m, i, acc);
+}
+
+// the long segments straight from the head list (launch_seg_prelist): what seg_short_kernel registers as it meets them, known
+// before the update starts
+__global__ __launch_bounds__(256) void seg_long_list_kernel(SegScratch sc) {
+    const uint32_t nheads = *sc.nheads;
+    for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < nheads; h += gridDim.x * 256) {
+        const uint32_t p0 = sc.head_pos[h], p1 = sc.head_pos[h + 1];
+        if (p1 - p0 > SBR_SEG_CHUNK) {
+            const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
+            if (slot < sc.cap) {
+                sc.long_start[slot] = p0;
+                sc.long_end[slot] = p1;
+            }
+        }
+    }
 }
 
 // prefix of the long segments' chunk counts (a few thousand entries at most: one workgroup)
@@ -3452,7 +3468,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
         });
         return;
     }
-    (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
+    if (!sc.prelisted) (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
     DISPATCH_D(d, {
         const int gpb = 4 * (64 / (DD / 4));
         /* 4 workgroups per CU: with 8 the update's waves fill the register file and the dense-gradient GEMM on the side
@@ -3462,6 +3478,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
         int seg_grid = grid_for_groups((long long)total / 2 + 1, gpb);
         if (seg_grid > seg_grid_cap) seg_grid = seg_grid_cap;
         hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(seg_grid), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
+        if (sc.prelisted) return; /* the listed segments: launch_seg_hot_apply, on another stream */
         hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
         hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
         hipLaunchKernelGGL((seg_finish_kernel<DD, Emit>), dim3(64), dim3(256), 0, s, keys_sorted, sc, emit);
@@ -3501,6 +3518,18 @@ void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& bl
             }
             hipLaunchKernelGGL((small_back_kernel<DD>), dim3(dw_blocks + seg_blocks), dim3(256), lds, s, m, mb, blk, w, keys_sorted, total, sc, dw_blocks);
         }
+    });
+}
+
+void launch_seg_prelist(const SegScratch& sc, hipStream_t s) {
+    (void)hipMemsetAsync(sc.counters, 0, 2 * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(seg_long_list_kernel, dim3(256), dim3(256), 0, s, sc);
+    hipLaunchKernelGGL(seg_units_kernel, dim3(1), dim3(256), 0, s, sc);
+}
+void launch_seg_hot_apply(const ModelView& m, const BlockView& blk, const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s) {
+    DISPATCH_D(m.d, {
+        hipLaunchKernelGGL((seg_chunk_kernel<DD>), dim3(1024), dim3(256), 0, s, blk, keys_sorted, sc);
+        hipLaunchKernelGGL((seg_finish_kernel<DD, EmitApply>), dim3(64), dim3(256), 0, s, keys_sorted, sc, EmitApply{m});
     });
 }
 

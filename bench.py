@@ -525,6 +525,7 @@ def main():
 
     engine.set_device(local_rank)
     dist = None
+    backend_note = None
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
 
@@ -534,7 +535,18 @@ def main():
         if args.backend == "gloo":
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:  # RCCL over xGMI; a first collective here so that a transport problem shows before the plan is built
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:  # no usable RCCL on this host: the host-staged test transport still produces a (slower) line
+                backend_note = f"nccl unavailable ({e!r}): gloo, host-staged"
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                args.backend = "gloo"
 
     model_kind = {"lstm": 0, "lstm-coupled": 1, "ewma": 2}[args.model]
     loss_kind = {"bpr": 0, "hinge": 1, "warp": 2}[args.loss]
@@ -867,7 +879,7 @@ def main():
                                        f"owner-reduce exchange over {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged, test transport)'}") if world > 1 else "single device"},
             "process_group_ranks": dist.get_world_size() if dist is not None else 1,
             "rccl_ranks": dist.get_world_size() if dist is not None and args.backend == "nccl" else 0,
-            "collective_backend": (args.backend if args.backend == "gloo" else "nccl (RCCL)") if dist is not None else None,
+            "collective_backend": (backend_note or (args.backend if args.backend == "gloo" else "nccl (RCCL)")) if dist is not None else None,
             "ms_per_step_per_rank": per_rank,
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],

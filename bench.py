@@ -421,6 +421,100 @@ def simulate_world(args, model_kind, loss_kind):
     }
 
 
+def group_driver(args, model_kind, loss_kind):
+    """`--driver group`: the path INTEGRATION.md binds for a one-process caller (Hyperparameters::num_threads(n) -> n device
+    replicas -> sbr_group_fit): N replicas driven from THIS process through sbr_group_fit's own step sequence
+    (sbr_group_fit_begin / _epoch_prepare / _step), replica r on HIP device r mod device count — N physical devices when the
+    node has them, else N replicas sharing one GPU (then the devices' work is serialised: the host enqueue time is what that
+    run measures, not scaling).  Timed with one host thread for all devices and with one host thread per device; `value` is the
+    library's default mode.  ≙ /root/reference/src/models/sequence_model.rs:90-102 inside one process."""
+    import zlib
+
+    from sbr_rs_amd import engine
+    from sbr_rs_amd._abi import Param
+
+    n = args.gpus
+    physical = engine.device_count()
+    engine.set_device(0)
+    ptr, items = synthetic_csr(args.users * n, args.items, args.max_len, zipf=args.item_distribution == "zipf")
+    hp = make_hp(args, n, 0, model_kind, loss_kind, args.items)
+    models = engine.group_create(hp, n, partition_item_table=args.partition_table)
+    modes = {}
+
+    def run(threads):
+        gp = engine.GroupPlan(models, ptr, items, host_threads=threads)
+        st = {"nmb": gp.epoch_prepare(prefetch_next=True), "mb": 0}
+
+        def one():
+            if st["mb"] >= st["nmb"]:
+                st["nmb"], st["mb"] = gp.epoch_prepare(prefetch_next=True), 0
+            mb = st["mb"]
+            rows = sum(gp.member(r).minibatch_rows(mb) for r in range(n))
+            gp.step(mb)
+            st["mb"] += 1
+            return rows
+
+        for _ in range(args.warmup):
+            one()
+        gp.synchronize()
+        q0, s0, nth = gp.stats()
+        rows = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rows += one()
+        t_queued = time.perf_counter()
+        gp.synchronize()
+        t1 = time.perf_counter()
+        q1, s1, _ = gp.stats()
+        gp.close()
+        return {"host_threads": nth, "ms_per_step": 1e3 * (t1 - t0) / args.steps, "host_enqueue_ms_per_step": (q1 - q0) / max(s1 - s0, 1),
+                "host_loop_ms_per_step": 1e3 * (t_queued - t0) / args.steps, "interactions_per_s": rows / (t1 - t0), "interactions_timed": rows}
+
+    default = run(None)
+    modes["library_default"] = default
+    if n > 1:
+        modes["one_host_thread"] = run(False)
+        modes["host_thread_per_device"] = run(True)
+    names = ["ITEM_EMBEDDING", "ITEM_EMBEDDING_ACC", "ITEM_BIAS", "ITEM_BIAS_ACC"] + (["LSTM_W", "LSTM_W_ACC", "LSTM_B"] if model_kind != 2 else ["EWMA_ALPHA"])
+    crcs = []
+    if args.param_crc:
+        crcs = [{k: zlib.crc32(m.get_param(getattr(Param, k)).tobytes()) for k in names} for m in (models if not args.partition_table else models[:1] + models[-1:])]
+    out = {
+        "metric": "train interactions/sec", "value": default["interactions_per_s"], "unit": "interactions/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": default["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "driver": "group",
+        "host_enqueue_ms_per_step": default["host_enqueue_ms_per_step"], "host_threads": default["host_threads"],
+        "host_enqueue_fraction_of_step": default["host_enqueue_ms_per_step"] / default["ms_per_step"],
+        "physical_devices": physical,
+        "note": (f"{n} replicas on {physical} physical device(s)" + ("" if physical >= n else
+                 ": the replicas SHARE a GPU, their work is serialised — this is a measurement of the group driver's host side "
+                 "and of the exchange kernels, NOT of multi-GPU scaling")),
+        "config": {"workload": f"{workload_label(args, n)}: {n} x {args.users} users x {args.items} items, seq_len<={args.max_len}, dim {args.dim}, "
+                               f"{args.model}+{args.loss}, batch_sequences {args.batch_sequences} per replica, "
+                               f"{'item table partitioned over the replicas (owner-computes)' if args.partition_table else 'table replicated (owner-reduce exchange)'}, "
+                               f"{args.parallelism}", "parallelism": f"dp{n} in one process (sbr_group_fit)"},
+        "modes": modes,
+    }
+    if args.partition_table:
+        # remote-gather traffic of the partitioned table (SURVEY 8d): (n-1)/n of the gathered rows live on a peer
+        d = args.dim
+        gather_bytes = (3 * 4 * d + 2 * 4)  # hinge / BPR: input, target, one negative + two biases; WARP: + (k-1) rows
+        remote = gather_bytes * (n - 1) / n
+        link = 153e9
+        out["remote_gather"] = {
+            "bytes_per_interaction_remote": remote, "bytes_per_interaction_gathered": gather_bytes,
+            "xgmi_bound_interactions_per_s_per_gpu": (n - 1) * link / remote if n > 1 else None,
+            "assumption": f"(n-1)/n of the gathered rows are remote; {n - 1} peers x 153 GB/s per direction, all links concurrently; "
+                          "update lists travel the other way (3 reduced rows per interaction at most, before the per-row reduction)",
+            "measured_here": "no (one physical device: every 'remote' row is local HBM)" if physical < n else "yes",
+        }
+    if crcs:
+        out["param_crc_replicas"] = len(crcs)
+        out["param_crc_replicas_equal"] = all(c == crcs[0] for c in crcs)
+        out["param_crc"] = crcs[0]
+    return out
+
+
 def self_launch(n: int) -> int:
     """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on 127.0.0.1 with a free
     port (the user-sharded step needs one process per GPU, sequence_model.rs:90-102 ≙ DESIGN.md §8).  The ranks inherit stdout,
@@ -494,6 +588,9 @@ def main():
                     help="store the item table once across the ranks (BASELINE configs[4] layout) instead of replicating it")
     ap.add_argument("--param-crc", action="store_true",
                     help="add CRC-32 checksums of the trained parameters to the JSON line (tests compare runs bit for bit)")
+    ap.add_argument("--driver", choices=["ranks", "group"], default="ranks",
+                    help="ranks: one process per GPU over torch.distributed (the launcher contract); group: --gpus N replicas driven "
+                         "from ONE process through sbr_group_fit's step sequence (what INTEGRATION.md's Rust binding calls)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
@@ -503,13 +600,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.simulate_world <= 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.simulate_world <= 1 and args.driver != "group":
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's launcher would
         # (python -m torch.distributed.run, one rank per GPU); rank 0's JSON line stays the last line of stdout
         raise SystemExit(self_launch(args.gpus))
-    if world != args.gpus:
+    if world != args.gpus and args.driver != "group":
         args.gpus = world
-    multi = world > 1 or args.simulate_world > 1
+    multi = world > 1 or args.simulate_world > 1 or (args.driver == "group" and args.gpus > 1)
     if args.users is None:
         args.users = 125_000 if multi else 100_000   # BASELINE.json configs[3] (1M users over 8 GPUs) / configs[2]
     if args.max_len is None:
@@ -560,6 +657,11 @@ def main():
         else:
             args.batch_sequences = MAX_BATCH
             batch_rule = "default: 50 000 (EWMA: test MRR does not fall with the batch, DESIGN.md section 3)" if model_kind == 2 else "default: 50 000"
+    if args.driver == "group":
+        if world != 1:
+            raise SystemExit("--driver group runs in one process (no launcher)")
+        print(json.dumps(group_driver(args, model_kind, loss_kind)), flush=True)
+        return
     if args.simulate_world > 1:
         if world != 1:
             raise SystemExit("--simulate-world runs in one process on one GPU")

@@ -201,6 +201,32 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
                          uint64_t num_users, float* out_loss);
 sbr_status sbr_device_count(int32_t* out_count);
 
+/* sbr_group_fit taken apart, for a host that wants the group's steps one at a time (a progress bar, early stopping, the bench's
+ * `--driver group`, the parity tests): begin -> per epoch [epoch_prepare -> step(0) .. step(n_minibatches - 1)] -> fit_end.
+ * sbr_group_fit IS this sequence over hp.num_epochs epochs.  (≙ the loop of sequence_model.rs:100-171 with num_threads(n).)
+ *   sbr_group_epoch_prepare   every replica's sbr_fit_epoch_prepare (prefetch_next != 0: the next epoch is packed in the background)
+ *   sbr_group_step            one optimiser step of the whole group (Synchronous / partitioned / the staleness-one pipeline);
+ *                             returns when it is QUEUED on the devices' streams (a partitioned step includes its rendezvous)
+ *   sbr_group_step_local      parity access: only the local halves of `minibatch` (forward, scoring, BPTT on every replica); the
+ *                             next sbr_group_step(minibatch) then runs the exchange and the update alone.  Not for Asynchronous.
+ *   sbr_group_member_plan     replica r's plan, borrowed (sbr_fit_debug_fetch, sbr_fit_minibatch_rows, sbr_fit_counters)
+ *   sbr_group_plan_set_host_threads   one host thread per device queues that device's launches (the reference runs one rayon
+ *                             worker per partition, sequence_model.rs:100-102); default: from four devices on.  Same bits.
+ *   sbr_group_plan_stats      host time spent inside sbr_group_step so far, the number of steps, the host threads in use
+ *   sbr_group_fit_end         the loss of sbr_group_fit; destroys the plan.  sbr_group_plan_destroy: abandon a plan. */
+typedef struct sbr_group_plan sbr_group_plan;
+sbr_status sbr_group_fit_begin(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
+                               uint64_t num_users, sbr_group_plan** out);
+sbr_status sbr_group_epoch_prepare(sbr_group_plan* g, uint64_t* out_num_minibatches, int32_t prefetch_next);
+sbr_status sbr_group_step(sbr_group_plan* g, uint64_t minibatch);
+sbr_status sbr_group_step_local(sbr_group_plan* g, uint64_t minibatch);
+sbr_status sbr_group_member_plan(sbr_group_plan* g, uint32_t replica, sbr_fit_plan** out);
+sbr_status sbr_group_synchronize(sbr_group_plan* g);
+sbr_status sbr_group_plan_set_host_threads(sbr_group_plan* g, int32_t enable);
+sbr_status sbr_group_plan_stats(const sbr_group_plan* g, double* out_host_enqueue_ms, uint64_t* out_steps, int32_t* out_host_threads);
+sbr_status sbr_group_fit_end(sbr_group_plan* g, float* out_loss);
+void sbr_group_plan_destroy(sbr_group_plan* g);
+
 /* Builds the n replicas of a single-process group in one call (replica r on HIP device r mod device
  * count; destroy each with sbr_model_destroy).  flags = 0: n full parameter replicas, exactly what n
  * sbr_model_create calls give.  SBR_GROUP_PARTITION_ITEM_TABLE (BASELINE configs[4]): the

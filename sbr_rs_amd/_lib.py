@@ -74,6 +74,15 @@ def load():
         "sbr_set_device": [C.c_int32],
         "sbr_group_fit": [C.POINTER(vp), C.c_uint32, vp, vp, C.c_uint64, fp],
         "sbr_device_count": [C.POINTER(C.c_int32)],
+        "sbr_group_fit_begin": [C.POINTER(vp), C.c_uint32, vp, vp, C.c_uint64, C.POINTER(vp)],
+        "sbr_group_epoch_prepare": [vp, u64p, C.c_int32],
+        "sbr_group_step": [vp, C.c_uint64],
+        "sbr_group_step_local": [vp, C.c_uint64],
+        "sbr_group_member_plan": [vp, C.c_uint32, C.POINTER(vp)],
+        "sbr_group_synchronize": [vp],
+        "sbr_group_plan_set_host_threads": [vp, C.c_int32],
+        "sbr_group_plan_stats": [vp, C.POINTER(C.c_double), u64p, C.POINTER(C.c_int32)],
+        "sbr_group_fit_end": [vp, fp],
         "sbr_group_create": [C.POINTER(SbrHparams), C.c_uint32, C.c_uint32, C.POINTER(vp)],
         "sbr_model_is_partitioned": [vp, C.POINTER(C.c_int32)],
         "sbr_fit_exchange_export": [vp, C.POINTER(C.c_int32), u64p],
@@ -104,6 +113,8 @@ def load():
     L.sbr_model_destroy.restype = None
     L.sbr_fit_plan_destroy.argtypes = [vp]
     L.sbr_fit_plan_destroy.restype = None
+    L.sbr_group_plan_destroy.argtypes = [vp]
+    L.sbr_group_plan_destroy.restype = None
     L.sbr_status_string.argtypes = [C.c_int]
     L.sbr_status_string.restype = C.c_char_p
     L.sbr_abi_version.argtypes = []
@@ -129,4 +140,6 @@ DECLARED_SYMBOLS = [
     "sbr_partition_part_info", "sbr_partition_export_part", "sbr_partition_import_part", "sbr_partition_finalize",
     "sbr_fit_lists_export", "sbr_fit_lists_import", "sbr_fit_step_reduce_own", "sbr_fit_step_owner_apply", "sbr_selftest_math",
     "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort", "sbr_release_cached_memory",
+    "sbr_group_fit_begin", "sbr_group_epoch_prepare", "sbr_group_step", "sbr_group_step_local", "sbr_group_member_plan",
+    "sbr_group_synchronize", "sbr_group_plan_set_host_threads", "sbr_group_plan_stats", "sbr_group_fit_end", "sbr_group_plan_destroy",
 ]

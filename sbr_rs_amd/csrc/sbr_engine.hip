@@ -10,11 +10,14 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -86,7 +89,12 @@ struct ScratchCache {
         }
         const hipError_t e = host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
         if (e != hipSuccess) {
-            if (e == hipErrorOutOfMemory && cached[0] + cached[1]) { /* give the cache back and try once more */
+            bool have_cached;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                have_cached = cached[0] + cached[1] != 0;
+            }
+            if (e == hipErrorOutOfMemory && have_cached) { /* give the cache back and try once more */
                 trim();
                 return host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
             }
@@ -1555,9 +1563,11 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
             /* single device: the hot rows (segments of more than SBR_SEG_CHUNK entries: a skewed catalogue) are listed and their
              * chunk units counted HERE, still underneath BPTT — registering them during the short-segment pass put their three
              * launches behind it on the update's critical path (Zipf(1) items at 8 192 sequences per step: 0.13 of 2.66 ms).
-             * (after ev_sorted: the short-segment pass does not wait for the list)  SBR_NO_HOT_PRELIST=1: the old order. */
-            static const bool no_prelist = std::getenv("SBR_NO_HOT_PRELIST") != nullptr;
-            if (p->ndev == 1 && overlap && !no_prelist && 3ull * (uint64_t)mb.R > 4096) {
+             * (after ev_sorted: the short-segment pass does not wait for the list)
+             * Only under sbr_fit_step (fuse_back): the list's only consumer is sbr_fit_step_apply; a caller that drives ONE device
+             * through the exchange halves (scatter / reduce_own register long segments themselves, on the main stream) must not
+             * find the list kernels running beside them on this stream. */
+            if (p->ndev == 1 && overlap && p->fuse_back && 3ull * (uint64_t)mb.R > 4096) {
                 sbr::launch_seg_prelist(p->seg, on);
                 p->hot_prelisted = true;
             }
@@ -1759,6 +1769,9 @@ sbr_status sbr_fit_step_dense(sbr_fit_plan* p, void* device_dense_out) {
     SBRCHK(ensure_device(m));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     SBRCHK(ensure_dense_reduced(p));
+    /* a WARP step with the ordering on its own stream writes the block header THERE (side_header in sbr_fit_step_local): join
+     * it here rather than rely on the caller having run sbr_fit_step_scatter first */
+    if (p->sorted_event_live && p->sort_off_stream) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0));
     HIPCHK(hipMemcpyAsync(device_dense_out, bv.header, 32, hipMemcpyDeviceToDevice, m->stream));
     HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(device_dense_out) + 32, bv.dense, dense_count(m) * 4,
                           hipMemcpyDeviceToDevice, m->stream));
@@ -2160,78 +2173,139 @@ sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds,
     return SBR_OK;
 }
 
-/* Single-process multi-device fit: the in-process analogue of fit with num_threads(n)
- * (sequence_model.rs:90-102, 163-169).  One host thread drives n replicas, each on its own HIP
- * device and stream; the owner-reduce exchange of sbr_fit_step_scatter / _owner_reduce /
+/* ---- single-process multi-device fit (≙ fit with num_threads(n) on one host, sequence_model.rs:90-102, 163-169) --------
+ * n replicas, each on its own HIP device and stream; the owner-reduce exchange of sbr_fit_step_scatter / _owner_reduce /
  * _apply_table is carried by peer copies (xGMI when the devices are peers) ordered with events:
  *   scattered[r]  send_r of this step is complete
  *   reduced[p]    own_p and dense_p of this step are complete
- *   applied[q]    q has finished reading its peers' buffers and has applied the step          */
-sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
-                         uint64_t num_users, float* out_loss) {
-    if (!models || n == 0) return SBR_ERR_INVALID_ARGUMENT;
-    for (uint32_t r = 0; r < n; ++r) {
-        const sbr_model* m = models[r];
-        if (!m || m->hp.num_devices != n || m->hp.device_rank != r || m->hp.num_epochs != models[0]->hp.num_epochs)
-            return SBR_ERR_INVALID_ARGUMENT;
-    }
-    if (n == 1) return sbr_model_fit(models[0], user_ptr, item_ids, num_users, out_loss);
-    if (n > 16) return SBR_ERR_INVALID_ARGUMENT;
+ *   applied[q]    q has finished reading its peers' buffers and has applied the step
+ * A step is a short list of PHASES; inside a phase device r's work depends on nothing another device queues in the same phase,
+ * so the phases either run as loops of one host thread or — sbr_group_plan_set_host_threads — on one host thread per device
+ * (the reference runs one rayon worker per partition, sequence_model.rs:100-102): a device's ~20 launches per step are then
+ * queued beside the other devices' instead of behind them.  An event is recorded in the phase BEFORE the one that waits for
+ * it, and phases are separated by a host barrier, so hipStreamWaitEvent never sees an event that has not been recorded yet. */
+namespace {
 
+/* n - 1 helper threads (the caller is worker 0).  run(f) = f(r) on every worker, then a barrier.  The helpers spin for the next
+ * phase for a short while (a step's phases follow each other within microseconds) and then sleep on a condition variable. */
+struct PhaseWorkers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<uint32_t> pending{0};
+    std::atomic<bool> quit{false};
+    const std::function<sbr_status(uint32_t)>* job = nullptr;
+    std::vector<sbr_status> status;
+
+    explicit PhaseWorkers(uint32_t n) : status(n, SBR_OK) {
+        for (uint32_t r = 1; r < n; ++r) threads.emplace_back([this, r] { loop(r); });
+    }
+    ~PhaseWorkers() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            quit.store(true, std::memory_order_release);
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void loop(uint32_t r) {
+        uint64_t seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == seen) {
+                if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return generation.load(std::memory_order_acquire) != seen; });
+            }
+            seen = generation.load(std::memory_order_acquire);
+            if (quit.load(std::memory_order_acquire)) return;
+            status[r] = (*job)(r);
+            pending.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    sbr_status run(const std::function<sbr_status(uint32_t)>& f) {
+        const uint32_t n = (uint32_t)status.size();
+        job = &f;
+        pending.store(n - 1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> g(mu); /* a helper between its last spin and its wait must not miss the new generation */
+            generation.fetch_add(1, std::memory_order_release);
+        }
+        cv.notify_all();
+        status[0] = f(0);
+        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        for (uint32_t r = 0; r < n; ++r)
+            if (status[r] != SBR_OK) return status[r];
+        return SBR_OK;
+    }
+};
+
+}  // namespace
+
+struct sbr_group_plan {
     struct Dev {
         sbr_fit_plan* plan = nullptr;
         uint8_t *send = nullptr, *dense = nullptr, *recv = nullptr, *own = nullptr, *table = nullptr, *dense_all = nullptr;
         hipEvent_t scattered = nullptr, reduced = nullptr, applied = nullptr, gathered = nullptr;
         hipStream_t xs = nullptr; /* exchange stream (Asynchronous) */
     };
-    const bool partitioned = models[0]->shared != nullptr;
-    /* a partitioned table is updated in place by its owners after a rendezvous, so there is no staleness-one pipeline for
-     * it: Parallelism::Asynchronous runs the synchronous step there (same everywhere a partitioned table is driven) */
-    const bool async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS && !partitioned;
-    for (uint32_t r = 0; r < n; ++r)
-        if (models[r]->shared != models[0]->shared) return SBR_ERR_INVALID_ARGUMENT;
-    std::vector<Dev> dev(n);
+    std::vector<sbr_model*> models;
+    std::vector<Dev> dev;
+    uint32_t n = 0;
     uint64_t chunk = 0, db = 0;
-    auto cleanup = [&]() {
-        for (uint32_t r = 0; r < n; ++r) {
-            hipSetDevice(models[r]->device);
-            hipStreamSynchronize(models[r]->stream);
-        }
-        for (uint32_t r = 0; r < n; ++r) {
-            Dev& v = dev[r];
-            hipSetDevice(models[r]->device);
-            dfree(v.send); dfree(v.dense); dfree(v.recv); dfree(v.own); dfree(v.table); dfree(v.dense_all);
-            if (v.scattered) hipEventDestroy(v.scattered);
-            if (v.reduced) hipEventDestroy(v.reduced);
-            if (v.applied) hipEventDestroy(v.applied);
-            if (v.gathered) hipEventDestroy(v.gathered);
-            if (v.xs) { hipStreamSynchronize(v.xs); hipStreamDestroy(v.xs); }
-            if (v.plan) sbr_fit_plan_destroy(v.plan);
-        }
-    };
-    bool first = true;
+    bool partitioned = false, async = false;
+    bool first = true;               /* no step has been applied yet: nothing to wait for */
+    uint64_t nmb = 0;                /* minibatches of the prepared epoch */
+    uint32_t epochs_prepared = 0;
+    int64_t local_done = -1;         /* minibatch whose local half sbr_group_step_local has queued (parity access), or -1 */
+    int64_t async_local_done = -1;   /* Asynchronous: minibatch whose local half the pipeline has queued ahead */
+    std::vector<uint32_t> hbounds;
+    std::unique_ptr<PhaseWorkers> workers;
+    double enqueue_ms = 0.0;         /* host time spent inside sbr_group_step (queueing; a partitioned step includes its rendezvous) */
+    uint64_t steps = 0;
+
+    sbr_status phase(const std::function<sbr_status(uint32_t)>& f) {
+        if (workers) return workers->run(f);
+        for (uint32_t r = 0; r < n; ++r) SBRCHK(f(r));
+        return SBR_OK;
+    }
+    sbr_status wait_applied(uint32_t r, hipStream_t s) { /* peers must be done with the previous step's buffers / table rows */
+        if (first) return SBR_OK;
+        for (uint32_t q = 0; q < n; ++q)
+            if (q != r) HIPCHK(hipStreamWaitEvent(s, dev[q].applied, 0));
+        return SBR_OK;
+    }
+    /* local half of minibatch mb on device r (a partitioned table must not still be written by the previous step's owners) */
+    sbr_status local(uint32_t r, uint64_t mb) {
+        SBRCHK(ensure_device(models[r]));
+        if (partitioned) SBRCHK(wait_applied(r, models[r]->stream));
+        return sbr_fit_step_local(dev[r].plan, mb);
+    }
     /* Parallelism::Synchronous: compute, exchange, apply — every device sees every update before its next minibatch */
-    auto sync_step = [&](uint64_t mb) -> sbr_status {
-        for (uint32_t r = 0; r < n; ++r) {
-            SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
-            if (!first) /* peers must be done reading send_r / dense_r / own_r of the previous step */
-                for (uint32_t q = 0; q < n; ++q)
-                    if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
+    sbr_status sync_step(uint64_t mb) {
+        const bool have_local = local_done == (int64_t)mb;
+        SBRCHK(phase([&](uint32_t r) -> sbr_status {
+            if (!have_local) SBRCHK(local(r, mb));
+            SBRCHK(ensure_device(models[r]));
+            SBRCHK(wait_applied(r, models[r]->stream));
             SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
             HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
-        }
-        for (uint32_t p = 0; p < n; ++p) { /* all-to-all: chunk p of every device -> device p */
+            return SBR_OK;
+        }));
+        SBRCHK(phase([&](uint32_t p) -> sbr_status { /* all-to-all: chunk p of every device -> device p */
             SBRCHK(ensure_device(models[p]));
             for (uint32_t r = 0; r < n; ++r) {
                 if (r != p) HIPCHK(hipStreamWaitEvent(models[p]->stream, dev[r].scattered, 0));
-                HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault,
-                                      models[p]->stream));
+                HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault, models[p]->stream));
             }
             SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
             SBRCHK(sbr_fit_step_dense(dev[p].plan, dev[p].dense));
             HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
-        }
-        for (uint32_t q = 0; q < n; ++q) { /* all-gather of the owners' chunks and of the dense blocks */
+            return SBR_OK;
+        }));
+        SBRCHK(phase([&](uint32_t q) -> sbr_status { /* all-gather of the owners' chunks and of the dense blocks */
             SBRCHK(ensure_device(models[q]));
             for (uint32_t p = 0; p < n; ++p) {
                 if (p != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[p].reduced, 0));
@@ -2240,31 +2314,27 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             }
             SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
             HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
-        }
+            return SBR_OK;
+        }));
         first = false;
         return SBR_OK;
-    };
-    /* Partitioned item table: every row is stored once (on its owner) and read by everybody through the
-     * shared mapping.  A step: all devices compute on the current table; each reduces its own entries into
-     * a list; after a host-side rendezvous (the owners need the list bounds to size their merge) every
-     * owner merges the peers' lists over its rows in device order and updates them in place.  Bitwise the
-     * same result as the replicated Synchronous exchange. */
-    std::vector<uint32_t> hbounds((size_t)n * (n + 1));
-    auto partitioned_step = [&](uint64_t mb) -> sbr_status {
-        for (uint32_t r = 0; r < n; ++r) {
-            if (!first) /* no owner may still be writing rows of the previous step */
-                for (uint32_t q = 0; q < n; ++q)
-                    if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
-            SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
+    }
+    /* Partitioned item table: every row is stored once (on its owner) and read by everybody through the shared mapping.  A step:
+     * all devices compute on the current table; each reduces its own entries into a list; after a host-side rendezvous (the
+     * owners need the list bounds to size their merge, and nobody may still be READING the table) every owner merges the peers'
+     * lists over its rows in device order and updates them in place.  Bitwise the replicated Synchronous exchange. */
+    sbr_status partitioned_step(uint64_t mb) {
+        const bool have_local = local_done == (int64_t)mb;
+        SBRCHK(phase([&](uint32_t r) -> sbr_status {
+            if (!have_local) SBRCHK(local(r, mb));
+            SBRCHK(ensure_device(models[r]));
             SBRCHK(partition_reduce_own(dev[r].plan, mb));
             SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
-        }
-        for (uint32_t r = 0; r < n; ++r) { /* rendezvous: every device has finished READING the table */
-            SBRCHK(ensure_device(models[r]));
             HIPCHK(hipStreamSynchronize(models[r]->stream));
             HIPCHK(hipMemcpy(&hbounds[(size_t)r * (n + 1)], dev[r].plan->bounds_dev, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
-        for (uint32_t q = 0; q < n; ++q) {
+            return SBR_OK;
+        }));
+        SBRCHK(phase([&](uint32_t q) -> sbr_status {
             SBRCHK(ensure_device(models[q]));
             sbr::PeerLists pl;
             std::memset(&pl, 0, sizeof(pl));
@@ -2282,57 +2352,65 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             SBRCHK(apply_dense_blocks(dev[q].plan, dev[q].dense_all));
             SBRCHK(partition_owner_apply(dev[q].plan, pl, total));
             HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
-        }
+            return SBR_OK;
+        }));
         first = false;
         return SBR_OK;
-    };
-    /* Parallelism::Asynchronous (mod.rs:36-38), the deterministic analogue of Hogwild: staleness is
-     * fixed at one step.  Device r computes minibatch mb+1 on its compute stream while the exchange of
-     * step mb (peer copies + owner reduce) runs on its exchange stream; update mb is applied after
-     * that computation has read the parameters. */
-    auto async_epoch = [&](uint64_t nmb) -> sbr_status {
-        for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_step_local(dev[r].plan, 0));
-        for (uint64_t mb = 0; mb < nmb; ++mb) {
-            for (uint32_t r = 0; r < n; ++r) {
-                if (!first)
-                    for (uint32_t q = 0; q < n; ++q)
-                        if (q != r) HIPCHK(hipStreamWaitEvent(models[r]->stream, dev[q].applied, 0));
-                SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
-                SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
-                HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
-            }
-            if (mb + 1 < nmb)
-                for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_step_local(dev[r].plan, mb + 1));
-            for (uint32_t p = 0; p < n; ++p) {
-                SBRCHK(ensure_device(models[p]));
-                for (uint32_t r = 0; r < n; ++r) {
-                    HIPCHK(hipStreamWaitEvent(dev[p].xs, dev[r].scattered, 0));
-                    HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault, dev[p].xs));
-                }
-                hipStream_t compute = models[p]->stream;
-                models[p]->stream = dev[p].xs; /* the owner reduce belongs to the exchange stream */
-                const sbr_status st = sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own);
-                models[p]->stream = compute;
-                SBRCHK(st);
-                HIPCHK(hipEventRecord(dev[p].reduced, dev[p].xs));
-            }
-            for (uint32_t q = 0; q < n; ++q) {
-                SBRCHK(ensure_device(models[q]));
-                for (uint32_t p = 0; p < n; ++p) {
-                    if (p != q) HIPCHK(hipStreamWaitEvent(dev[q].xs, dev[p].reduced, 0));
-                    HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, dev[q].xs));
-                    HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, dev[q].xs));
-                }
-                HIPCHK(hipEventRecord(dev[q].gathered, dev[q].xs));
-                HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[q].gathered, 0));
-                SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
-                HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
-            }
-            first = false;
+    }
+    /* Parallelism::Asynchronous (mod.rs:36-38), the deterministic analogue of Hogwild: staleness is fixed at one step.  Device
+     * r computes minibatch mb + 1 on its compute stream while the exchange of step mb (peer copies + owner reduce) runs on its
+     * exchange stream; update mb is applied after that computation has read the parameters. */
+    sbr_status async_step(uint64_t mb) {
+        if (async_local_done < (int64_t)mb) {
+            SBRCHK(phase([&](uint32_t r) -> sbr_status { return local(r, mb); }));
+            async_local_done = (int64_t)mb;
         }
+        const bool ahead = mb + 1 < nmb;
+        SBRCHK(phase([&](uint32_t r) -> sbr_status {
+            SBRCHK(ensure_device(models[r]));
+            SBRCHK(wait_applied(r, models[r]->stream));
+            SBRCHK(sbr_fit_step_scatter(dev[r].plan, mb, dev[r].send));
+            SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
+            HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
+            if (ahead) SBRCHK(sbr_fit_step_local(dev[r].plan, mb + 1));
+            return SBR_OK;
+        }));
+        if (ahead) async_local_done = (int64_t)mb + 1;
+        SBRCHK(phase([&](uint32_t p) -> sbr_status {
+            SBRCHK(ensure_device(models[p]));
+            for (uint32_t r = 0; r < n; ++r) {
+                HIPCHK(hipStreamWaitEvent(dev[p].xs, dev[r].scattered, 0));
+                HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault, dev[p].xs));
+            }
+            SBRCHK(sbr_fit_step_owner_reduce_on(dev[p].plan, dev[p].recv, dev[p].own, dev[p].xs)); /* belongs to the exchange stream */
+            HIPCHK(hipEventRecord(dev[p].reduced, dev[p].xs));
+            return SBR_OK;
+        }));
+        SBRCHK(phase([&](uint32_t q) -> sbr_status {
+            SBRCHK(ensure_device(models[q]));
+            for (uint32_t p = 0; p < n; ++p) {
+                if (p != q) HIPCHK(hipStreamWaitEvent(dev[q].xs, dev[p].reduced, 0));
+                HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, dev[q].xs));
+                HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, dev[q].xs));
+            }
+            HIPCHK(hipEventRecord(dev[q].gathered, dev[q].xs));
+            HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[q].gathered, 0));
+            SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+            HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+            return SBR_OK;
+        }));
+        first = false;
         return SBR_OK;
-    };
-    auto run = [&]() -> sbr_status {
+    }
+    sbr_status begin(sbr_model* const* ms, uint32_t count, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users) {
+        n = count;
+        models.assign(ms, ms + count);
+        dev.resize(n);
+        hbounds.assign((size_t)n * (n + 1), 0);
+        partitioned = models[0]->shared != nullptr;
+        /* a partitioned table is updated in place by its owners after a rendezvous, so there is no staleness-one pipeline for
+         * it: Parallelism::Asynchronous runs the synchronous step there (same everywhere a partitioned table is driven) */
+        async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS && !partitioned;
         for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_begin(models[r], user_ptr, item_ids, num_users, &dev[r].plan));
         SBRCHK(sbr_fit_chunk_bytes(dev[0].plan, &chunk));
         SBRCHK(sbr_fit_dense_bytes(dev[0].plan, &db));
@@ -2357,36 +2435,164 @@ sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* u
             HIPCHK(hipEventCreateWithFlags(&v.gathered, hipEventDisableTiming));
             if (async) HIPCHK(hipStreamCreateWithFlags(&v.xs, hipStreamNonBlocking));
         }
-        const uint32_t epochs = models[0]->hp.num_epochs;
-        for (uint32_t e = 0; e < epochs; ++e) {
-            uint64_t nmb = 0;
-            for (uint32_t r = 0; r < n; ++r) {
-                uint64_t k = 0;
-                SBRCHK(sbr_fit_epoch_prepare(dev[r].plan, &k));
-                if (r && k != nmb) return SBR_ERR_INVALID_ARGUMENT;
-                nmb = k;
-                if (e + 1 < epochs) SBRCHK(sbr_fit_epoch_prefetch(dev[r].plan));
-            }
-            if (partitioned)
-                for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(partitioned_step(mb));
-            else if (async) SBRCHK(async_epoch(nmb));
-            else
-                for (uint64_t mb = 0; mb < nmb; ++mb) SBRCHK(sync_step(mb));
+        return SBR_OK;
+    }
+    sbr_status epoch_prepare(uint64_t* out_nmb, bool prefetch_next) {
+        uint64_t k0 = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            uint64_t k = 0;
+            SBRCHK(sbr_fit_epoch_prepare(dev[r].plan, &k));
+            if (r && k != k0) return SBR_ERR_INVALID_ARGUMENT;
+            k0 = k;
+            if (prefetch_next) SBRCHK(sbr_fit_epoch_prefetch(dev[r].plan));
         }
-        for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(dev[r].plan, nullptr, nullptr));
+        nmb = k0;
+        local_done = async_local_done = -1;
+        ++epochs_prepared;
+        if (out_nmb) *out_nmb = k0;
+        return SBR_OK;
+    }
+    sbr_status step(uint64_t mb) {
+        if (mb >= nmb) return SBR_ERR_INVALID_ARGUMENT;
+        const auto t0 = std::chrono::steady_clock::now();
+        const sbr_status st = partitioned ? partitioned_step(mb) : async ? async_step(mb) : sync_step(mb);
+        local_done = -1;
+        enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++steps;
+        return st;
+    }
+    /* every stream of the group drained (also on an error path: a peer copy still in flight must not find its buffers recycled) */
+    void drain() {
+        for (uint32_t r = 0; r < n; ++r) {
+            hipSetDevice(models[r]->device);
+            hipStreamSynchronize(models[r]->stream);
+            if (models[r]->side) hipStreamSynchronize(models[r]->side);
+            if (models[r]->sorter) hipStreamSynchronize(models[r]->sorter);
+            if (dev[r].xs) hipStreamSynchronize(dev[r].xs);
+        }
+    }
+    ~sbr_group_plan() {
+        workers.reset();
+        drain();
+        for (uint32_t r = 0; r < n; ++r) {
+            Dev& v = dev[r];
+            hipSetDevice(models[r]->device);
+            dfree(v.send); dfree(v.dense); dfree(v.recv); dfree(v.own); dfree(v.table); dfree(v.dense_all);
+            if (v.scattered) hipEventDestroy(v.scattered);
+            if (v.reduced) hipEventDestroy(v.reduced);
+            if (v.applied) hipEventDestroy(v.applied);
+            if (v.gathered) hipEventDestroy(v.gathered);
+            if (v.xs) hipStreamDestroy(v.xs);
+            if (v.plan) sbr_fit_plan_destroy(v.plan);
+        }
+    }
+};
+
+sbr_status sbr_group_fit_begin(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
+                               uint64_t num_users, sbr_group_plan** out) {
+    if (!models || !out || n == 0 || n > 16) return SBR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    for (uint32_t r = 0; r < n; ++r) {
+        const sbr_model* m = models[r];
+        if (!m || m->hp.num_devices != n || m->hp.device_rank != r || m->hp.num_epochs != models[0]->hp.num_epochs ||
+            m->shared != models[0]->shared)
+            return SBR_ERR_INVALID_ARGUMENT;
+    }
+    sbr_group_plan* g = new (std::nothrow) sbr_group_plan;
+    if (!g) return SBR_ERR_OUT_OF_MEMORY;
+    const sbr_status st = g->begin(models, n, user_ptr, item_ids, num_users);
+    if (st != SBR_OK) { delete g; return st; }
+    /* default: one host thread per device from four devices on (measured: profiles/r05_group_driver.jsonl) */
+    if (n >= 4) g->workers.reset(new PhaseWorkers(n));
+    *out = g;
+    return SBR_OK;
+}
+
+sbr_status sbr_group_plan_set_host_threads(sbr_group_plan* g, int32_t enable) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    if (enable && !g->workers && g->n > 1) g->workers.reset(new PhaseWorkers(g->n));
+    if (!enable) g->workers.reset();
+    return SBR_OK;
+}
+
+sbr_status sbr_group_epoch_prepare(sbr_group_plan* g, uint64_t* out_num_minibatches, int32_t prefetch_next) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    return g->epoch_prepare(out_num_minibatches, prefetch_next != 0);
+}
+
+sbr_status sbr_group_step(sbr_group_plan* g, uint64_t minibatch) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    return g->step(minibatch);
+}
+
+sbr_status sbr_group_step_local(sbr_group_plan* g, uint64_t minibatch) {
+    if (!g || minibatch >= g->nmb || g->async) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(g->phase([&](uint32_t r) -> sbr_status { return g->local(r, minibatch); }));
+    g->local_done = (int64_t)minibatch;
+    return SBR_OK;
+}
+
+sbr_status sbr_group_member_plan(sbr_group_plan* g, uint32_t replica, sbr_fit_plan** out) {
+    if (!g || !out || replica >= g->n) return SBR_ERR_INVALID_ARGUMENT;
+    *out = g->dev[replica].plan;
+    return SBR_OK;
+}
+
+sbr_status sbr_group_synchronize(sbr_group_plan* g) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    g->drain();
+    return hipGetLastError() == hipSuccess ? SBR_OK : SBR_ERR_HIP;
+}
+
+sbr_status sbr_group_plan_stats(const sbr_group_plan* g, double* out_host_enqueue_ms, uint64_t* out_steps, int32_t* out_host_threads) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    if (out_host_enqueue_ms) *out_host_enqueue_ms = g->enqueue_ms;
+    if (out_steps) *out_steps = g->steps;
+    if (out_host_threads) *out_host_threads = g->workers ? (int32_t)g->n : 1;
+    return SBR_OK;
+}
+
+sbr_status sbr_group_fit_end(sbr_group_plan* g, float* out_loss) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    auto finish = [&]() -> sbr_status {
+        const uint32_t n = g->n;
+        for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(g->dev[r].plan, nullptr, nullptr));
         float lagged = 0.0f; /* the workers' terms added in worker order, f32 (sequence_model.rs:173-177) */
         for (uint32_t r = 0; r < n; ++r) {
             float term = 0.0f;
-            SBRCHK(sbr_fit_end_lagged(dev[r].plan, &term));
+            SBRCHK(sbr_fit_end_lagged(g->dev[r].plan, &term));
             lagged = lagged + term;
         }
-        for (uint32_t r = 0; r < n; ++r) models[r]->last_lagged_loss = lagged;
-        return sbr_fit_end(dev[0].plan, out_loss, nullptr);
+        for (uint32_t r = 0; r < n; ++r) g->models[r]->last_lagged_loss = lagged;
+        return sbr_fit_end(g->dev[0].plan, out_loss, nullptr);
     };
-    const sbr_status st = run();
-    cleanup();
+    const sbr_status st = finish();
+    delete g;
     return st;
 }
+
+void sbr_group_plan_destroy(sbr_group_plan* g) { delete g; }
+
+sbr_status sbr_group_fit(sbr_model* const* models, uint32_t n, const uint64_t* user_ptr, const uint32_t* item_ids,
+                         uint64_t num_users, float* out_loss) {
+    if (!models || n == 0) return SBR_ERR_INVALID_ARGUMENT;
+    if (n == 1) {
+        if (!models[0] || models[0]->hp.num_devices != 1 || models[0]->hp.device_rank != 0) return SBR_ERR_INVALID_ARGUMENT;
+        return sbr_model_fit(models[0], user_ptr, item_ids, num_users, out_loss);
+    }
+    sbr_group_plan* g = nullptr;
+    SBRCHK(sbr_group_fit_begin(models, n, user_ptr, item_ids, num_users, &g));
+    const uint32_t epochs = models[0]->hp.num_epochs;
+    sbr_status st = SBR_OK;
+    for (uint32_t e = 0; e < epochs && st == SBR_OK; ++e) {
+        uint64_t nmb = 0;
+        st = sbr_group_epoch_prepare(g, &nmb, e + 1 < epochs);
+        for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) st = sbr_group_step(g, mb);
+    }
+    if (st != SBR_OK) { sbr_group_plan_destroy(g); return st; }
+    return sbr_group_fit_end(g, out_loss);
+}
+
 
 /* n replicas of one model (num_devices = n, device_rank = r, replica r on HIP device r mod device count).
  * SBR_GROUP_PARTITION_ITEM_TABLE: instead of n full copies, the item table (embeddings, biases and their

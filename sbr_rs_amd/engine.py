@@ -76,6 +76,72 @@ def group_fit(models, user_ptr, item_ids) -> float:
     return loss.value
 
 
+class GroupPlan:
+    """sbr_group_fit taken apart (sbr_group_fit_begin .. sbr_group_fit_end): the single-process group's steps one at a time —
+    the bench's ``--driver group`` and the parity tests of the multi-device step.  ``host_threads``: None = the library's
+    default (one host thread per device from four devices on), True / False = force."""
+
+    def __init__(self, models, user_ptr, item_ids, host_threads=None):
+        self.models = list(models)
+        self._L = _lib.load()
+        self._up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        self._it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        handles = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        h = C.c_void_p()
+        _check(self._L.sbr_group_fit_begin(handles, len(self.models), _ptr(self._up), _ptr(self._it), len(self._up) - 1, C.byref(h)))
+        self._h = h
+        if host_threads is not None:
+            _check(self._L.sbr_group_plan_set_host_threads(self._h, 1 if host_threads else 0))
+        self._members = {}
+
+    def epoch_prepare(self, prefetch_next: bool = False) -> int:
+        n = C.c_uint64()
+        _check(self._L.sbr_group_epoch_prepare(self._h, C.byref(n), 1 if prefetch_next else 0))
+        return n.value
+
+    def step(self, mb: int):
+        _check(self._L.sbr_group_step(self._h, mb))
+
+    def step_local(self, mb: int):
+        _check(self._L.sbr_group_step_local(self._h, mb))
+
+    def member(self, r: int) -> "FitPlan":
+        """Replica r's plan, borrowed from the group (debug_fetch, minibatch_rows, counters)."""
+        if r not in self._members:
+            h = C.c_void_p()
+            _check(self._L.sbr_group_member_plan(self._h, r, C.byref(h)))
+            self._members[r] = FitPlan._borrowed(self.models[r], h)
+        return self._members[r]
+
+    def synchronize(self):
+        _check(self._L.sbr_group_synchronize(self._h))
+
+    def stats(self):
+        """(host ms spent queueing steps, steps, host threads in use)."""
+        ms, n, th = C.c_double(), C.c_uint64(), C.c_int32()
+        _check(self._L.sbr_group_plan_stats(self._h, C.byref(ms), C.byref(n), C.byref(th)))
+        return ms.value, n.value, th.value
+
+    def end(self) -> float:
+        loss = C.c_float()
+        h, self._h = self._h, None
+        self._members = {}
+        _check(self._L.sbr_group_fit_end(h, C.byref(loss)))
+        return loss.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._members = {}
+            self._L.sbr_group_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _DBG_U32 = {1, 7, 8, 9}
 
 
@@ -88,6 +154,12 @@ class FitPlan:
         h = C.c_void_p()
         _check(self._L.sbr_fit_begin(model._h, _ptr(self._up), _ptr(self._it), len(self._up) - 1, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def _borrowed(cls, model: "Model", handle) -> "FitPlan":
+        p = cls.__new__(cls)
+        p.model, p._L, p._h, p._owned = model, _lib.load(), handle, False
+        return p
 
     def epoch_prepare(self) -> int:
         n = C.c_uint64()
@@ -184,7 +256,8 @@ class FitPlan:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.sbr_fit_plan_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._L.sbr_fit_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -220,6 +293,18 @@ class Model:
         v = C.c_int32()
         _check(self._L.sbr_model_is_partitioned(self._h, C.byref(v)))
         return bool(v.value)
+
+    def partition_parts(self):
+        """[(home rank, bytes)] of the partitioned table's parts — runs of pages with one home, in address order over the arrays
+        E, E_acc, (E_m), b, b_acc, (b_m) (sbr_partition_part_info)."""
+        n = C.c_uint32()
+        _check(self._L.sbr_partition_num_parts(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            home, nbytes = C.c_uint32(), C.c_uint64()
+            _check(self._L.sbr_partition_part_info(self._h, i, C.byref(home), C.byref(nbytes)))
+            out.append((home.value, nbytes.value))
+        return out
 
     def dense_count(self) -> int:
         d = self.storage_dim

@@ -137,7 +137,20 @@ def check_first_step(full, o, po, *, lstm: bool, nb: int, nsel=64, nrows=256, nd
     return {"rows": int(R), "sampled_sequences": int(sel.size), "sampled_rows": int(n), "sampled_items": int(items.size), "max_entries_per_item": int(max_entries)}
 
 
-def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=160, seed=0):
+def nearest_touched(sorted_touched, boundaries):
+    """For every row index B in `boundaries`: the nearest touched row below B and the nearest at or above it (a touched row
+    on either side of every ownership change of a partitioned table)."""
+    out = []
+    for B in boundaries:
+        i = int(np.searchsorted(sorted_touched, B, side="left"))
+        if i > 0:
+            out.append(int(sorted_touched[i - 1]))
+        if i < sorted_touched.size:
+            out.append(int(sorted_touched[i]))
+    return np.unique(np.array(out, dtype=np.int64))
+
+
+def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=160, seed=0, boundaries=()):
     """The multi-device step (user-sharded data parallelism) at a size the oracle cannot run whole.
     `full`: adapter of the side that runs `world` devices' first step — .world, .rows(q), .step_local_all(), .fetch(q, which),
     .apply_all(), .model(q).  `o`, `po`: an oracle model with num_devices = world and its plan, epoch prepared, not stepped.
@@ -147,7 +160,10 @@ def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=1
          in device order (the first toucher initialises), ONE optimiser update (oracle.row_apply) — against the row on the first
          and on the last replica after the step;
       3. (LSTM) the devices' dense-gradient blocks added in device order, the oracle's dense update of that sum — against the dense
-         parameters of the first and the last replica."""
+         parameters of the first and the last replica.
+    `boundaries` (a partitioned item table, BASELINE configs[4]): row indices at which the owner of a row changes — logical slice
+    starts and the physical page runs' first rows; the nearest touched row on each side of every one of them, the last touched rows
+    of the table (the uneven last slice) and a sample of rows that several devices touch join the sampled rows."""
     from oracle.oracle import row_reduce
 
     rs = np.random.RandomState(seed)
@@ -177,6 +193,18 @@ def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=1
         q = int(rs.randint(world))
         rr = rs.choice(per[q]["all"].size // 3, size=nrows // 3, replace=False)
         picks.append(per[q]["all"][3 * rr + k])
+    near = np.zeros(0, dtype=np.int64)
+    if len(boundaries):  # a partitioned table: touched rows on both sides of every ownership change, and the last rows of the table
+        touched = np.unique(np.concatenate([P["sorted"] for P in per]))
+        near = nearest_touched(touched, list(boundaries))
+        picks.append(near.astype(picks[0].dtype))
+        picks.append(touched[-2:].astype(picks[0].dtype))
+        several = None  # rows that more than one device touches: the device-ordered merge at the owner
+        for q in range(1, world):
+            both = np.intersect1d(per[0]["sorted"], per[q]["sorted"])
+            several = both if several is None else np.union1d(several, both)
+        if several is not None and several.size:
+            picks.append(several[rs.choice(several.size, size=min(32, several.size), replace=False)].astype(picks[0].dtype))
     items = np.unique(np.concatenate(picks)).astype(np.uint32)
     params = (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC)
     before = {p: g0.get_param_rows(p, items) for p in params}
@@ -220,4 +248,4 @@ def check_first_step_multi(full, o, po, *, lstm: bool, nb: int, nsel=24, nrows=1
             for p in (Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC):
                 _same(full.model(q).get_param(p), o.get_param(p), f"{p.name} on replica {q} after the step")
     return {"world": world, "sampled_items": int(items.size), "items_touched_by_several_devices": int(np.sum(touched_by > 1)),
-            "rows_per_device": [int(full.rows(q)) for q in range(world)]}
+            "rows_per_device": [int(full.rows(q)) for q in range(world)], "boundary_items": [int(x) for x in near]}

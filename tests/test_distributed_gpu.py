@@ -169,3 +169,22 @@ def test_bench_gpus_2_self_launched():
     assert len(line["ms_per_step_per_rank"]) == 2
     assert line["param_crc_ranks"] == 2 and line["param_crc_ranks_equal"] is True
     assert line["steps"] == 2 and line["interactions_timed"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--partition-table", "--model", "ewma", "--loss", "hinge"]])
+def test_bench_group_driver_two_replicas(extra):
+    """`bench.py --driver group --gpus 2`: two replicas driven from one process through sbr_group_fit's step sequence (the path
+    INTEGRATION.md binds; sequence_model.rs:90-102 inside one process), sharing cuda:0 here.  One JSON line with the driver's
+    fields, host enqueue time per step for both host-thread modes, and equal parameter CRCs on both replicas."""
+    env_drop = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_drop if k in os.environ}
+    try:
+        line = _bench(["--driver", "group", "--gpus", "2"] + extra)
+    finally:
+        os.environ.update(saved)
+    assert line["driver"] == "group" and line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["param_crc_replicas"] == 2 and line["param_crc_replicas_equal"] is True
+    assert line["host_enqueue_ms_per_step"] > 0 and set(line["modes"]) == {"library_default", "one_host_thread", "host_thread_per_device"}
+    assert line["modes"]["host_thread_per_device"]["host_threads"] == 2 and line["modes"]["one_host_thread"]["host_threads"] == 1
+    assert line["value"] > 0 and line["modes"]["library_default"]["interactions_timed"] > 0

@@ -332,6 +332,38 @@ def test_partitioned_item_table_group_fit(kind, loss, d, world, opt):
         assert np.array_equal(rg, ro) and mg == mo
 
 
+@pytest.mark.parametrize("threads", [True, False])
+@pytest.mark.parametrize("kind,loss,d,world,par,partition", [
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 3, PAR_SYNC, False),
+    (ModelKind.EWMA, LOSS_HINGE, 64, 3, PAR_ASYNC, False),     # the staleness-one pipeline, phase by phase
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 5, PAR_SYNC, True),  # owner-computes over a partitioned table
+])
+def test_group_plan_steps_with_and_without_host_threads(kind, loss, d, world, par, partition, threads):
+    """sbr_group_fit taken apart (sbr_group_fit_begin / _epoch_prepare / _step / _fit_end), with one host thread per device
+    queueing that device's launches (≙ one rayon worker per partition, sequence_model.rs:100-102) and with one thread for all:
+    both must equal the oracle with num_devices = world bit for bit on every replica — the phases' host barriers order every
+    event record before the waits on it."""
+    from sbr_rs_amd.engine import GroupPlan, group_create
+
+    items, T, B, epochs = 211, 12, 5, 3
+    ptr, it = synthetic_interactions(130, items, T + 5, seed=37, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, epochs=epochs, B=B, ndev=world, par=par)
+    models = group_create(hp, world, partition_item_table=partition)
+    o = OracleModel(hp)
+    gp = GroupPlan(models, ptr, it, host_threads=threads)
+    for e in range(epochs):
+        for mb in range(gp.epoch_prepare(prefetch_next=e + 1 < epochs)):
+            gp.step(mb)
+    ms, steps, nthreads = gp.stats()
+    assert steps > 0 and ms > 0 and nthreads == (world if threads else 1)
+    lg = gp.end()
+    lo = o.fit(ptr, it)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    for q in range(world):
+        assert_params_equal(models[q], o, kind, f"group plan (host threads {threads}) replica {q} of {world}")
+        assert_lagged_equal(models[q], o, f"group plan replica {q}")
+
+
 def test_group_create_replicated_matches_individual_models():
     from sbr_rs_amd.engine import group_create, group_fit
 
@@ -1154,6 +1186,72 @@ def test_bench_regime_multi_device_first_step_sampled_parity():
     assert out["items_touched_by_several_devices"] > 50 and min(out["rows_per_device"]) > 400_000, out
     for p in plans:
         p.close()
+    po.close()
+
+
+@pytest.mark.parametrize("name,kind,loss,d,items,T", [
+    # BASELINE configs[4] through its OWN split: 1e6 users over 8 devices, 1e7 items x 256 partitioned over 8 owners
+    # (1 250 000 rows = 1.28 GB of embeddings per owner), EWMA + hinge
+    ("configs4_ewma256_10M_items", ModelKind.EWMA, LOSS_HINGE, 256, 10_000_000, 64),
+    # the LSTM + WARP workload of configs[2]/[3] over a partitioned table: 1e6 items x 128 over 8 owners
+    ("lstm_warp_d128_1M_items", ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 1_000_000, 64),
+])
+def test_bench_regime_partitioned_first_step_sampled_parity(name, kind, loss, d, items, T):
+    """The item-table-partitioned step (sbr_group_create(..., SBR_GROUP_PARTITION_ITEM_TABLE): rows [r*S, (r+1)*S) on replica
+    r's device, one virtual range mapped into all eight replicas; every replica reduces its own entries per row into a list
+    (sparse_reduce_list_kernel), the owners' bounds (owner_bounds_kernel) meet at the host rendezvous, every owner merges the
+    eight lists over its rows in device order and updates them in place (owner_list_apply_kernel)) AT SIZE: eight replicas in one
+    process on one GPU, 8 x 125 000 users, 8 192 sequences per replica and step.  The first optimiser step is compared with the
+    oracle's replicated num_devices = 8 step by sampling (tests/sampled_parity.py::check_first_step_multi): every replica's
+    half-step on a sample of its sequences (read through the shared mapping), ~250 item rows' device-ordered gradient sums and
+    ONE update — among them the nearest touched row on each side of every ownership change (the seven logical slice starts and
+    every physical page run's first row), the last touched rows of the uneven last slice and rows that several devices touch —
+    read back from replica 0 and replica 7, and (LSTM) the dense parameters.
+    ≙ /root/reference/src/models/ewma.rs:266-352, sequence_model.rs:163-169 over shared HogwildParameter rows (ewma.rs:167-198)."""
+    import bench
+    from sampled_parity import check_first_step_multi, count_subsequences
+    from sbr_rs_amd.engine import GroupPlan, group_create
+
+    world, users, B = 8, 125_000, 8_192
+    ptr, it = bench.synthetic_csr(users * world, items, T)
+    hp = hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world)
+    models = group_create(hp, world, partition_item_table=True)
+    assert all(m.is_partitioned() for m in models)
+    o = OracleModel(hp)
+    po = o.fit_begin(ptr, it)
+    gp = GroupPlan(models, ptr, it)
+    assert gp.epoch_prepare() == po.epoch_prepare()
+    # where the owner of a row changes: logical slices of S = ceil(items / world) rows, and the physical parts of the embedding
+    # array (runs of pages homed on one device: a page belongs to the owner of its first row)
+    S = (items + world - 1) // world
+    boundaries = [k * S for k in range(1, world)]
+    off, row_bytes = 0, 4 * models[0].storage_dim
+    for home, nbytes in models[0].partition_parts():
+        off += nbytes
+        if off >= items * row_bytes:
+            break
+        boundaries.append(off // row_bytes)
+    boundaries = sorted(set(boundaries))
+    assert len(boundaries) >= world - 1
+
+    class Full:
+        pass
+
+    f = Full()
+    f.world = world
+    f.model = lambda q: models[q]
+    f.rows = lambda q: gp.member(q).minibatch_rows(0)
+    f.step_local_all = lambda: (gp.step_local(0), gp.synchronize())
+    f.fetch = lambda q, which: gp.member(q).debug_fetch(which, f.rows(q))
+    f.apply_all = lambda: (gp.step(0), gp.synchronize())
+    nb = min(B, count_subsequences(ptr, T) // world)
+    out = check_first_step_multi(f, o, po, lstm=kind != ModelKind.EWMA, nb=nb, boundaries=boundaries)
+    assert out["items_touched_by_several_devices"] > 30 and min(out["rows_per_device"]) > 200_000, out
+    assert len(out["boundary_items"]) >= 2 * (world - 1), out
+    for k in range(1, world):  # both sides of every logical owner boundary were compared
+        assert any(x < k * S for x in out["boundary_items"]) and any(x >= k * S for x in out["boundary_items"])
+    loss_g = gp.end()
+    assert np.isfinite(loss_g)
     po.close()
 
 

@@ -564,8 +564,8 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
     Result<float, FittingError> fit(const data::CompressedInteractions& interactions) { return replicas_->fit(interactions); }
 
     /// The number the reference's `fit` would have returned for the last `fit` call: sequence_model.rs:157 reads the
-    /// loss node BEFORE :160 runs its forward pass, so every subsequence contributes what the worker's previous
-    /// subsequence of the same length left there.  `fit` itself returns the true mean loss.
+    /// loss node BEFORE :160 runs its forward pass; the nodes are shared running sums (lstm.rs:322-328), so a subsequence
+    /// of s steps contributes L_{s-1} of the worker's most recent earlier subsequence with at least s steps.  `fit` itself returns the true mean loss.
     float last_fit_lagged_loss() const {
         float v = 0.0f;
         check(sbr_model_last_fit_lagged_loss(replicas_->primary(), &v), "sbr_model_last_fit_lagged_loss");

@@ -138,8 +138,8 @@ sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
 sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows);
 sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples);
 /* The number the reference's `fit` returns.  sequence_model.rs:157 adds `loss.value()` of the loss node BEFORE :160 runs its
- * forward pass, so every subsequence contributes what the worker's previous subsequence OF THE SAME LENGTH left in that node
- * (0 the first time), accumulated in f32; `fit` returns the sum over the workers of accumulator / (1 + examples) (:173-177).
+ * forward pass; the loss nodes are shared running sums (lstm.rs:322-328), so a subsequence of s steps contributes the running sum
+ * L_{s-1} of the worker's most recent earlier subsequence with AT LEAST s steps (0 if none since this fit began), accumulated in f32; `fit` returns the sum over the workers of accumulator / (1 + examples) (:173-177).
  * sbr_fit_end / sbr_model_fit report the true mean instead; this is the lagged figure for a caller that must return what the
  * crate returns.  sbr_fit_end_lagged: THIS device's term (single device: the whole figure; multi-device hosts add the terms in
  * device order in f32).  sbr_model_last_fit_lagged_loss: the whole figure of the last completed sbr_model_fit / sbr_group_fit. */

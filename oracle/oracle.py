@@ -53,6 +53,7 @@ def lib():
         L.orc_fit_plan_destroy.restype = None
         L.orc_fit_epoch_prepare.argtypes = [vp, u64p]
         L.orc_fit_minibatch_rows.argtypes = [vp, C.c_int, C.c_uint64, u64p]
+        L.orc_fit_last_offsets.argtypes = [vp, C.c_int, vp, C.c_uint64, u64p]
         L.orc_fit_step_local.argtypes = [vp, C.c_int, C.c_uint64]
         L.orc_fit_exchange_bytes.argtypes = [vp]
         L.orc_fit_exchange_bytes.restype = C.c_uint64
@@ -154,6 +155,15 @@ class OraclePlan:
 
     def step(self, mb: int):
         _check(lib().orc_fit_step(self._h, mb))
+
+    def last_offsets(self, device: int = 0) -> np.ndarray:
+        """Packed layout of the device's last local step: off[t] = packed rows before step t, t = 0 .. Tm (sequences sorted by
+        steps, descending; row of (step t, sequence b) = off[t] + b)."""
+        T = int(self.model.hp.max_sequence_length)
+        off = np.zeros(T + 1, dtype=np.uint64)
+        tm = C.c_uint64()
+        _check(lib().orc_fit_last_offsets(self._h, device, _ptr(off), off.size, C.byref(tm)))
+        return off[: tm.value + 1].astype(np.int64)
 
     def exchange_bytes(self) -> int:
         return lib().orc_fit_exchange_bytes(self._h)

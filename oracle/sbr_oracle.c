@@ -553,6 +553,15 @@ int orc_fit_minibatch_rows(orc_plan* p, int q, uint64_t mb, uint64_t* out_rows) 
     return SBR_OK;
 }
 
+/* packed layout of the device's LAST local step: off[t] = packed rows before step t (Tm + 1 entries written; returns Tm) */
+int orc_fit_last_offsets(orc_plan* p, int q, uint64_t* out_off, uint64_t cap, uint64_t* out_tm) {
+    const orc_local* L = &p->loc[q];
+    if ((uint64_t)L->Tm + 1 > cap) return SBR_ERR_INVALID_ARGUMENT;
+    for (int t = 0; t <= L->Tm; ++t) out_off[t] = (uint64_t)L->off[t];
+    *out_tm = (uint64_t)L->Tm;
+    return SBR_OK;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* Recurrent forward over the packed minibatch.
  * LSTM (≙ wyrm nn::lstm Layer::forward, lstm.rs:293-298): z = bW + [x_t ; h_{t-1}] W as a
@@ -658,22 +667,29 @@ static void orc_score(orc_model* m, orc_local* L, uint64_t epoch_key, orc_rng* t
 }
 
 /* The loss figure the reference returns.  sequence_model.rs:157 adds `loss.value().scalar_sum()` of the node
- * losses[loss_idx] BEFORE :160 runs `loss.forward()` on it, so what a worker accumulates for a sequence of n items
- * is the value the previous forward pass left in that node — the summed loss L_{n-2} of the worker's previous
- * sequence of the same length (0 the first time; wyrm keeps a node's value until the next forward, recalled).
- * Accumulated in f32 like the reference's `loss_value`; sequences of one minibatch in minibatch order (with
- * batch_sequences = 1 this is the reference's order).  The engine reports the true sums (orc_fit_end); this figure
- * exists so that the two can be told apart (tests/test_oracle.py::test_lagged_loss_figure). */
+ * losses[loss_idx] BEFORE :160 runs `loss.forward()` on it, so what a worker accumulates for a sequence is whatever
+ * earlier forward passes left in that node.  The nodes are the running sums of lstm.rs:322-328 / ewma.rs:337-343:
+ * summed_losses[k] = summed_losses[k-1].clone() + loss_k shares the Rc node, so `forward()` on the node of a sequence
+ * with s steps evaluates — and leaves its value in — every node 0 .. s-1, and does not touch the nodes above.  The
+ * value read for a sequence with s steps is therefore the running sum L_{s-1} of the worker's most recent earlier
+ * sequence with AT LEAST s steps (0 before the first one: the graph is built per fit call, :103; wyrm keeps a node's
+ * value until its next forward, recalled).  Accumulated in f32 like the reference's `loss_value`; sequences of one
+ * minibatch in minibatch order (with batch_sequences = 1 this is the reference's order).  The engine reports the true
+ * sums (orc_fit_end); this figure exists so that the two can be told apart
+ * (tests/test_oracle.py::test_lagged_loss_figure, ::test_lagged_loss_mixed_lengths). */
 static void orc_lagged_loss_update(orc_plan* p, int q) {
     const orc_local* L = &p->loc[q];
     float* node = p->lagged_node + (size_t)q * p->m->hp.max_sequence_length;
     for (int b = 0; b < L->B; ++b) {
-        float sum = 0.0f; /* L_t = L_{t-1} + l_t (lstm.rs:322-328) */
         int steps = 0;
-        for (int t = 0; t < L->Tm && b < L->off[t + 1] - L->off[t]; ++t, ++steps) sum = sum + L->loss[L->off[t] + b];
+        for (int t = 0; t < L->Tm && b < L->off[t + 1] - L->off[t]; ++t) ++steps;
         if (steps == 0) continue;
-        p->lagged_dev[q] = p->lagged_dev[q] + node[steps - 1];
-        node[steps - 1] = sum;
+        p->lagged_dev[q] = p->lagged_dev[q] + node[steps - 1]; /* :157, before the forward pass of :160 */
+        float sum = 0.0f;                                       /* L_t = L_{t-1} + l_t (lstm.rs:322-328) */
+        for (int t = 0; t < steps; ++t) {
+            sum = sum + L->loss[L->off[t] + b];
+            node[t] = sum;
+        }
     }
 }
 

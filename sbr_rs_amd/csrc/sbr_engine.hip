@@ -1241,7 +1241,7 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     tick("copy stream");
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
-    if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + T);
+    if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + 2 * T); /* accumulator + (node, staged value) per step: sbr_report.hip */
     if (st == SBR_OK) st = dmalloc(&p->lag_seqsum, p->bmax);
     if (st == SBR_OK && (hipEventCreateWithFlags(&p->ev_seqsum, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess ||
@@ -1249,7 +1249,7 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
     if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
-    hipMemsetAsync(p->lag_state, 0, (1 + T) * sizeof(float), m->stream); /* the reference builds its loss nodes per fit call */
+    hipMemsetAsync(p->lag_state, 0, (1 + 2 * T) * sizeof(float), m->stream); /* the reference builds its loss nodes per fit call */
     hipMemsetAsync(p->loss_acc, 0, 17 * sizeof(double), m->stream);
     hipMemsetAsync(p->ex_acc, 0, 18 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
@@ -1547,7 +1547,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
             HIPCHK(hipStreamWaitEvent(on, m->ev_scored, 0));
         }
         if (side_header) { /* the step's loss bookkeeping rides on the ordering's stream: nothing on the main stream waits for it */
-            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, on);
+            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, p->lag_state, mb.B, on);
             sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
                                      p->header_accumulated ? p->ex_acc : nullptr, nullptr, on);
         }
@@ -1623,7 +1623,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
             p->lag_busy = false;
         }
         if (!fuse_lag) {
-            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, mb.B, m->stream);
+            sbr::launch_seq_loss(mv, p->wb.v.loss, p->lag_seqsum, p->lag_state, mb.B, m->stream);
             if (overlap) HIPCHK(hipEventRecord(p->ev_seqsum, m->stream));
         }
         sbr::launch_block_header(m->mv, bv, p->wb.v, mv, mb.R, p->header_accumulated ? p->loss_acc : nullptr,
@@ -2283,6 +2283,10 @@ struct sbr_group_plan {
         if (partitioned) SBRCHK(wait_applied(r, models[r]->stream));
         return sbr_fit_step_local(dev[r].plan, mb);
     }
+    sbr_status single_step(uint64_t mb) {
+        if (local_done == (int64_t)mb) return sbr_fit_step_apply(dev[0].plan, mb);
+        return sbr_fit_step(dev[0].plan, mb);
+    }
     /* Parallelism::Synchronous: compute, exchange, apply — every device sees every update before its next minibatch */
     sbr_status sync_step(uint64_t mb) {
         const bool have_local = local_done == (int64_t)mb;
@@ -2424,6 +2428,7 @@ struct sbr_group_plan {
                         (void)hipDeviceEnablePeerAccess(models[q]->device, 0); /* already-enabled is fine */
                 }
             (void)hipGetLastError();
+            if (n == 1) continue; /* single_step: no exchange buffers */
             SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.dense_all, n * db));
             if (!partitioned) { /* the replicated exchange moves table-sized chunks; the partitioned one needs none */
                 SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.recv, n * chunk));
@@ -2455,7 +2460,8 @@ struct sbr_group_plan {
     sbr_status step(uint64_t mb) {
         if (mb >= nmb) return SBR_ERR_INVALID_ARGUMENT;
         const auto t0 = std::chrono::steady_clock::now();
-        const sbr_status st = partitioned ? partitioned_step(mb) : async ? async_step(mb) : sync_step(mb);
+        /* a group of one has nobody to exchange with: the single-device step (its table may still be a mapped range) */
+        const sbr_status st = n == 1 ? single_step(mb) : partitioned ? partitioned_step(mb) : async ? async_step(mb) : sync_step(mb);
         local_done = -1;
         enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ++steps;

@@ -129,7 +129,7 @@ struct SmallTail {
     uint32_t* header;
     double* loss_acc;            /* may be null (several devices: the header travels) */
     unsigned long long* ex_acc;
-    float* lag_state;            /* [accumulator | loss-node value per sequence length] */
+    float* lag_state;            /* [accumulator | (loss node k, its staged next value) per step k] (sbr_report.hip) */
     uint64_t* keys_sorted;
     uint32_t* head_pos;
     uint32_t* nheads;
@@ -160,11 +160,12 @@ void launch_block_header_parts(uint32_t* header, int rows_host, const double* pa
                                double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
                                hipStream_t s);
 /* sbr_report.hip — the loss figure the reference's `fit` returns (sequence_model.rs:157 reads the loss node BEFORE :160 runs its
- * forward pass: every subsequence contributes what the worker's previous subsequence of the same length left there).  seq_loss:
- * per-sequence summed loss, t ascending; lagged_chain: the strictly sequential f32 accumulation over the minibatch's sequences on
- * one wave.  lag_state = [accumulator | node value per sequence length]. */
-void launch_seq_loss(const MbView& mb, const float* loss, float* seqsum, int b_host, hipStream_t s);
-void launch_lagged_chain(const MbView& mb, const float* seqsum, int b_host, float* lag_state, hipStream_t s);
+ * forward pass: a subsequence of s steps contributes the running sum L_{s-1} of the worker's most recent earlier subsequence with at
+ * least s steps).  seq_loss: the sequences' running sums, t ascending (px[b] = what sequence b + 1 reads; the nodes' next values);
+ * lagged_chain: the strictly sequential f32 accumulation over the minibatch's sequences on one wave.
+ * lag_state = [accumulator | (node k, its staged next value) per step k]. */
+void launch_seq_loss(const MbView& mb, const float* loss, float* px, float* lag_state, int b_host, hipStream_t s);
+void launch_lagged_chain(const MbView& mb, const float* px, int b_host, float* lag_state, hipStream_t s);
 /* BPTT (dX, dZ) and, separately, the dense gradient into blk.dense (may run on a second stream:
  * it reads only dZ, X, H) */
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

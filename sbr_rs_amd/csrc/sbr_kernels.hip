@@ -355,12 +355,20 @@ __device__ __forceinline__ void small_tail(const MbView& mb, const BlockView& bl
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (wave == 0) {
         const int ns = mb.steps[0];
+        /* the lagged loss figure (sbr_report.hip): the node of this length is read, then nodes 0 .. ns-1 take the sequence's
+         * running sums — lane l holds the sum after term base + l */
+        const float x = t.lag_state[1 + 2 * (ns - 1)];
         float sum = 0.0f;
         for (int base = 0; base < ns; base += 64) {
             const int tt = base + lane;
             const float v = tt < ns ? w.loss[mb.off[tt]] : 0.0f;
             const int cnt = ns - base < 64 ? ns - base : 64;
-            for (int l = 0; l < cnt; ++l) sum = sum + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+            float mine = 0.0f;
+            for (int l = 0; l < cnt; ++l) {
+                sum = sum + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+                mine = lane == l ? sum : mine;
+            }
+            if (tt < ns) t.lag_state[1 + 2 * tt] = mine;
         }
         if (lane == 0) {
             t.header[0] = (uint32_t)R;
@@ -375,11 +383,7 @@ __device__ __forceinline__ void small_tail(const MbView& mb, const BlockView& bl
                 t.ex_acc[1] += tsum;
                 t.ex_acc[2] += (unsigned long long)R;
             }
-            float* node = t.lag_state + 1;
-            const float acc = t.lag_state[0];
-            const float x = node[ns - 1];
-            t.lag_state[0] = acc + x;
-            node[ns - 1] = sum;
+            t.lag_state[0] = t.lag_state[0] + x;
         }
     }
     for (uint32_t e = tid; e < n; e += NT) {

@@ -1,20 +1,27 @@
 // sbr_report.hip — the loss figure the reference's `fit` returns, on the device.
 //
-// /root/reference/src/models/sequence_model.rs:157 adds `loss.value().scalar_sum()` of the node losses[loss_idx]
-// BEFORE :160 runs `loss.forward()` on it: what a worker accumulates for a subsequence of n items is the value its
-// previous subsequence OF THE SAME LENGTH left in that node (0 the first time), in f32, and `fit` returns the sum over
-// the workers of that accumulator / (1 + examples) (:173-177).  The engine's sbr_fit_end reports the true sums; this
-// file keeps the reference's figure beside it so that a caller behind INTEGRATION.md can return what the crate returns.
+// /root/reference/src/models/sequence_model.rs:157 adds `loss.value().scalar_sum()` of the node losses[loss_idx] BEFORE :160 runs
+// `loss.forward()` on it.  The nodes are the running sums of lstm.rs:322-328 / ewma.rs:337-343 — summed_losses[k] =
+// summed_losses[k-1].clone() + loss_k, the SAME Rc node — so a forward pass over a sequence of s steps leaves its prefix sums
+// L_0 .. L_{s-1} in nodes 0 .. s-1 and leaves the nodes above untouched.  What a worker accumulates for a sequence of s steps is
+// therefore L_{s-1} of its most recent earlier sequence with AT LEAST s steps (0 if there was none since the graph was built, i.e.
+// since the start of this fit call), in f32, and `fit` returns the sum over the workers of accumulator / (1 + examples)
+// (:173-177).  The engine's sbr_fit_end reports the true sums; this file keeps the reference's figure beside it so that a caller
+// behind INTEGRATION.md can return what the crate returns.
 //
-// Per minibatch (sequences b = 0..B-1 in packed order = steps descending, so sequences of one length are one run):
-//   sum_b    = l_0 + l_1 + ... + l_{steps_b - 1}            t-ascending f32 chain  (L_t = L_{t-1} + l_t, lstm.rs:322-328)
-//   x_b      = first of its run ? node[steps_b] : sum_{b-1}  what the node of that length held when b read it
-//   total    = ((total + x_0) + x_1) + ...                   strictly sequential f32 chain over b
-//   node[s]  = sum of the last sequence of the run of length s
-// A length occurs in at most one run of a minibatch, so the x_b are independent of each other and only the chain over b is
-// sequential: ONE wave walks it, 64 values per load, v_readlane + v_add_f32 per value (a lone wave issues a dependent VALU
-// instruction every ~9 cycles), on the sorter stream underneath BPTT.
-// The CPU checker restates it sequentially (tests compare the two bit for bit).
+// Per minibatch (sequences b = 0..B-1 in packed order = steps descending, so "the most recent sequence with at least as many
+// steps" of sequence b > 0 is sequence b - 1):
+//   P_b(k)   = l_0 + l_1 + ... + l_k                          t-ascending f32 chain over sequence b's loss terms
+//   x_0      = node[steps_0 - 1]                               what the previous minibatches left
+//   x_b      = P_{b-1}(steps_b - 1)                            b > 0
+//   total    = ((total + x_0) + x_1) + ...                     strictly sequential f32 chain over b
+//   node[k]  = P_b(k) of the LAST b with steps_b > k            (k < steps_0; the nodes above keep their values)
+// The x_b are independent of each other and only the chain over b is sequential: ONE wave walks it, 64 values per load,
+// v_readlane + v_add_f32 per value (a lone wave issues a dependent VALU instruction every ~9 cycles), on the sorter stream
+// underneath BPTT.  The CPU checker restates it sequentially, one sequence at a time (tests compare the two bit for bit).
+//
+// state layout: state[0] = the partition's accumulator (loss_value of sequence_model.rs:105); state[1 + 2k] = node k;
+// state[2 + 2k] = the value node k takes at the end of the minibatch in flight (staging: x_0 is read before the nodes move).
 
 #include <hip/hip_runtime.h>
 
@@ -22,27 +29,30 @@
 
 namespace sbr {
 
-// one thread per sequence: the summed loss node of the sequence, t ascending
-__global__ __launch_bounds__(256) void seq_loss_kernel(MbView mb, const float* loss, float* seqsum) {
+// one thread per sequence: the running sums of the sequence, t ascending; px[b] = x_{b+1}; the nodes' next values
+__global__ __launch_bounds__(256) void seq_loss_kernel(MbView mb, const float* loss, float* px, float* state) {
     __builtin_amdgcn_s_setprio(3); /* rides the ordering's stream underneath BPTT's older MFMA waves, like the ordering itself */
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= mb.B) return;
     const int n = mb.steps[b];
+    const int nxt = b + 1 < mb.B ? mb.steps[b + 1] : 0;
     float s = 0.0f;
+    int t = 0;
 #pragma unroll 8
-    for (int t = 0; t < n; ++t) s = s + loss[mb.off[t] + b];
-    seqsum[b] = s;
+    for (; t < nxt; ++t) s = s + loss[mb.off[t] + b]; /* the common case: the next sequence is as long, nothing else to do */
+    if (nxt) px[b] = s;
+    for (; t < n; ++t) {
+        s = s + loss[mb.off[t] + b];
+        state[2 + 2 * t] = s;
+    }
 }
 
-// state[0] = the partition's accumulator (loss_value of sequence_model.rs:105), state[1 + s] = value left in the loss node of
-// a sequence with s + 1 steps.  One wave; `steps` / `seqsum` in global memory or LDS.  Tiles of LAG_TILE sequences: first the
-// tile's x values with all their loads in flight together (they do not depend on the chain; a chunk-at-a-time version paid two
-// dependent memory round trips per 64 sequences: 0.5 ms for 8 192 sequences), staged through `xs` (LDS, LAG_TILE floats); then
-// the chain, 64 values per LDS read; then the tile's node writes (a length's run is read at its first and written at its last
-// sequence, so reads of a tile come before its writes).
+// One wave; `px` in global memory or LDS.  Tiles of LAG_TILE sequences: first the tile's x values with all their loads in flight
+// together (they do not depend on the chain; a chunk-at-a-time version paid two dependent memory round trips per 64 sequences:
+// 0.5 ms for 8 192 sequences), staged through `xs` (LDS, LAG_TILE floats); then the chain, 64 values per LDS read.  At the end the
+// staged node values move into the nodes.
 #define LAG_TILE 4096
-__device__ __forceinline__ void lagged_chain(const int* steps, const float* seqsum, int B, float* state, int lane, float* xs) {
-    float* node = state + 1;
+__device__ __forceinline__ void lagged_chain(const float* px, int B, int s0, float* state, int lane, float* xs) {
     float acc = state[0];
     for (int tile0 = 0; tile0 < B; tile0 += LAG_TILE) {
         const int n = B - tile0 < LAG_TILE ? B - tile0 : LAG_TILE;
@@ -51,11 +61,7 @@ __device__ __forceinline__ void lagged_chain(const int* steps, const float* seqs
         for (int c = 0; c < nchunks; ++c) {
             const int j = tile0 + c * 64 + lane;
             float x = 0.0f;
-            if (j < tile0 + n) {
-                const int s = steps[j];
-                const int sp = j > 0 ? steps[j - 1] : -1;
-                x = sp != s ? node[s - 1] : seqsum[j - 1];
-            }
+            if (j < tile0 + n) x = j == 0 ? state[1 + 2 * (s0 - 1)] : px[j - 1];
             xs[c * 64 + lane] = x;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -65,7 +71,7 @@ __device__ __forceinline__ void lagged_chain(const int* steps, const float* seqs
             const float vn = xs[(c + 1 < nchunks ? c + 1 : c) * 64 + lane];  // next chunk's values while this chunk's chain runs
             // (a lane-to-lane form — one v_add_f32 with a wave_shr:1 DPP operand per element instead of v_readlane + v_add — was
             // measured and is no faster: beside the GEMM's back-to-back 64-cycle MFMAs this wave's vector instructions wait for the
-            // pipe one MFMA pass at a time either way; profiles/r04_tail_experiments.md)
+            // pipe one MFMA pass at a time either way; NOTES.md, round 4)
             const int cnt = n - c * 64 < 64 ? n - c * 64 : 64;
             if (cnt == 64) {
 #pragma unroll
@@ -77,28 +83,17 @@ __device__ __forceinline__ void lagged_chain(const int* steps, const float* seqs
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-        for (int c = 0; c < nchunks; ++c) {  // the runs' last sequences leave their sums in the nodes
-            const int j = tile0 + c * 64 + lane;
-            if (j < tile0 + n) {
-                const int s = steps[j];
-                const int sn = j + 1 < B ? steps[j + 1] : -1;
-                if (sn != s) node[s - 1] = seqsum[j];
-            }
-        }
-        /* the next tile's node reads must see these writes: same wave, vector memory operations complete in order; the compiler
-         * keeps the order across the fence */
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
+    for (int t = lane; t < s0; t += 64) state[1 + 2 * t] = state[2 + 2 * t]; /* x_0 was read above: same wave, in order */
     if (lane == 0) state[0] = acc;
 }
 
-__global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, const float* seqsum, int B, float* state) {
+__global__ __launch_bounds__(64) void lagged_chain_kernel(const int* steps, const float* px, int B, float* state) {
     // one wave under BPTT's MFMA waves, which are older and win the SIMD's issue arbitration: at priority 0 the chain of 8 192
     // sequences took 0.44 ms of elapsed time for ~0.05 ms of dependent adds (profiles/r04_*kernel_stats*)
     __shared__ float xs[LAG_TILE];
     __builtin_amdgcn_s_setprio(3);
-    lagged_chain(steps, seqsum, B, state, threadIdx.x, xs);
+    lagged_chain(px, B, steps[0], state, threadIdx.x, xs);
 }
 
 // header of the exchange block: row count, loss sum (reporting only: order-free f64 reduction, compared with a tolerance) and
@@ -118,9 +113,8 @@ __global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, in
      * memory it kept the header launch of a 50 000-sequence step off the chip until a BPTT workgroup retired (64-sequence tiles
      * leave less than 24 KB of LDS per CU) — 1.5 ms during which the key ordering behind it on the stream could not start */
     extern __shared__ float lag_lds[];
-    float* ssum = lag_lds;
-    int* ssteps = reinterpret_cast<int*>(lag_lds + SBR_HEADER_LAG_MAX_B);
-    float* sx = lag_lds + 2 * SBR_HEADER_LAG_MAX_B;
+    float* spx = lag_lds;
+    float* sx = lag_lds + SBR_HEADER_LAG_MAX_B;
     double acc = 0.0;
     unsigned int tacc = 0;
     for (int i = threadIdx.x; i < nparts; i += nthreads) {
@@ -137,20 +131,24 @@ __global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, in
         tpart[threadIdx.x >> 6] = tacc;
     }
     if (lag_state) { /* a wave per sequence, 64 loss terms per coalesced load, then the t-ascending chain by v_readlane: one
-                      * sequence per step (the reference's schedule) must not wait for ~100 dependent load-add pairs */
+                      * sequence per step (the reference's schedule) must not wait for ~100 dependent load-add pairs.  Lane l keeps
+                      * the running sum after term base + l: the next sequence's x and the nodes' next values come from there */
         const int lane = threadIdx.x & 63;
         for (int b = threadIdx.x >> 6; b < mb.B; b += nwaves) {
             const int n = mb.steps[b];
+            const int nxt = b + 1 < mb.B ? mb.steps[b + 1] : 0;
             float s = 0.0f;
             for (int base = 0; base < n; base += 64) {
                 const int t = base + lane;
                 const float v = t < n ? loss[mb.off[t] + b] : 0.0f;
                 const int cnt = n - base < 64 ? n - base : 64;
-                for (int l = 0; l < cnt; ++l) s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
-            }
-            if (lane == 0) {
-                ssum[b] = s;
-                ssteps[b] = n;
+                float mine = 0.0f;
+                for (int l = 0; l < cnt; ++l) {
+                    s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+                    mine = lane == l ? s : mine;
+                }
+                if (t < n && t >= nxt) lag_state[2 + 2 * t] = mine;
+                if (t + 1 == nxt) spx[b] = mine;
             }
         }
     }
@@ -172,13 +170,14 @@ __global__ __launch_bounds__(1024) void block_header_kernel(uint32_t* header, in
             ex_acc[2] += (unsigned long long)R;
         }
     }
-    if (lag_state && threadIdx.x < 64) lagged_chain(ssteps, ssum, mb.B, lag_state, threadIdx.x, sx);
+    /* (the barrier above orders the waves' node staging and spx before this wave's reads: one workgroup, one CU) */
+    if (lag_state && threadIdx.x < 64 && mb.B > 0) lagged_chain(spx, mb.B, mb.steps[0], lag_state, threadIdx.x, sx);
 }
 
 void launch_block_header_parts(uint32_t* header, int rows_host, const double* part_loss, const unsigned int* part_tries, int nparts,
                                double* loss_acc, unsigned long long* ex_acc, const MbView& mb, const float* loss, float* lag_state,
                                hipStream_t s) {
-    const size_t lds = lag_state ? (size_t)(2 * SBR_HEADER_LAG_MAX_B + (SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B)) * 4 : 0;
+    const size_t lds = lag_state ? (size_t)(SBR_HEADER_LAG_MAX_B + (SBR_HEADER_LAG_MAX_B < LAG_TILE ? LAG_TILE : SBR_HEADER_LAG_MAX_B)) * 4 : 0;
     /* a small step walks its sequences' loss chains here, a wave per sequence: sixteen waves when there are more than four sequences
      * (MovieLens-100K at 16 sequences per step: 16 -> 6 us of a 266 us step) */
     const int threads = lag_state && mb.B > 4 ? 1024 : 256;
@@ -186,14 +185,14 @@ void launch_block_header_parts(uint32_t* header, int rows_host, const double* pa
                        mb, loss, lag_state);
 }
 
-void launch_seq_loss(const MbView& mb, const float* loss, float* seqsum, int b_host, hipStream_t s) {
+void launch_seq_loss(const MbView& mb, const float* loss, float* px, float* lag_state, int b_host, hipStream_t s) {
     if (b_host <= 0) return;
-    hipLaunchKernelGGL(seq_loss_kernel, dim3((b_host + 255) / 256), dim3(256), 0, s, mb, loss, seqsum);
+    hipLaunchKernelGGL(seq_loss_kernel, dim3((b_host + 255) / 256), dim3(256), 0, s, mb, loss, px, lag_state);
 }
 
-void launch_lagged_chain(const MbView& mb, const float* seqsum, int b_host, float* state, hipStream_t s) {
+void launch_lagged_chain(const MbView& mb, const float* px, int b_host, float* state, hipStream_t s) {
     if (b_host <= 0) return;
-    hipLaunchKernelGGL(lagged_chain_kernel, dim3(1), dim3(64), 0, s, mb.steps, seqsum, b_host, state);
+    hipLaunchKernelGGL(lagged_chain_kernel, dim3(1), dim3(64), 0, s, mb.steps, px, b_host, state);
 }
 
 }  // namespace sbr

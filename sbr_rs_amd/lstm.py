@@ -190,7 +190,8 @@ class _ImplicitSequenceModel:
     def last_fit_lagged_loss(self) -> float:
         """The number the reference's ``fit`` would have returned for the last single-process ``fit`` (one device or
         ``num_threads`` replicas): sequence_model.rs:157 reads the loss node before :160 runs its forward pass, so every
-        subsequence contributes what the worker's previous subsequence of the same length left there.  ``fit`` returns the
+        subsequence of s steps contributes the running loss sum L_{s-1} of the worker's most recent earlier subsequence with at
+        least s steps (the loss nodes are shared running sums, lstm.rs:322-328).  ``fit`` returns the
         true mean loss."""
         return self.params.last_fit_lagged_loss()
 

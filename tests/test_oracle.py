@@ -325,7 +325,7 @@ def test_fit_is_deterministic_and_recallable(oracle_lib):
 
 def test_lagged_loss_figure(oracle_lib):
     """the reference adds a loss node's value BEFORE running its forward pass
-    (sequence_model.rs:157 vs :160), i.e. the loss of the worker's previous sequence of the same length.  The
+    (sequence_model.rs:157 vs :160), i.e. what earlier sequences left in that node (mixed lengths: the next test).  The
     oracle exposes that figure beside the true sums: with equal-length sequences and one sequence per step it
     is the true sum minus the last sequence's loss."""
     n_users, n = 9, 7
@@ -351,6 +351,45 @@ def test_lagged_loss_figure(oracle_lib):
         lagged = np.float32(lagged + v)
     assert plan.end_lagged() == np.float32(lagged / np.float32(1 + examples))
     assert plan.end_lagged() < true_loss
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_lagged_loss_mixed_lengths(oracle_lib, B):
+    """Mixed-length data: the loss nodes are SHARED running sums (lstm.rs:322-328: summed_losses[k] = summed_losses[k-1].clone() +
+    loss_k), so the forward pass of a sequence with s steps leaves L_0 .. L_{s-1} in nodes 0 .. s-1 — a shorter sequence later
+    reads the prefix sum of the last sequence that was at least as long, not the sum of the last sequence of its own length.
+    The figure is re-derived here from the per-step losses by walking an explicit node array in the oracle's order of work."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(3, 11, size=40)
+    lens[:6] = [10, 4, 10, 7, 4, 3]
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    items = rng.integers(0, 60, size=int(ptr[-1])).astype(np.uint32)
+    T = 10
+    hp = hparams(60, T, 16, int(ModelKind.EWMA), LOSS_HINGE, B=B, epochs=2)
+    plan = OracleModel(hp).fit_begin(ptr, items)
+    node = np.zeros(T, dtype=np.float32)
+    acc = np.float32(0.0)
+    examples = 0
+    shorter_after_longer = 0
+    for _ in range(2):
+        for mb in range(plan.epoch_prepare()):
+            plan.step(mb)
+            rows = plan.minibatch_rows(mb)
+            loss = plan.debug_fetch(Debug.LOSS, rows)
+            off = plan.last_offsets()  # rows before step t; packed order: sequences sorted by steps, descending
+            nb = int(off[1])
+            for b in range(nb):
+                steps = int(np.sum(np.diff(off) > b))
+                acc = np.float32(acc + node[steps - 1])           # sequence_model.rs:157
+                shorter_after_longer += int(node[steps - 1] != 0 and steps < T - 1)
+                run = np.float32(0.0)
+                for t in range(steps):                             # :160 — every node up to this length is re-evaluated
+                    run = np.float32(run + loss[int(off[t]) + b])
+                    node[t] = run
+                examples += steps
+    true_loss, ex = plan.end()
+    assert ex == examples and shorter_after_longer > 10
+    assert plan.end_lagged() == np.float32(acc / np.float32(1 + examples))
 
 
 @pytest.mark.parametrize("kind,loss,d,opt", [

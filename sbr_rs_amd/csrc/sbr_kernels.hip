@@ -448,7 +448,8 @@ __device__ __forceinline__ void score_single_rows_fwd(const ModelView& m, const 
 // (NT = 256 up to 64 rows; sixteen waves beyond: up to 128 rows are then ONE pass of the score loop and the ranking of the keys
 // takes a quarter of the time — but a 1 024-thread workgroup costs ~3 us more to start and drain, which a ten-row step notices)
 template <int D, int NT>
-__global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+__device__ __forceinline__ void score_tail_body(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                                                const SmallTail& tail) {
     constexpr int NW = NT / 64;
     double loss_part;
     unsigned int tries_part;
@@ -475,6 +476,10 @@ __global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, 
         w.part_tries[0] = tsum;
     }
     small_tail<NT>(mb, blk, w, tail, lsum, tsum);
+}
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+    score_tail_body<D, NT>(m, mb, blk, w, epoch_key, tail);
 }
 
 // Single-negative losses (hinge, BPR: one candidate, no retry loop): U rows per lane group and pass, all their gathers
@@ -738,13 +743,12 @@ __device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbVi
 }
 
 // TAIL (one workgroup, a one-sequence step): the step's SmallTail follows in the same launch
-template <int D, bool WHOLE, bool TAIL = false>
-__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+template <int D, bool WHOLE, bool TAIL>
+__device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                                              const SmallTail& tail, int wave, int nwaves, int part) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
     float a[4], oma[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -829,11 +833,16 @@ __global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, B
         const double lsum = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
         const unsigned int tsum = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
         if (threadIdx.x == 0) {
-            w.part_loss[blockIdx.x] = lsum;
-            w.part_tries[blockIdx.x] = tsum;
+            w.part_loss[part] = lsum;
+            w.part_tries[part] = tsum;
         }
         if constexpr (TAIL) small_tail<256>(mb, blk, w, tail, lsum, tsum);
     }
+}
+template <int D, bool WHOLE, bool TAIL = false>
+__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
+    ewma_seq_body<D, WHOLE, TAIL>(m, mb, blk, w, epoch_key, tail, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6),
+                                  (int)((gridDim.x * blockDim.x) >> 6), (int)blockIdx.x);
 }
 
 // dalpha: chunk partials (chain over sequences inside a chunk), then chain across chunks

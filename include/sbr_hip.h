@@ -135,6 +135,20 @@ sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches)
  * follows (the shuffle advances the partition RNGs and the epoch counter). */
 sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p);
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
+/* `count` consecutive optimiser steps from `first` (= that many sbr_fit_step calls; sbr_model_fit runs every epoch as ONE such
+ * call).  At the reference's own schedule — one subsequence per optimiser step, sequence_model.rs:111-169 (batch_sequences = 1) — with
+ * embedding_dim <= 32, EWMA, a single-negative loss (hinge, BPR), Adagrad and max_sequence_length <= 129, a run of steps is ONE
+ * kernel launch: one workgroup walks the steps with each step's working set in LDS (one gather per step; nobody else touches the
+ * parameters at one sequence per step).  Same bits as the separate launches.  Single device. */
+sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count);
+/* How one-sequence steps at embedding_dim <= 32 are launched: 0 = one launch per kernel family (eight per step), 1 = fused
+ * launches (LSTM four per step: forward, scoring + header + key ordering, BPTT, gradient + updates; EWMA two), 2 (default) =
+ * additionally runs of steps in one launch through sbr_fit_steps / sbr_model_fit where the shape allows.  No result bit depends
+ * on it (tests run all three). */
+sbr_status sbr_model_set_step_fusion(sbr_model* m, int32_t level);
+/* Profiling aid of the one-launch step runs: shader-clock ticks of the run's workgroup summed per phase since sbr_fit_begin —
+ * [0] ids, key ordering, gather, [1] scan + scores, [2] backward scan, [3] reduction + updates, [4] closing barrier — and [5] the steps. */
+sbr_status sbr_fit_debug_phase_clocks(sbr_fit_plan* p, uint64_t out[6]);
 sbr_status sbr_fit_minibatch_rows(const sbr_fit_plan* p, uint64_t minibatch, uint64_t* out_rows);
 sbr_status sbr_fit_end(sbr_fit_plan* p, float* out_loss, uint64_t* out_examples);
 /* The number the reference's `fit` returns.  sequence_model.rs:157 adds `loss.value()` of the loss node BEFORE :160 runs its

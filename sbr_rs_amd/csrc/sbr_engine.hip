@@ -422,6 +422,8 @@ struct sbr_model {
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     float last_lagged_loss = 0.0f; /* what the reference's fit would have returned for the last sbr_model_fit / sbr_group_fit */
+    int step_fusion = 2; /* one-sequence steps at d <= 32 (sbr_model_set_step_fusion): 0 separate launches, 1 fused launches
+                          * (SmallTail + small_back: four per step), 2 runs of steps in one launch where the shape allows */
     DeviceArena eval_arena;        /* prediction-side scratch (guarded by mu) */
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -614,6 +616,9 @@ struct sbr_fit_plan {
         std::vector<int> off_host;         /* concatenated off tables of this rank */
         std::vector<uint32_t> rows_of_dev; /* [num_mb][ndev] */
         DevicePacked dp;
+        sbr::StepDesc* d_desc = nullptr;   /* one sequence per step (batch_sequences = 1): the steps of the epoch for the one-launch form */
+        uint64_t desc_cap = 0;
+        std::vector<sbr::StepDesc> desc_host;
         uint64_t rows_cap = 0, off_cap = 0, seq_cap = 0;
         /* pinned host staging of the packed index arrays (written directly by the packer, one DMA each) */
         uint32_t *h_in = nullptr, *h_out = nullptr, *h_ctr = nullptr;
@@ -637,6 +642,7 @@ struct sbr_fit_plan {
     int key_bits = 64;
     double* loss_acc = nullptr;
     unsigned long long* ex_acc = nullptr;
+    unsigned long long* phase_clocks = nullptr; /* [6] epoch_steps_kernel's per-phase s_memtime ticks + steps (sbr_fit_debug_phase_clocks) */
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
     bool hot_prelisted = false; /* this step's long segments (hot rows) were listed behind the ordering: their chunks are reduced on the
@@ -1247,6 +1253,8 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
                          hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&p->ev_hot, hipEventDisableTiming) != hipSuccess)) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
+    if (st == SBR_OK) st = dmalloc(&p->phase_clocks, 6);
+    if (st == SBR_OK) hipMemsetAsync(p->phase_clocks, 0, 6 * sizeof(unsigned long long), m->stream);
     if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
     if (st != SBR_OK) { sbr_fit_plan_destroy(p); return st; }
     hipMemsetAsync(p->lag_state, 0, (1 + 2 * T) * sizeof(float), m->stream); /* the reference builds its loss nodes per fit call */
@@ -1276,6 +1284,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     tick("join+sync");
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
+        dfree(p->ep[i].d_desc);
         if (p->ep[i].free_event) hipEventDestroy(p->ep[i].free_event);
         hfree(p->ep[i].h_in); hfree(p->ep[i].h_out); hfree(p->ep[i].h_ctr);
         hfree(p->ep[i].h_prev); hfree(p->ep[i].h_steps);
@@ -1292,7 +1301,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
         p->keys_sorted = nullptr; p->glist = p->gblist = nullptr; p->gfl = nullptr;
     }
     dfree(p->block); dfree(p->keys); dfree(p->keys_sorted); dfree(p->sort_temp);
-    dfree(p->loss_acc); dfree(p->ex_acc);
+    dfree(p->loss_acc); dfree(p->ex_acc); dfree(p->phase_clocks);
     dfree(p->lag_state); dfree(p->lag_seqsum);
     if (p->ev_seqsum) hipEventDestroy(p->ev_seqsum);
     if (p->ev_lagged) hipEventDestroy(p->ev_lagged);
@@ -1432,6 +1441,21 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
         e.rows_cap = row_base; e.off_cap = e.off_host.size(); e.seq_cap = seq_base;
     }
     hipStream_t cs = p->copy_stream;
+    e.desc_host.clear();
+    if (B == 1 && p->ndev == 1) {
+        e.desc_host.resize(nmb);
+        for (uint64_t mb = 0; mb < nmb; ++mb) {
+            const sbr_fit_plan::Mb& d = e.mbs[mb];
+            e.desc_host[mb] = sbr::StepDesc{(uint32_t)d.R, (uint32_t)d.row_base, (uint32_t)d.off_base, (uint32_t)d.seq_base};
+        }
+        if (nmb > e.desc_cap) {
+            dfree(e.d_desc);
+            e.d_desc = nullptr; e.desc_cap = 0;
+            SBRCHK(dmalloc(&e.d_desc, nmb));
+            e.desc_cap = nmb;
+        }
+        HIPCHK(hipMemcpyAsync(e.d_desc, e.desc_host.data(), nmb * sizeof(sbr::StepDesc), hipMemcpyHostToDevice, cs));
+    }
     HIPCHK(hipMemcpyAsync(e.dp.in_idx, e.h_in, row_base * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(hipMemcpyAsync(e.dp.out_idx, e.h_out, row_base * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(hipMemcpyAsync(e.dp.ctr, e.h_ctr, row_base * 4, hipMemcpyHostToDevice, cs));
@@ -1537,7 +1561,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
     static const char* ewma_env0 = std::getenv("SBR_EWMA_FUSED");
     const bool ewma_seq_pass = !m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0 && (ewma_env0 ? std::atoi(ewma_env0) : SBR_EWMA_FUSED_DEFAULT) != 0;
-    const bool small_tail = !overlap && p->ndev == 1 && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
+    const bool small_tail = m->step_fusion >= 1 && !overlap && p->ndev == 1 && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
     (void)ewma_seq_pass;
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
@@ -1647,7 +1671,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         HIPCHK(hipEventRecord(m->ev_fork, m->stream));
         HIPCHK(hipStreamWaitEvent(side, m->ev_fork, 0));
     }
-    p->dw_deferred = p->fuse_back && !overlap && p->ndev == 1 && sbr::small_back_shape_ok(m->mv, (int)mb.R) && (m->ng || mb.B <= 256);
+    p->dw_deferred = m->step_fusion >= 1 && p->fuse_back && !overlap && p->ndev == 1 && sbr::small_back_shape_ok(m->mv, (int)mb.R) && (m->ng || mb.B <= 256);
     if (p->dw_deferred) p->dense_unreduced_chunks = 0;
     if (!p->dw_deferred) {
         /* one device: the ordered reduction of the chunk partials is left to the consumer — the optimiser step folds it into
@@ -1729,6 +1753,62 @@ sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch) {
     p->fuse_back = false;
     SBRCHK(st);
     return sbr_fit_step_apply(p, minibatch);
+}
+
+/* `count` consecutive optimiser steps starting at `first`.  One sequence per step at d <= 32 (the reference's own schedule,
+ * sequence_model.rs:111-169) with EWMA, a single-negative loss and Adagrad: runs of up to SBR_EPOCH_STEPS_PER_LAUNCH steps are ONE
+ * launch each (sbr::launch_epoch_steps) — same bits as `count` calls of sbr_fit_step, which is what every other shape gets. */
+#ifndef SBR_EPOCH_STEPS_PER_LAUNCH
+#define SBR_EPOCH_STEPS_PER_LAUNCH 8192 /* a launch stays well under a second (a one-sequence step is 5-100 us) */
+#endif
+sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count) {
+    if (!p || p->ndev != 1) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_fit_plan::Epoch& ep = p->ep[p->cur];
+    if (first > ep.num_mb || count > ep.num_mb - first) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    const bool one_launch = m->step_fusion >= 2 && !m->timing && p->bmax == 1 && ep.d_desc && ep.desc_host.size() == ep.num_mb &&
+                            sbr::epoch_steps_shape_ok(m->mv, p->T - 1);
+    if (!one_launch) {
+        for (uint64_t mb = first; mb < first + count; ++mb) SBRCHK(sbr_fit_step(p, mb));
+        return SBR_OK;
+    }
+    if (!count) return SBR_OK;
+    SBRCHK(ensure_device(m));
+    if (p->lag_busy) { /* an earlier step's chain on the ordering's stream still owns lag_state */
+        HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
+        p->lag_busy = false;
+    }
+    if (p->sorted_event_live) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0)); /* (a larger step before: its ordering owned the keys) */
+    SBRCHK(join_dense(p));
+    const sbr::BlockView bv = block_view(m, p->block, p->rmax);
+    const sbr::EpochView ev{ep.dp.off, ep.dp.steps, ep.dp.prev_row, ep.dp.in_idx, ep.dp.out_idx, ep.dp.ctr, ep.d_desc};
+    const sbr::SmallTail tail{bv.header, p->loss_acc, p->ex_acc, p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
+    const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
+    for (uint64_t b = first; b < first + count; b += SBR_EPOCH_STEPS_PER_LAUNCH) {
+        const uint64_t e = std::min(first + count, b + (uint64_t)SBR_EPOCH_STEPS_PER_LAUNCH);
+        sbr::launch_epoch_steps(m->mv, ev, bv, p->wb.v, epoch_key, tail, (int)b, (int)e, p->T - 1, p->phase_clocks, m->stream);
+    }
+    m->opt_steps += count; /* Adagrad: no per-step host-side corrections */
+    p->hot_prelisted = p->sort_off_stream = p->dw_deferred = p->header_accumulated = false;
+    p->dense_unreduced_chunks = 0;
+    p->last_R = ep.mbs[first + count - 1].R;
+    p->last_block = p->block;
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_debug_phase_clocks(sbr_fit_plan* p, uint64_t out[6]) {
+    if (!p || !out) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(p->m));
+    HIPCHK(hipStreamSynchronize(p->m->stream));
+    HIPCHK(hipMemcpy(out, p->phase_clocks, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SBR_OK;
+}
+
+sbr_status sbr_model_set_step_fusion(sbr_model* m, int32_t level) {
+    if (!m || level < 0 || level > 2) return SBR_ERR_INVALID_ARGUMENT;
+    m->step_fusion = level;
+    return SBR_OK;
 }
 
 /* ---- multi-device owner-reduce protocol ------------------------------------------ */
@@ -2016,7 +2096,7 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         uint64_t nmb = 0;
         st = sbr_fit_epoch_prepare(p, &nmb);
         if (st == SBR_OK && e + 1 < m->hp.num_epochs) st = sbr_fit_epoch_prefetch(p); /* host packs epoch e+1 while the GPU runs e */
-        for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) st = sbr_fit_step(p, mb);
+        if (st == SBR_OK) st = sbr_fit_steps(p, 0, nmb);
     }
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
     if (st == SBR_OK) st = sbr_fit_end_lagged(p, &m->last_lagged_loss);

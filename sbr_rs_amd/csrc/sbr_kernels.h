@@ -138,6 +138,24 @@ bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
 /* The optimiser half of a small single-device LSTM step at d <= 32 (one dense-gradient chunk, single-launch sparse update) in ONE
  * launch: dense gradient (per-element row chains) + dense update + sparse update, instead of three. */
 bool small_back_shape_ok(const ModelView& m, int rows_host);
+/* A RUN of consecutive one-sequence optimiser steps (the reference's own schedule, sequence_model.rs:111-169) at d <= 32 in ONE
+ * launch: one workgroup walks the steps with each step's working set in LDS — one gather of the step's 3 n rows and of the touched
+ * rows' optimiser state, then scan, scores, backward scan, dalpha, key ordering, per-row reduction and the Adagrad updates out of
+ * LDS (ewma_steps_kernel, sbr_kernels.hip).  EWMA with a single-negative loss, Adagrad, at most SBR_EWMA_STEPS_MAX_ROWS rows per
+ * step.  desc[i] = the i-th step of the epoch's packed arrays (one sequence each). */
+struct StepDesc { uint32_t rows, row_base, off_base, seq_base; };
+struct EpochView {
+    const int* off;
+    const int* steps;
+    const int* prev_row;
+    const uint32_t *in_idx, *out_idx, *ctr;
+    const StepDesc* desc;
+};
+#define SBR_EPOCH_STEPS_MAX_LDS (150 * 1024)  /* dynamic LDS of the run's workgroup */
+bool epoch_steps_shape_ok(const ModelView& m, int max_rows_host);
+void launch_epoch_steps(const ModelView& m, const EpochView& ev, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                        const SmallTail& tail, int step_begin, int step_end, int max_rows_host,
+                        unsigned long long* phase_clocks /* [6] or null */, hipStream_t s);
 void launch_seg_hot_apply(const ModelView& m, const BlockView& blk, const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
 void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
                        const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);

@@ -2648,6 +2648,393 @@ __global__ __launch_bounds__(256) void small_back_kernel(ModelView m, MbView mb,
     dense_apply_element(m, i, acc);
 }
 
+// ---- a RUN of one-sequence optimiser steps in ONE launch (launch_epoch_steps) --------------------------------------------
+// The reference's own schedule is one optimiser step per subsequence (sequence_model.rs:111-169).  At d <= 32 such a step is a
+// few microseconds of arithmetic.  At one sequence per step nobody but the step's own workgroup touches the parameters, so a
+// run of consecutive steps needs no grid-wide synchronisation: ONE workgroup walks them, step k + 1's gather reading the rows
+// step k's update wrote from the same CU (workgroup-scope release / acquire).
+// (Round 5 measured the LSTM in this form as the four launches' phases concatenated — lstm_fwd_wave_seq | score + tail |
+// lstm_bwd_wave_seq | dense gradient + update | sparse update, barriers between — and it LOST to the four launches: 35.4 against
+// 31 us per step on the reference's Criterion shape, 152 against 118 us on MovieLens-100K.  The launches' dispatch overhead was
+// already hidden behind their predecessors; what a step waits for is its dependent memory round trips and the instruction count
+// of lone waves (~9 cycles per instruction), and one CU's four waves are fewer than the launches' workgroups.  Removed; NOTES.md.)
+__device__ __forceinline__ void phase_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// ---- EWMA + single-negative loss: a run of one-sequence steps with the step's whole working set in LDS --------------------
+// (ewma.rs:266-352 for one subsequence; sequence_model.rs:111-169 around it.)  A one-sequence EWMA step is ~3 n rows of 4 d bytes
+// and a few hundred flops; as launches — and as the concatenated phases of epoch_steps_kernel — it was a chain of ~10 dependent
+// global-memory round trips (ids -> rows -> H -> coefficients -> rows again for the backward scan -> keys -> rows -> table), each
+// ~1 us, around ~1 us of arithmetic.  Here a step makes ONE: the gather of its 3 n table rows (input, target, negative) together
+// with the optimiser state of the rows it will update — the ids were requested during the previous step, the negative of a
+// single-negative loss is a hash of the row counter, and the keys are ordered before the gather, so the touched rows are known.
+// Everything between — scan, scores, loss, backward scan, dalpha, the per-row reduction and the Adagrad update — works on LDS;
+// the updated rows are written back and the next step's gather waits for them (workgroup-scope release / acquire: one CU).
+// alpha and its accumulator, the loss accumulators and the lagged-loss nodes live in LDS / registers for the whole run and are
+// written back once.  The step's block arrays (debug fetch, sbr_fit_sparse_stats) are written for the LAST step of the run only.
+// Arithmetic: operation for operation that of ewma_seq_body / ewma_backward_seq / small_tail / seg_short_rows / EmitApply /
+// dense_apply_element, on the same lane layout (d/4 lanes x 4 elements per row), so the bits are theirs.
+#define SBR_EWMA_STEPS_MAX_ROWS 128 /* rows per step: the gather keeps 3 x 128 d / 1 024 + 12 row pieces per thread in registers */
+#define SBR_EWMA_STEPS_LDS_FLOATS(max_rows, d) \
+    (2 * (size_t)(d) + (size_t)(((max_rows) + 3) & ~3) + 8 * (size_t)(max_rows) * (d) + 9 * (size_t)(max_rows) + (d) + 1 + 12 * (size_t)(max_rows))
+template <int D>
+__global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView ev, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail,
+                                                         int step_begin, int step_end, int max_rows, unsigned long long* prof) {
+    constexpr int L = D / 4, NGRP = 256 / L;
+    constexpr int RQ = SBR_EWMA_STEPS_MAX_ROWS * L / 256;              // 16-byte pieces per thread and gathered array
+    constexpr int HQ = (3 * SBR_EWMA_STEPS_MAX_ROWS + NGRP - 1) / NGRP;  // segment-head positions per lane group
+    extern __shared__ __attribute__((aligned(16))) float el[];
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane % L, grp = tid / L;
+    /* run-resident state */
+    float* alphaL = el;                      // [D]
+    float* alphaAcc = alphaL + D;            // [D]
+    float* lagN = alphaAcc + D;              // [max_rows] loss nodes (sbr_report.hip)
+    float* stepL = lagN + ((max_rows + 3) & ~3);
+    for (int k = tid; k < D; k += 256) { alphaL[k] = m.alpha[k]; alphaAcc[k] = m.alpha_acc[k]; }
+    for (int t = tid; t < max_rows; t += 256) lagN[t] = tail.lag_state[1 + 2 * t];
+    float lag_acc = tail.lag_state[0];
+    double la0 = 0.0, la1 = 0.0;             // thread 64 (wave 1 does the bookkeeping): loss_acc[0], loss_acc[1]
+    unsigned long long ex0 = 0, ex1 = 0, ex2 = 0;
+    if (tid == 64 && tail.loss_acc) { la0 = tail.loss_acc[0]; la1 = tail.loss_acc[1]; ex0 = tail.ex_acc[0]; ex1 = tail.ex_acc[1]; ex2 = tail.ex_acc[2]; }
+    unsigned long long pc[5] = {0, 0, 0, 0, 0};
+    unsigned long long tq = clock64();
+#define SBR_PHASE_CLOCK(i) { const unsigned long long now = clock64(); pc[i] += now - tq; tq = now; }
+    /* the ids of the first step (later ones are requested a step ahead) */
+    StepDesc sd = ev.desc[step_begin];
+    uint32_t nin = 0, nout = 0, nctr = 0;
+    if (tid < (int)sd.rows) { nin = ev.in_idx[sd.row_base + tid]; nout = ev.out_idx[sd.row_base + tid]; nctr = ev.ctr[sd.row_base + tid]; }
+    __syncthreads();
+    for (int st = step_begin; st < step_end; ++st) {
+        const int n = (int)sd.rows, n3 = 3 * n;
+        const bool last = st + 1 == step_end;
+        float* X = stepL;                    // [n][D] E[in_t]
+        float* P = X + (size_t)n * D;        // [n][D] E[out_t]
+        float* N = P + (size_t)n * D;        // [n][D] E[neg_t]
+        float* H = N + (size_t)n * D;        // [n][D] s_t
+        float* DS = H + (size_t)n * D;       // [n][D] dloss/ds_t, then dX_t in place
+        float* A = DS + (size_t)n * D;       // [3n][D] optimiser state (E_acc) of the row at segment head p
+        uint32_t* iin = reinterpret_cast<uint32_t*>(A + (size_t)n3 * D);
+        uint32_t* iout = iin + n;
+        uint32_t* ineg = iout + n;
+        float* bp = reinterpret_cast<float*>(ineg + n);  // b[out_t], b[neg_t] and their optimiser state
+        float* bn = bp + n;
+        float* bpa = bn + n;
+        float* bna = bpa + n;
+        float* coef = bna + n;
+        float* lossv = coef + n;
+        float* dab = lossv + n;              // [D]
+        uint64_t* ka = reinterpret_cast<uint64_t*>(dab + D + ((9 * n + D) & 1));  // 8-byte aligned: stepL and n D are multiples of 4
+        uint64_t* kb = ka + n3;
+        /* ---- ids (registers -> LDS), keys; the next step's ids are requested now */
+        if (tid < n) {
+            const uint32_t ng = sbr_neg_draw(epoch_key, nctr, 0u, m.num_items);
+            iin[tid] = nin; iout[tid] = nout; ineg[tid] = ng;
+            ka[3 * tid] = ((uint64_t)nin << 32) | (uint32_t)(3 * tid);
+            ka[3 * tid + 1] = ((uint64_t)nout << 32) | (uint32_t)(3 * tid + 1);
+            ka[3 * tid + 2] = ((uint64_t)ng << 32) | (uint32_t)(3 * tid + 2);
+        }
+        StepDesc sdn = sd;
+        if (!last) {
+            sdn = ev.desc[st + 1];
+            if (tid < (int)sdn.rows) { nin = ev.in_idx[sdn.row_base + tid]; nout = ev.out_idx[sdn.row_base + tid]; nctr = ev.ctr[sdn.row_base + tid]; }
+        }
+        __syncthreads();
+        /* ---- the gather of the 3 n rows is requested first (16-byte pieces into registers, up to RQ per thread and array) ... */
+        const int nq = n * L;  // pieces per array
+        float4 vx[RQ], vp[RQ], vn[RQ];
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < nq) {
+                const int rr = idx / L, l4 = idx - rr * L;
+                vx[u] = ld4(m.E + (size_t)iin[rr] * D + 4 * l4);
+                vp[u] = ld4(m.E + (size_t)iout[rr] * D + 4 * l4);
+                vn[u] = ld4(m.E + (size_t)ineg[rr] * D + 4 * l4);
+            }
+        }
+        float b0 = 0.f, b1 = 0.f, a0 = 0.f, a1 = 0.f;
+        if (tid < n) {
+            const uint32_t po = iout[tid], pn = ineg[tid];
+            b0 = m.b[po]; b1 = m.b[pn]; a0 = m.bacc[po]; a1 = m.bacc[pn];
+        }
+        /* ... and while it travels: the keys' stable order by row (distinct keys, so the rank of a key among all of them is its
+         * place) and sigmoid(alpha) */
+        for (int e0 = 0; e0 < n3; e0 += 256) {  // workgroup-uniform trip count
+            const int e = e0 + tid;
+            const uint64_t k = e < n3 ? ka[e] : ~0ull;
+            int rank = 0;
+            for (int j0 = 0; j0 < n3; j0 += 64) {
+                /* 64 keys per LDS read (one per lane), then compared one by one out of the lanes' registers: a dependent LDS read
+                 * per key cost a step of ~30 keys 1.6 us */
+                const uint64_t kj = j0 + lane < n3 ? ka[j0 + lane] : ~0ull;
+                const uint32_t klo = (uint32_t)kj, khi = (uint32_t)(kj >> 32);
+                const int cnt = n3 - j0 < 64 ? n3 - j0 : 64;
+                for (int l = 0; l < cnt; ++l) {
+                    const uint64_t other = ((uint64_t)__builtin_amdgcn_readlane(khi, l) << 32) | (uint64_t)__builtin_amdgcn_readlane(klo, l);
+                    rank += other < k ? 1 : 0;
+                }
+            }
+            if (e < n3) kb[rank] = k;
+        }
+        float a[4], oma[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = sbr_sigmoidf(alphaL[4 * lg + j]);
+            oma[j] = 1.0f - a[j];
+        }
+        __syncthreads();
+        /* the optimiser state (E_acc) of every segment head's row, requested as soon as the order is known: piece (p, lg) by the
+         * thread that will update it — it stays in flight underneath the scan and lands in LDS before the update */
+        float4 ha[HQ];
+#pragma unroll
+        for (int i = 0; i < HQ; ++i) {
+            const int p = i * NGRP + grp;
+            ha[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < n3) {
+                const uint32_t row = (uint32_t)(kb[p] >> 32);
+                if (p == 0 || (uint32_t)(kb[p - 1] >> 32) != row) ha[i] = ld4(m.Eacc + (size_t)row * D + 4 * lg);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RQ; ++u) {
+            const int idx = u * 256 + tid;
+            if (idx < nq) {
+                st4(X + 4 * (size_t)idx, vx[u]);
+                st4(P + 4 * (size_t)idx, vp[u]);
+                st4(N + 4 * (size_t)idx, vn[u]);
+            }
+        }
+        if (tid < n) { bp[tid] = b0; bn[tid] = b1; bpa[tid] = a0; bna[tid] = a1; }
+        __syncthreads();
+        SBR_PHASE_CLOCK(0)
+        /* ---- scan (ewma.rs:302-313): one lane group, s_t to LDS */
+        if (tid < L) {
+            float4 s = ld4(X + 4 * lg);
+            st4(H + 4 * lg, s);
+            float4 xn = ld4(X + (size_t)(n > 1 ? 1 : 0) * D + 4 * lg);
+            for (int t = 1; t < n; ++t) {
+                const float4 x = xn;
+                xn = ld4(X + (size_t)(t + 1 < n ? t + 1 : t) * D + 4 * lg);  // the next row's LDS read under this row's arithmetic
+                s.x = sbr_fma(a[0], s.x, oma[0] * x.x);
+                s.y = sbr_fma(a[1], s.y, oma[1] * x.y);
+                s.z = sbr_fma(a[2], s.z, oma[2] * x.z);
+                s.w = sbr_fma(a[3], s.w, oma[3] * x.w);
+                st4(H + (size_t)t * D + 4 * lg, s);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HQ; ++i) {
+            const int p = i * NGRP + grp;
+            if (p < n3) st4(A + (size_t)p * D + 4 * lg, ha[i]);
+        }
+        __syncthreads();
+        /* ---- scores, loss, dloss/ds of every step (ewma.rs:315-335): a lane group per row */
+        for (int r0 = 0; r0 < n; r0 += NGRP) {  // workgroup-uniform trip count (the DPP reductions want whole groups)
+            const int r = r0 + grp;
+            const int rr = r < n ? r : n - 1;
+            const float4 sv = ld4(H + (size_t)rr * D + 4 * lg), ep = ld4(P + (size_t)rr * D + 4 * lg), ec = ld4(N + (size_t)rr * D + 4 * lg);
+            const float pos = bp[rr] + group_allreduce<L>(dot4(sv, ep));
+            const float neg = bn[rr] + group_allreduce<L>(dot4(sv, ec));
+            float g, l;
+            if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(pos, neg, &g);
+            else l = sbr_loss_hinge(pos, neg, &g);
+            if (r < n) {
+                // dloss/ds: g*E[neg] - g*E[pos], two rounded products and one subtraction
+                st4(DS + (size_t)r * D + 4 * lg, make_float4(g * ec.x - g * ep.x, g * ec.y - g * ep.y, g * ec.z - g * ep.z, g * ec.w - g * ep.w));
+                if (lg == 0) { coef[r] = g; lossv[r] = l; }
+            }
+        }
+        __syncthreads();
+        SBR_PHASE_CLOCK(1)
+        /* ---- backward scan (ewma_backward_seq): one lane group; dX over DS, dalpha partial to LDS.  Wave 1 meanwhile: loss bookkeeping */
+        if (tid < L) {
+            float carry[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
+            float4 dsn = ld4(DS + (size_t)(n - 1) * D + 4 * lg), xnn = ld4(X + (size_t)(n - 1) * D + 4 * lg),
+                   spn = ld4(H + (size_t)(n > 1 ? n - 2 : 0) * D + 4 * lg);
+            for (int t = n - 1; t >= 0; --t) {
+                const float4 dsv = dsn, xv_ = xnn, spv_ = spn;
+                {   // step t - 1's operands under step t's arithmetic
+                    const int tp = t > 0 ? t - 1 : 0;
+                    dsn = ld4(DS + (size_t)tp * D + 4 * lg);
+                    xnn = ld4(X + (size_t)tp * D + 4 * lg);
+                    spn = ld4(H + (size_t)(tp > 0 ? tp - 1 : 0) * D + 4 * lg);
+                }
+                float ds[4] = {dsv.x, dsv.y, dsv.z, dsv.w};
+                if (t != n - 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
+                }
+                float4 dx;
+                if (t > 0) {
+                    const float xs[4] = {xv_.x, xv_.y, xv_.z, xv_.w}, sps[4] = {spv_.x, spv_.y, spv_.z, spv_.w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = oma[j] * ds[j];
+                        carry[j] = a[j] * ds[j];
+                        da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
+                    }
+                    dx = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                }
+                st4(DS + (size_t)t * D + 4 * lg, dx);
+            }
+            st4(dab + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
+        } else if (tid >= 64 && tid < 128) { /* wave 1: the step's loss figures (block_header_kernel / small_tail) */
+            double lp = 0.0;
+            for (int r = lane; r < n; r += 64) lp += (double)lossv[r];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) lp += __shfl_xor(lp, off, 64);
+            /* the lagged figure: the node of this length is read, then nodes 0 .. n-1 take the running sums (sbr_report.hip) */
+            const float x = lagN[n - 1];
+            float sum = 0.0f;
+            for (int base = 0; base < n; base += 64) {
+                const int tt = base + lane;
+                const float v = tt < n ? lossv[tt] : 0.0f;
+                const int cnt = n - base < 64 ? n - base : 64;
+                float mine = 0.0f;
+                for (int l = 0; l < cnt; ++l) {
+                    sum = sum + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+                    mine = lane == l ? sum : mine;
+                }
+                if (tt < n) lagN[tt] = mine;
+            }
+            lag_acc = lag_acc + x;
+            if (lane == 0) { /* (thread 64 keeps the accumulators of the run) */
+                la0 += lp; la1 += lp;
+                ex0 += (unsigned long long)n; ex1 += (unsigned long long)n; ex2 += (unsigned long long)n;
+                if (last) {
+                    tail.header[0] = (uint32_t)n;
+                    tail.header[1] = (uint32_t)n;
+                    tail.header[2] = tail.header[3] = 0;
+                    *reinterpret_cast<double*>(tail.header + 4) = lp;
+                    *reinterpret_cast<unsigned long long*>(tail.header + 6) = (unsigned long long)n;
+                    w.part_loss[0] = lp;
+                    w.part_tries[0] = (unsigned int)n;
+                }
+            }
+        }
+        __syncthreads();
+        SBR_PHASE_CLOCK(2)
+        /* ---- dalpha and its update (ewma_dab_final_kernel with one sequence + dense_apply_element), in LDS */
+        float galpha = 0.0f;
+        if (tid < D) {
+            float pcv = 0.0f;
+            pcv = pcv + dab[tid];
+            const float av = sbr_sigmoidf(alphaL[tid]);
+            galpha = pcv * (av * (1.0f - av));
+        }
+        /* ---- sparse update: a lane group per SEGMENT of the ordered keys (a position whose row differs from its predecessor's starts
+         * one); entries in (packed row, kind) order, the first initialises, SBR_SEG_CHUNK-entry chunk partials added in order.  The
+         * row's parameters are the gathered copy of any of its entries, its optimiser state came with the gather. */
+        for (int p0 = 0; p0 < n3; p0 += NGRP) {
+            const int p = p0 + grp;
+            if (p >= n3) continue;
+            const uint32_t row = (uint32_t)(kb[p] >> 32);
+            if (p > 0 && (uint32_t)(kb[p - 1] >> 32) == row) continue;
+            RowPrefetch q;
+            {
+                const uint32_t src = (uint32_t)kb[p];
+                const uint32_t r = src / 3, kind = src % 3;
+                q.w = ld4((kind == 0 ? X : (kind == 1 ? P : N)) + (size_t)r * D + 4 * lg);
+                q.a = ld4(A + (size_t)p * D + 4 * lg);
+                q.mo = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f), g = tot;
+            float totb = 0.0f, gb = 0.0f, bv = 0.0f, ba = 0.0f;
+            bool tot_first = true, tot_hb = false, first = true, has_b = false, have_bias = false;
+            int in_chunk = 0;
+            for (int e = p; e < n3 && (uint32_t)(kb[e] >> 32) == row; ++e) {
+                const uint32_t src = (uint32_t)kb[e];
+                const uint32_t r = src / 3, kind = src % 3;
+                const float4 v = ld4((kind == 0 ? DS : H) + (size_t)r * D + 4 * lg);
+                const float scl = kind == 0 ? 1.0f : (kind == 1 ? -coef[r] : coef[r]);
+                if (first) {
+                    g = make_float4(scl * v.x, scl * v.y, scl * v.z, scl * v.w);
+                    first = false;
+                } else {
+                    g.x = g.x + scl * v.x; g.y = g.y + scl * v.y; g.z = g.z + scl * v.z; g.w = g.w + scl * v.w;
+                }
+                if (kind != 0) {
+                    gb = has_b ? gb + scl : scl;
+                    has_b = true;
+                    if (!have_bias) { bv = kind == 1 ? bp[r] : bn[r]; ba = kind == 1 ? bpa[r] : bna[r]; have_bias = true; }
+                }
+                if (++in_chunk == SBR_SEG_CHUNK) { /* a chunk is complete: the partials are added in order, the first initialises */
+                    if (tot_first) { tot = g; tot_first = false; } else { tot.x = tot.x + g.x; tot.y = tot.y + g.y; tot.z = tot.z + g.z; tot.w = tot.w + g.w; }
+                    if (has_b) { totb = tot_hb ? totb + gb : gb; tot_hb = true; }
+                    first = true; has_b = false; in_chunk = 0; gb = 0.0f;
+                }
+            }
+            if (in_chunk) {
+                if (tot_first) { tot = g; tot_first = false; } else { tot.x = tot.x + g.x; tot.y = tot.y + g.y; tot.z = tot.z + g.z; tot.w = tot.w + g.w; }
+                if (has_b) { totb = tot_hb ? totb + gb : gb; tot_hb = true; }
+            }
+            /* EmitApply::row + bias_update (Adagrad) */
+            sbr_adagrad(&q.w.x, &q.a.x, tot.x, m.lr, m.l2);
+            sbr_adagrad(&q.w.y, &q.a.y, tot.y, m.lr, m.l2);
+            sbr_adagrad(&q.w.z, &q.a.z, tot.z, m.lr, m.l2);
+            sbr_adagrad(&q.w.w, &q.a.w, tot.w, m.lr, m.l2);
+            st4(m.E + (size_t)row * D + 4 * lg, q.w);
+            st4(m.Eacc + (size_t)row * D + 4 * lg, q.a);
+            if (tot_hb && lg == 0) {
+                sbr_adagrad(&bv, &ba, totb, m.lr, m.l2);
+                m.b[row] = bv;
+                m.bacc[row] = ba;
+            }
+        }
+        if (tid < D) { /* dense_apply_element, EWMA branch (Adagrad), on the run-resident copy */
+            float wv = alphaL[tid], G = alphaAcc[tid];
+            sbr_adagrad(&wv, &G, galpha, m.lr, m.l2);
+            alphaL[tid] = wv;
+            alphaAcc[tid] = G;
+            if (last) blk.dense[tid] = galpha;
+        }
+        SBR_PHASE_CLOCK(3)
+        if (last) { /* the block of the run's last step, for sbr_fit_debug_fetch / sbr_fit_sparse_stats */
+            for (int idx = tid; idx < n * L; idx += 256) {
+                const int rr = idx / L, l4 = idx - rr * L;
+                st4(blk.H + (size_t)rr * D + 4 * l4, ld4(H + (size_t)rr * D + 4 * l4));
+                st4(blk.dX + (size_t)rr * D + 4 * l4, ld4(DS + (size_t)rr * D + 4 * l4));
+            }
+            if (tid < n) {
+                blk.in_idx[tid] = iin[tid]; blk.out_idx[tid] = iout[tid]; blk.neg[tid] = ineg[tid];
+                blk.coef[tid] = coef[tid];
+                w.loss[tid] = lossv[tid];
+                w.tries[tid] = 1u;
+            }
+            for (int e = tid; e < n3; e += 256) tail.keys_sorted[e] = kb[e];
+            if (tid == 0) {
+                uint32_t nh = 0;
+                for (int e = 0; e < n3; ++e)
+                    if (e == 0 || (uint32_t)(kb[e] >> 32) != (uint32_t)(kb[e - 1] >> 32)) tail.head_pos[nh++] = (uint32_t)e;
+                tail.head_pos[nh] = (uint32_t)n3;
+                *tail.nheads = nh;
+            }
+        }
+        sd = sdn;
+        phase_sync(); /* the table rows written above are read by the next step's gather */
+        SBR_PHASE_CLOCK(4)
+    }
+#undef SBR_PHASE_CLOCK
+    for (int k = tid; k < D; k += 256) { m.alpha[k] = alphaL[k]; m.alpha_acc[k] = alphaAcc[k]; }
+    for (int t = tid; t < max_rows; t += 256) tail.lag_state[1 + 2 * t] = lagN[t];
+    if (tid == 64) {
+        tail.lag_state[0] = lag_acc;
+        if (tail.loss_acc) { tail.loss_acc[0] = la0; tail.loss_acc[1] = la1; tail.ex_acc[0] = ex0; tail.ex_acc[1] = ex1; tail.ex_acc[2] = ex2; }
+    }
+    if (prof && tid == 0) {
+        for (int i = 0; i < 5; ++i) prof[i] += pc[i];
+        prof[5] += (unsigned long long)(step_end - step_begin);
+    }
+}
+
 // the long segments straight from the head list (launch_seg_prelist): what seg_short_kernel registers as it meets them, known
 // before the update starts
 __global__ __launch_bounds__(256) void seg_long_list_kernel(SegScratch sc) {
@@ -3245,8 +3632,7 @@ static int score_grid(int d, int rows, bool single_negative) {
 }
 
 bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host) {
-    static const bool off = std::getenv("SBR_NO_SMALL_TAIL") != nullptr; /* A/B switch */
-    return !off && sequences_host == 1 && rows_host > 0 && rows_host <= SBR_SMALL_TAIL_MAX_ROWS && (m.d == 16 || m.d == 32);
+    return sequences_host == 1 && rows_host > 0 && rows_host <= SBR_SMALL_TAIL_MAX_ROWS && (m.d == 16 || m.d == 32);
 }
 
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
@@ -3502,15 +3888,43 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
 #define SBR_SMALL_BACK_MAX_ROWS 256
 #endif
 bool small_back_shape_ok(const ModelView& m, int rows_host) {
-    static const bool off = std::getenv("SBR_NO_SMALL_BACK") != nullptr; /* A/B switch */
     /* up to 128 rows: a row costs every element's thread one dependent fma and a pair of loads — ms per fit of the reference's
      * Criterion bench (2 352 / 588 / 147 / 37 steps of ~9 / 36 / 150 / 600 rows), this form against the three launches:
      * 74.5 / 90.1, 34.6 / 37.6, 14.6 / 13.7, 7.7 / 5.6 */
-    if (off || (m.d != 16 && m.d != 32) || rows_host <= 0) return false;
+    if ((m.d != 16 && m.d != 32) || rows_host <= 0) return false;
     if (m.ng == 0) return 3ull * (uint64_t)rows_host <= SBR_SEG_INLINE_MAX_KEYS; /* EWMA: dalpha + its update + the sparse update; the caller checks
                                                                                     * that the sequences fit one dalpha chunk */
     return rows_host <= SBR_SMALL_BACK_MAX_ROWS;
 }
+/* dynamic LDS of ewma_steps_kernel for steps of at most max_rows rows (0: the shape cannot take the one-launch form) */
+static size_t epoch_steps_lds(const ModelView& m, int max_rows) {
+    if ((m.d != 16 && m.d != 32) || max_rows <= 0 || max_rows > SBR_EWMA_STEPS_MAX_ROWS) return 0;
+    if (m.optimizer != SBR_OPT_ADAGRAD || m.ng != 0 || m.loss == SBR_LOSS_WARP) return 0;
+    /* [alpha | alpha_acc | lag nodes] + the step's rows, optimiser state, ids, coefficients and keys */
+    const size_t fl = SBR_EWMA_STEPS_LDS_FLOATS(max_rows, m.d);
+    return fl * 4 <= SBR_EPOCH_STEPS_MAX_LDS ? fl * 4 : 0;
+}
+bool epoch_steps_shape_ok(const ModelView& m, int max_rows) { return epoch_steps_lds(m, max_rows) != 0; }
+void launch_epoch_steps(const ModelView& m, const EpochView& ev, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                        const SmallTail& tail, int step_begin, int step_end, int max_rows, unsigned long long* prof, hipStream_t s) {
+    const size_t lds = epoch_steps_lds(m, max_rows);
+    if (!lds || step_end <= step_begin) return;
+#define SBR_EWMA_STEPS(DD)                                                                                                          \
+    {                                                                                                                               \
+        static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */                     \
+        int dev = 0;                                                                                                                \
+        (void)hipGetDevice(&dev);                                                                                                   \
+        dev = dev >= 0 && dev < 64 ? dev : 0;                                                                                       \
+        if (lds > granted[dev]) {                                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ewma_steps_kernel<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            granted[dev] = lds;                                                                                                     \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((ewma_steps_kernel<DD>), dim3(1), dim3(256), lds, s, m, ev, blk, w, epoch_key, tail, step_begin, step_end, max_rows, prof); \
+    }
+    if (m.d == 32) SBR_EWMA_STEPS(32) else SBR_EWMA_STEPS(16)
+#undef SBR_EWMA_STEPS
+}
+
 void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t rows_host,
                        const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s) {
     const size_t n = m.ng ? (size_t)(2 * m.d + 1) * m.ng * m.d : (size_t)m.d;

@@ -177,6 +177,16 @@ class FitPlan:
     def step(self, mb: int):
         _check(self._L.sbr_fit_step(self._h, mb))
 
+    def steps(self, first: int, count: int):
+        """``count`` consecutive optimiser steps (sbr_fit_steps): one-sequence steps at d <= 32 run as one launch per run."""
+        _check(self._L.sbr_fit_steps(self._h, first, count))
+
+    def phase_clocks(self):
+        """Per-phase ticks (100 MHz) of the one-launch step runs since fit_begin: forward, score + tail, backward, dense, sparse; steps."""
+        out = (C.c_uint64 * 6)()
+        _check(self._L.sbr_fit_debug_phase_clocks(self._h, out))
+        return list(out)
+
     def step_local(self, mb: int):
         _check(self._L.sbr_fit_step_local(self._h, mb))
 
@@ -372,6 +382,11 @@ class Model:
         """Which kernel families are bracketed by events while timing is on (names of ``KernelFamily``; None = all)."""
         mask = 0xFFFFFFFF if families is None else sum(1 << int(KernelFamily[f]) for f in families)
         _check(self._L.sbr_model_timing_select(self._h, mask))
+
+    def set_step_fusion(self, level: int):
+        """How one-sequence steps at d <= 32 are launched: 0 separate launches, 1 fused launches (four per step), 2 (default)
+        runs of steps in one launch where the shape allows (sbr_model_set_step_fusion).  Same bits."""
+        _check(self._L.sbr_model_set_step_fusion(self._h, int(level)))
 
     def set_overlap(self, on: bool = True):
         """False: side-stream work runs on the main stream, so kernel families are timed standalone."""

@@ -1359,44 +1359,57 @@ def test_bench_regime_two_devices_whole_step_full_parity():
     (ModelKind.EWMA, LOSS_HINGE, 32, 0, 128, 1683),              # the reference's ewma bench: scan + score + backward scan + tail in one launch
     (ModelKind.EWMA, LOSS_BPR, 16, OPT_ADAM, 60, 50),
 ])
-@pytest.mark.parametrize("fused", ["on", "off"])
-def test_one_sequence_steps_fused_launches(monkeypatch, kind, loss, d, opt, T, items, fused):
-    """One subsequence per optimiser step (the reference's own schedule, sequence_model.rs:111-169) at d <= 32 runs as four
-    launches: forward, score + [header, lagged loss figure, key ordering] (sbr::SmallTail), backward, and [dense gradient + dense
-    update + sparse update] (launch_small_back: the dense gradient as per-element row chains on the vector ALU instead of MFMA
-    accumulators); EWMA with a single-negative loss as two: [scan + score + backward scan + tail] and [dalpha + its update +
-    sparse update].  Whole fits against the oracle, bit for bit, with the fused forms and (fused = off, SBR_NO_SMALL_TAIL /
-    SBR_NO_SMALL_BACK) with the eight separate launches they replace."""
-    import subprocess
-    import sys
-    import textwrap
-
-    code = textwrap.dedent(f"""
-        import sys
-        sys.path.insert(0, "tests")
-        import numpy as np
-        from helpers import hparams, synthetic_interactions
-        from oracle.oracle import OracleModel
-        from sbr_rs_amd._abi import Param
-        from sbr_rs_amd.engine import Model
-        ptr, it = synthetic_interactions(14, {items}, {T} + 30, seed=31, min_len=3, zipf=True)
-        hp = hparams({items}, {T}, {d}, {int(kind)}, {loss}, B=1, epochs=2, opt={opt}, lr={0.02 if opt else 0.16})
-        g, o = Model(hp), OracleModel(hp)
+@pytest.mark.parametrize("fused", [2, 1, 0])
+def test_one_sequence_steps_fused_launches(kind, loss, d, opt, T, items, fused):
+    """One subsequence per optimiser step (the reference's own schedule, sequence_model.rs:111-169) at d <= 32.  fused = 1: four
+    launches per step — forward, score + [header, lagged loss figure, key ordering] (sbr::SmallTail), backward, and [dense gradient
+    + dense update + sparse update] (launch_small_back); EWMA with a single-negative loss two: [scan + score + backward scan + tail]
+    and [dalpha + its update + sparse update].  fused = 2 (the default): EWMA with a single-negative loss and Adagrad up to 128 rows
+    per step runs every epoch's steps in ONE launch (ewma_steps_kernel: one workgroup walks the steps, each step's working set in
+    LDS); everything else in the matrix takes the fused launches step by step.  fused = 0: the eight separate launches they
+    replace.  Whole fits (two epochs, then a second fit call on the same model) against the oracle, bit for bit, every parameter
+    and accumulator, the loss figures, and a representation computed from the re-emitted packed weight copies."""
+    ptr, it = synthetic_interactions(14, items, T + 30, seed=31, min_len=3, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, B=1, epochs=2, opt=opt, lr=0.02 if opt else 0.16)
+    g, o = Model(hp), OracleModel(hp)
+    g.set_step_fusion(fused)
+    params = [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC]
+    params += [Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC] if kind == ModelKind.EWMA else [Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC]
+    for call in range(2):
         lg, lo = g.fit(ptr, it), o.fit(ptr, it)
         assert abs(lg - lo) <= 1e-6 * abs(lo), (lg, lo)
         assert np.float32(g.last_fit_lagged_loss()).tobytes() == np.float32(o.last_fit_lagged_loss()).tobytes()
-        params = [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC]
-        params += [Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC] if {int(kind)} == 2 else [Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC]
         for q in params:
-            a, b = g.get_param(q), o.get_param(q)
-            assert a.tobytes() == b.tobytes(), q
-        hist = it[int(ptr[2]):int(ptr[3])]
-        assert g.user_representation(hist).tobytes() == o.user_representation(hist).tobytes()   # (the packed weight copies were re-emitted)
-        print("ok")
-    """)
-    env = dict(__import__("os").environ)
-    if fused == "off":  # the switches are read once per process
-        env["SBR_NO_SMALL_TAIL"] = env["SBR_NO_SMALL_BACK"] = "1"
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-800:] + r.stderr[-1500:]
+            assert g.get_param(q).tobytes() == o.get_param(q).tobytes(), (call, q)
+    hist = it[int(ptr[2]):int(ptr[3])]
+    assert g.user_representation(hist).tobytes() == o.user_representation(hist).tobytes()   # (the packed weight copies were re-emitted)
+
+
+@pytest.mark.parametrize("loss,d,T,items", [(LOSS_HINGE, 32, 128, 1683), (LOSS_BPR, 16, 129, 60), (LOSS_HINGE, 32, 12, 9)])
+def test_step_runs_in_one_launch_equal_single_steps(loss, d, T, items):
+    """sbr_fit_steps over arbitrary runs (a prefix, an empty run, the middle, the rest) equals the same steps taken one by one,
+    and the block of the last step stays readable (debug fetch, sparse stats) — the reference's ewma bench shape (T = 128, d = 32,
+    hinge, Adagrad), the largest step the one-launch form takes (128 rows, d = 16, BPR), and nine items (every row repeated many
+    times inside a step: long segments, bias and row shared by inputs, targets and negatives)."""
+    ptr, it = synthetic_interactions(40, items, T + 22, seed=5, min_len=3, zipf=True)
+    hp = hparams(items, T, d, int(ModelKind.EWMA), loss, B=1, epochs=1)
+    a, b = Model(hp), Model(hp)
+    b.set_step_fusion(1)
+    pa, pb = a.fit_begin(ptr, it), b.fit_begin(ptr, it)
+    n = pa.epoch_prepare()
+    assert pb.epoch_prepare() == n and n > 12
+    pa.steps(0, 5); pa.steps(5, 0); pa.steps(5, n - 7); pa.steps(n - 2, 2)
+    assert pa.phase_clocks()[5] == n   # every step went through the one-launch form
+    for mb in range(n):
+        pb.step(mb)
+    assert pb.phase_clocks()[5] == 0
+    rows = pa.minibatch_rows(n - 1)
+    for w in (Debug.IN_IDX, Debug.OUT_IDX, Debug.HIDDEN, Debug.NEGATIVES, Debug.COEF, Debug.DINPUT, Debug.DENSE_GRAD, Debug.LOSS, Debug.TRIES):
+        assert pa.debug_fetch(w, rows).tobytes() == pb.debug_fetch(w, rows).tobytes(), w
+    assert pa.sparse_stats() == pb.sparse_stats()
+    assert pa.counters() == pb.counters()
+    assert pa.end_lagged() == pb.end_lagged()
+    assert pa.end() == pb.end()
+    for q in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC):
+        assert a.get_param(q).tobytes() == b.get_param(q).tobytes(), q
+    assert a.counters() == b.counters()

@@ -1005,25 +1005,36 @@ static void orc_reduce_row(const orc_entry* ent, uint64_t i, uint64_t j, int d, 
  *  Adagrad update (with L2) per touched row, also for rows whose summed data-gradient is zero
  *  (SURVEY App. A-14); biases likewise for target/negative rows. */
 /* one optimiser step from ONE worker's gradients: its dense gradient, then its sparse entries per row */
+/* per-thread scratch of orc_apply_gradients, grown on demand and kept: the timed baseline (orc_fit_threads) takes one optimiser
+ * step per ~30-row subsequence on every worker, and four malloc / free pairs per step are serialisation the reference does not have */
+static __thread float* orc_tls_dense = NULL;
+static __thread uint64_t orc_tls_dense_cap = 0;
+static __thread orc_entry* orc_tls_ent = NULL;
+static __thread uint64_t orc_tls_ent_cap = 0;
+static __thread float* orc_tls_row = NULL; /* gsum | part */
+static __thread int orc_tls_row_cap = 0;
+
 static void orc_apply_gradients(orc_model* m, uint32_t R, const uint32_t* in_idx, const uint32_t* out_idx, const uint32_t* neg,
                                 const orc_entry_src* es, const float* dense) {
     int d = m->d;
     uint64_t nd = orc_ndense(m);
     orc_begin_optimizer_step(m);
-    float* dg = (float*)malloc(nd * 4);
+    if (nd > orc_tls_dense_cap) { free(orc_tls_dense); orc_tls_dense = (float*)malloc(nd * 4); orc_tls_dense_cap = nd; }
+    float* dg = orc_tls_dense;
     memcpy(dg, dense, nd * 4);
     orc_dense_update(m, dg);
-    free(dg);
     uint64_t ne = 3ull * R;
-    orc_entry* ent = (orc_entry*)malloc(sizeof(orc_entry) * (ne ? ne : 1));
+    if (ne + 1 > orc_tls_ent_cap) { free(orc_tls_ent); orc_tls_ent_cap = 2 * (ne + 1); orc_tls_ent = (orc_entry*)malloc(sizeof(orc_entry) * orc_tls_ent_cap); }
+    orc_entry* ent = orc_tls_ent;
     for (uint32_t r = 0; r < R; ++r) {
         ent[3 * r].row = in_idx[r]; ent[3 * r].src = 3u * r;
         ent[3 * r + 1].row = out_idx[r]; ent[3 * r + 1].src = 3u * r + 1;
         ent[3 * r + 2].row = neg[r]; ent[3 * r + 2].src = 3u * r + 2;
     }
     qsort(ent, ne, sizeof(orc_entry), orc_entry_cmp);
-    float* gsum = (float*)malloc(sizeof(float) * d);
-    float* part = (float*)malloc(sizeof(float) * d);
+    if (d > orc_tls_row_cap) { free(orc_tls_row); orc_tls_row = (float*)malloc(sizeof(float) * 2 * d); orc_tls_row_cap = d; }
+    float* gsum = orc_tls_row;
+    float* part = orc_tls_row + d;
     uint64_t i = 0;
     while (i < ne) {
         uint32_t row = ent[i].row;
@@ -1034,7 +1045,6 @@ static void orc_apply_gradients(orc_model* m, uint32_t R, const uint32_t* in_idx
         orc_row_update(m, row, gsum, 1, has_b, gb);
         i = j;
     }
-    free(part); free(gsum); free(ent);
 }
 
 static int orc_apply_own_block(orc_plan* p, const void* block, int q) {

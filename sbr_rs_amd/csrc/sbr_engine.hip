@@ -60,10 +60,7 @@ struct ScratchCache {
     std::vector<Blk> idle;
     std::unordered_map<void*, Blk> live;
     size_t cached[2] = {0, 0}; /* device, pinned host */
-    static bool enabled() {
-        static const bool on = !std::getenv("SBR_NO_SCRATCH_CACHE"); /* A/B switch */
-        return on;
-    }
+    static bool enabled() { return true; }
     hipError_t get(void** out, size_t bytes, bool host) {
         *out = nullptr;
         bytes = (bytes + 255) & ~(size_t)255;
@@ -564,7 +561,7 @@ struct WorkBuffers {
 sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool training, WorkBuffers* wb) {
     const uint64_t d = (uint64_t)m->d;
     sbr::WorkView& v = wb->v;
-    v.fold_max_tiles = std::getenv("SBR_FOLD_MAX_TILES") ? std::atoi(std::getenv("SBR_FOLD_MAX_TILES")) : SBR_FOLD_MAX_TILES_DEFAULT;
+    v.fold_max_tiles = SBR_FOLD_MAX_TILES_DEFAULT;
     if (m->ng) {
         SBRCHK(dmalloc(&v.C, rmax * d));
         SBRCHK(dmalloc(&v.G, rmax * d * 4));
@@ -787,10 +784,9 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
      * backward pass, whose workgroups fill every CU, so that the sort's kernels only run in slots that retiring
      * workgroups free — delayed the GEMM, which does not need the sorted keys, by 0.36 ms per step.  Priority: normal
      * (13.42-13.50 ms per step; high 13.62-13.74: the sort then wins every freed slot and the backward pass loses more
-     * than the update gains; low 13.58-13.63).  SBR_SORT_PRIO = high | normal | low is the A/B switch. */
-    const char* sort_prio_env = std::getenv("SBR_SORT_PRIO");
-    const int sort_prio = !sort_prio_env || sort_prio_env[0] == 'n' ? 0 : sort_prio_env[0] == 'h' ? prio_greatest : prio_least;
-    if (hipStreamCreateWithPriority(&m->sorter, hipStreamNonBlocking, sort_prio) != hipSuccess) { delete m; return SBR_ERR_HIP; }
+     * than the update gains; low 13.58-13.63). */
+    (void)prio_greatest;
+    if (hipStreamCreateWithPriority(&m->sorter, hipStreamNonBlocking, 0) != hipSuccess) { delete m; return SBR_ERR_HIP; }
     if (hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -1148,14 +1144,6 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
                          sbr_fit_plan** out) {
     if (!m || !user_ptr || !out) return SBR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    static const bool prof = std::getenv("SBR_PROF_FIT") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto tick = [&](const char* what) {
-        if (!prof) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[fit_begin] %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-        t_prev = now;
-    };
     SBRCHK(ensure_device(m));
     const uint64_t T = m->hp.max_sequence_length;
     for (uint64_t u = 0; u < num_users; ++u)
@@ -1198,14 +1186,11 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         sbr_xs_seed(&p->part_rng[q], seed);
         p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
     }
-    tick("host lists");
     p->items.assign(item_ids, item_ids + nnz);
     p->bmax = m->hp.batch_sequences;
     p->rmax = p->bmax * (T - 1);
     if (3 * p->rmax >= (1ull << 32) || part * T >= (1ull << 32)) { delete p; return SBR_ERR_INVALID_ARGUMENT; }
-    tick("plan host");
     sbr_status st = alloc_work(m, p->rmax, p->bmax, true, &p->wb);
-    tick("alloc_work");
     if (st == SBR_OK) { p->block_bytes = block_bytes_for(m, p->rmax); st = dmalloc(&p->block, p->block_bytes); }
     const uint64_t max_entries = 3 * p->rmax; /* only a device's own entries are ever sorted */
     int item_bits = 1;
@@ -1241,10 +1226,8 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         if (st == SBR_OK) st = dmalloc(&p->seg.head_pos, max_entries + 1);
         if (st == SBR_OK) st = dmalloc(&p->seg.nheads, 1);
     }
-    tick("allocs");
     if (st == SBR_OK && !m->copier && hipStreamCreateWithFlags(&m->copier, hipStreamNonBlocking) != hipSuccess) st = SBR_ERR_HIP;
     p->copy_stream = m->copier;
-    tick("copy stream");
     for (int i = 0; i < 2 && st == SBR_OK; ++i)
         if (hipEventCreateWithFlags(&p->ep[i].free_event, hipEventDisableTiming) != hipSuccess) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->lag_state, 1 + 2 * T); /* accumulator + (node, staged value) per step: sbr_report.hip */
@@ -1261,27 +1244,17 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     hipMemsetAsync(p->loss_acc, 0, 17 * sizeof(double), m->stream);
     hipMemsetAsync(p->ex_acc, 0, 18 * sizeof(unsigned long long), m->stream);
     hipMemsetAsync(p->block, 0, p->block_bytes, m->stream);
-    tick("events+memsets");
     *out = p;
     return SBR_OK;
 }
 
 void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     if (!p) return;
-    static const bool prof = std::getenv("SBR_PROF_FIT") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto tick = [&](const char* what) {
-        if (!prof) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[plan_destroy] %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
-        t_prev = now;
-    };
     hipSetDevice(p->m->device);
     if (p->pending) { p->worker.join(); p->pending = false; }
     hipStreamSynchronize(p->m->side);
     hipStreamSynchronize(p->m->sorter);
     hipStreamSynchronize(p->m->stream);
-    tick("join+sync");
     for (int i = 0; i < 2; ++i) {
         p->ep[i].dp.release();
         dfree(p->ep[i].d_desc);
@@ -1289,9 +1262,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
         hfree(p->ep[i].h_in); hfree(p->ep[i].h_out); hfree(p->ep[i].h_ctr);
         hfree(p->ep[i].h_prev); hfree(p->ep[i].h_steps);
     }
-    tick("epoch buffers");
     if (p->copy_stream) hipStreamSynchronize(p->copy_stream); /* the model's: stays */
-    tick("copy stream");
     p->wb.release();
     for (auto& px : p->xchg_peer) for (auto& b : px) b.release();
     for (auto& b : p->xchg_own) b.release();
@@ -1311,9 +1282,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     dfree(p->seg.head_pos); dfree(p->seg.nheads);
     dfree(p->glist); dfree(p->gblist); dfree(p->gfl); dfree(p->bounds_dev);
     dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp);
-    tick("frees");
     delete p;
-    tick("delete");
 }
 
 /* Host side of one epoch: ≙ thread_rng.shuffle(partition) (sequence_model.rs:109) for every
@@ -1536,33 +1505,27 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* A small step (its sparse update is the single-launch form: <= 4 096 keys) is a chain of launches of a few microseconds
      * each; the event hand-offs between three streams then cost more than the overlap buys (MovieLens-100K at one sequence per
      * step: 1.67 s with the side streams, 1.57 s on one), so everything is queued on the main stream. */
-    static const char* small_env = std::getenv("SBR_SMALL_STEP_ROWS");
-    const int small_rows = small_env ? std::atoi(small_env) : 1365;
+    constexpr int small_rows = 1365;
     const bool overlap = m->overlap && mb.R > small_rows;
     hipStream_t side = overlap ? m->side : m->stream;
-    /* Where the key ordering of a WARP step runs (its negatives come out of the score kernel).  SBR_SORT_PLACE:
-     *   stream  its own stream from the end of the score kernel on: it takes whatever slots the backward pass's retiring
-     *           workgroups free, and is finished by the time the update needs the keys
-     *   pre     the main stream between score and backward pass (its ~0.1-0.2 ms are then on the critical path)
-     *   post    the main stream right after the backward pass, beside the start of the dense-gradient GEMM */
-    static const char* place_env = std::getenv("SBR_SORT_PLACE");
-    enum { SORT_OWN_STREAM, SORT_PRE, SORT_POST };
-    const int place = !overlap ? SORT_PRE : !place_env ? SORT_OWN_STREAM : !std::strcmp(place_env, "pre") ? SORT_PRE : !std::strcmp(place_env, "post") ? SORT_POST : SORT_OWN_STREAM;
+    /* Where the key ordering of a WARP step runs (its negatives come out of the score kernel): on its own stream from the end of the
+     * score kernel on — it takes whatever slots the backward pass's retiring workgroups free, and is finished by the time the update
+     * needs the keys; a small step (everything on one stream) orders between score and backward pass.  (Measured and dropped: the
+     * main stream before or right after the backward pass for large steps — its 0.1-0.3 ms are then on the critical path;
+     * profiles/r04_tail_experiments.md (c).) */
+    enum { SORT_OWN_STREAM, SORT_PRE };
+    const int place = overlap ? SORT_OWN_STREAM : SORT_PRE;
     hipStream_t sorter = place == SORT_OWN_STREAM ? m->sorter : m->stream;
-    const bool early_sort = m->hp.loss != SBR_LOSS_WARP && !std::getenv("SBR_NO_EARLY_SORT"); /* the variable is the A/B switch */
+    const bool early_sort = m->hp.loss != SBR_LOSS_WARP;
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
     /* WARP step with the ordering on its own stream: the per-sequence loss sums and the block header (row count, loss sum; the
      * single-device accumulators) are queued on THAT stream, behind the score kernel's event and ahead of the ordering — between
      * score and BPTT they were two launches and their gaps (~35 us of a 2.5 ms step) on the critical path for nobody's benefit.
-     * Their consumers (update / scatter / dense / fit_end) all join the ordering's stream first.  SBR_HEADER_ON_MAIN=1: the old place. */
-    static const bool header_on_main = std::getenv("SBR_HEADER_ON_MAIN") != nullptr;
-    const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM && !header_on_main;
+     * Their consumers (update / scatter / dense / fit_end) all join the ordering's stream first. */
+    const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM;
     /* ONE subsequence per step at d <= 32 (the reference's own schedule): header, lagged loss figure and the ordering of the step's
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
-    static const char* ewma_env0 = std::getenv("SBR_EWMA_FUSED");
-    const bool ewma_seq_pass = !m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0 && (ewma_env0 ? std::atoi(ewma_env0) : SBR_EWMA_FUSED_DEFAULT) != 0;
     const bool small_tail = m->step_fusion >= 1 && !overlap && p->ndev == 1 && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
-    (void)ewma_seq_pass;
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
@@ -1608,9 +1571,8 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         p->sort_off_stream = false;
     }
     /* EWMA + single-negative loss (BASELINE configs[4]): scan and score in one pass per sequence, optionally the backward scan too
-     * (SBR_EWMA_FUSED = 0: three launches / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
-    static const char* ewma_env = std::getenv("SBR_EWMA_FUSED");
-    int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? (ewma_env ? std::atoi(ewma_env) : SBR_EWMA_FUSED_DEFAULT) : 0;
+     * (0: three launches — EWMA + WARP / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
+    int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? SBR_EWMA_FUSED_DEFAULT : 0;
     if (ewma_fused && small_tail) ewma_fused = 2; /* a one-sequence step: the backward scan rides along as well */
     if (ewma_fused) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
@@ -1679,7 +1641,6 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         ScopedTimer t(m, SBR_K_DENSE_GRAD, 1, side);
         p->dense_unreduced_chunks = sbr::launch_dense_gradient(m->mv, mv, bv, p->wb.v, mb.R, mb.B, side, /*defer_reduce=*/p->ndev == 1);
     }
-    if (!early_sort && place == SORT_POST && !small_tail) SBRCHK(launch_sort(m->stream));
     if (side != m->stream) HIPCHK(hipEventRecord(m->ev_join, side));
     p->dense_pending = side != m->stream;
     if (!fuse_lag) {
@@ -2869,7 +2830,7 @@ sbr_status forward_histories(sbr_model* m, const std::vector<const uint32_t*>& f
     dp.prev_row = ar.take<int>(R); dp.off = ar.take<int>(pk.off.size()); dp.steps = ar.take<int>((size_t)pk.B);
     float* H = ar.take<float>(R * d);
     WorkBuffers wb;
-    wb.v.fold_max_tiles = std::getenv("SBR_FOLD_MAX_TILES") ? std::atoi(std::getenv("SBR_FOLD_MAX_TILES")) : SBR_FOLD_MAX_TILES_DEFAULT;
+    wb.v.fold_max_tiles = SBR_FOLD_MAX_TILES_DEFAULT;
     if (m->ng) {
         wb.v.C = ar.take<float>(R * d);
         wb.v.G = ar.take<float>(R * d * 4);
@@ -2960,12 +2921,8 @@ sbr_status sbr_mrr_score(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     std::vector<uint32_t> ranks(users.size(), 0);
     /* users per scoring launch: the rank GEMM streams the item table once per 128 users whatever the launch size, but every
      * launch has its ramp and tail — 8 192 users x 1e6 items at d = 128: 104 / 108 / 109 / 112 TFLOP/s at 1 024 / 2 048 /
-     * 4 096 / 8 192 users per launch (SBR_EVAL_USERS overrides: the A/B switch) */
-    static const size_t EVAL_B = []() -> size_t {
-        const char* e = std::getenv("SBR_EVAL_USERS");
-        const long v = e ? std::atol(e) : 0;
-        return v >= 128 ? (size_t)v : 8192; /* unset, non-numeric or tiny: the default (a zero step would never advance) */
-    }();
+     * 4 096 / 8 192 users per launch */
+    constexpr size_t EVAL_B = 8192;
     /* the forward pass's scratch is (users x history steps) rows of 6d floats: bound a launch by rows as well */
     const size_t eval_rows_cap = (size_t)1 << 22;
     for (size_t c0 = 0, c1 = 0; c0 < users.size(); c0 = c1) {

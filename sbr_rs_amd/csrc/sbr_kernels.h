@@ -53,7 +53,7 @@ struct ModelView {
  * 256 reversed): with about as many tiles as resident slots (512) every CU then gets long + short.  ms per step on one box,
  * folded / not: 375 tiles 2.29 / 2.55, 512 tiles 2.65 / 2.97 (BPTT alone 0.72 / 0.91 — it had no fold before), 625 tiles 3.16 /
  * 3.33, 750 and 1 024 tiles equal; with several rounds of tiles the dispatcher's own order — longest first, next tile to the
- * first free slot — is the better schedule: 1 563 tiles 13.65 / 13.53.  SBR_FOLD_MAX_TILES overrides. */
+ * first free slot — is the better schedule: 1 563 tiles 13.65 / 13.53. */
 #define SBR_FOLD_MAX_TILES_DEFAULT 1024
 struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     float *C, *G, *dH, *dZ;
@@ -66,7 +66,7 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
     unsigned int* part_tries;
     float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM, 64-bit address path) */
-    int fold_max_tiles;     /* the recurrent kernels fold their length-sorted tile list up to this many tiles (SBR_FOLD_MAX_TILES) */
+    int fold_max_tiles;     /* the recurrent kernels fold their length-sorted tile list up to this many tiles */
     int wide_addresses;     /* 1: the dense-gradient GEMM takes its 64-bit per-lane address path even where the buffer path would do (tests) */
 };
 

@@ -3547,7 +3547,7 @@ __global__ void selftest_mfma32_chain_kernel(const float* a, const float* b, int
 #define SBR_RESIDENT_WG_PER_CU 7
 #endif
 static inline int grid_for_groups(long long groups, int groups_per_block) {
-    static const int per_cu = std::getenv("SBR_RESIDENT_WG_PER_CU") ? std::atoi(std::getenv("SBR_RESIDENT_WG_PER_CU")) : SBR_RESIDENT_WG_PER_CU;
+    constexpr int per_cu = SBR_RESIDENT_WG_PER_CU;
     long long g = (groups + groups_per_block - 1) / groups_per_block;
     if (g < 1) g = 1;
     if (g > 256 * per_cu) g = 256 * per_cu;
@@ -3798,9 +3798,8 @@ int launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView&
          * are out of range and read as zeros; on its 64-bit address path they are cleared here */
         const bool buffer_path = DD >= 128 && !w.wide_addresses && (size_t)rows_host * DD * 4 < ((size_t)1 << 31);
         const size_t pad_rows = buffer_path ? 0 : (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
-        /* SBR_DW_LDS_PAD: extra dynamic LDS per workgroup = a cap on the kernel's residency (20 KB static: 32 KB more leave
-         * three workgroups per CU instead of four, and room for the sparse update's waves beside them) */
-        static const int lds_pad = std::getenv("SBR_DW_LDS_PAD") ? std::atoi(std::getenv("SBR_DW_LDS_PAD")) : 0;
+        constexpr int lds_pad = 0; /* (a residency cap through extra dynamic LDS — three workgroups per CU instead of four, room for
+                                    * the sparse update's waves beside them — measured and dropped: profiles/r03_dw_experiments.md) */
         if (m.ng == 4) {
             if constexpr (full4) {
                 if (pad_rows) (void)hipMemsetAsync(w.dZ + (size_t)rows_host * NGD, 0, pad_rows * NGD * sizeof(float), s);
@@ -3873,7 +3872,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
         /* 4 workgroups per CU: with 8 the update's waves fill the register file and the dense-gradient GEMM on the side
          * stream cannot become resident beside it (measured: 14.04 ms per step at 2048, 13.92 at 1024; the update alone
          * takes the same 1.13-1.2 ms either way) */
-        static const int seg_grid_cap = std::getenv("SBR_SEG_GRID") ? std::atoi(std::getenv("SBR_SEG_GRID")) : 1024;
+        constexpr int seg_grid_cap = 1024;
         int seg_grid = grid_for_groups((long long)total / 2 + 1, gpb);
         if (seg_grid > seg_grid_cap) seg_grid = seg_grid_cap;
         hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(seg_grid), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);
@@ -4018,15 +4017,13 @@ void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint
                  const uint32_t* test_in_hist, const uint64_t* hist_ptr, const uint32_t* hist_items, float* ts_scratch,
                  uint32_t* ranks, uint32_t* nonfinite_flag, hipStream_t s) {
     if (num_users == 0) return;
-    // 32 users per wave (128 per workgroup, four waves per SIMD); SBR_RANK_UW = 2 selects the 64-users-per-wave form (half the
-    // barriers and LDS fills per flop at half the waves), which measured 5 % slower — kept as the A/B and test switch
-    static const int uw_env = std::getenv("SBR_RANK_UW") ? std::atoi(std::getenv("SBR_RANK_UW")) : 0;
-    const int uw = m.d > 128 ? 1 : uw_env ? uw_env : 1; /* measured at 8 192 users x 1e6 items, d = 128: 105 TFLOP/s with 32 users per wave, 100 with 64 */
-    const uint32_t wgu = 128u * (uint32_t)uw;
+    // 32 users per wave (128 per workgroup, four waves per SIMD).  (A 64-users-per-wave form — half the barriers and LDS fills per
+    // flop at half the waves — measured 5 % slower at 8 192 users x 1e6 items, d = 128: 100 against 105 TFLOP/s; removed.)
+    const uint32_t wgu = 128u;
     const uint32_t utiles = (num_users + wgu - 1) / wgu;
     // item groups: at least one 32-item tile each, and MANY more workgroups than the chip holds at once (a launch of
     // 1 024 workgroups on 768 resident slots ran one full round and a third of a second one)
-    static const uint32_t target_wgs = std::getenv("SBR_RANK_WGS") ? (uint32_t)std::atoi(std::getenv("SBR_RANK_WGS")) : 768u * 6u;
+    constexpr uint32_t target_wgs = 768u * 6u;
     uint32_t groups = (target_wgs + utiles - 1) / utiles;
     const uint32_t max_groups = (m.num_items + 31) / 32;
     if (groups > max_groups) groups = max_groups;
@@ -4037,12 +4034,7 @@ void launch_rank(const ModelView& m, const float* reps, const int* rep_row, uint
     groups = (m.num_items + per - 1) / per;
     DISPATCH_D(m.d, {
         hipLaunchKernelGGL((rank_test_score_kernel<DD>), dim3((num_users + 255) / 256), dim3(256), 0, s, m, reps, rep_row, num_users, test_item, test_in_hist, ts_scratch, ranks);
-        if constexpr (DD <= 128) {
-            if (uw == 2) hipLaunchKernelGGL((rank_gemm_kernel<DD, 2>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
-            else hipLaunchKernelGGL((rank_gemm_kernel<DD, 1>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
-        } else {
-            hipLaunchKernelGGL((rank_gemm_kernel<DD, 1>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
-        }
+        hipLaunchKernelGGL((rank_gemm_kernel<DD, 1>), dim3(utiles, groups), dim3(256), 0, s, m, reps, rep_row, num_users, ts_scratch, per, ranks, nonfinite_flag);
         hipLaunchKernelGGL((rank_history_kernel<DD>), dim3(num_users), dim3(64), 0, s, m, reps, rep_row, ts_scratch, hist_ptr, hist_items, ranks);
     });
 }

@@ -547,7 +547,7 @@ def main():
                     help="subsequences per optimiser step and GPU.  Default: the QUALITY-NEUTRAL batch — the largest one with unchanged "
                          "test MRR in the committed sweep (profiles/quality_neutral_batch.json: 8 192 for the LSTM; EWMA's MRR does not "
                          "fall up to 50 000, its default).  The 50 000-sequence figure (two optimiser steps per epoch of configs[2]: "
-                         "the hardware's throughput regime, where the LSTM gives up a quarter of its MRR at equal epochs, DESIGN.md §3) "
+                         "the hardware's throughput regime, where the LSTM gives up a quarter of its MRR at equal epochs, NOTES.md §3) "
                          "is reported beside it as `value_max_batch`.")
     ap.add_argument("--item-distribution", choices=["uniform", "zipf"], default="uniform",
                     help="uniform = the pure-roofline run (no cache reuse); zipf = Zipf(1.0) over a permuted catalogue")
@@ -656,7 +656,7 @@ def main():
             batch_rule = f"default: the quality-neutral batch ({qn['table']}: {qn['criterion']})"
         else:
             args.batch_sequences = MAX_BATCH
-            batch_rule = "default: 50 000 (EWMA: test MRR does not fall with the batch, DESIGN.md section 3)" if model_kind == 2 else "default: 50 000"
+            batch_rule = "default: 50 000 (EWMA: test MRR does not fall with the batch, NOTES.md section 3)" if model_kind == 2 else "default: 50 000"
     if args.driver == "group":
         if world != 1:
             raise SystemExit("--driver group runs in one process (no launcher)")
@@ -1006,7 +1006,7 @@ def main():
                 out["value_max_batch"] = {"value": top[0]["interactions_per_s"], "unit": "interactions/s", "ms_per_step": top[0]["ms_per_step"],
                                           "batch_sequences_per_gpu": MAX_BATCH, "score_kernel_roofline": top[0].get("score_kernel"),
                                           "note": "two optimiser steps per epoch of this workload: the hardware's throughput regime; at equal epochs the "
-                                                  "LSTM's test MRR is a quarter lower there (DESIGN.md section 3), so it is not the headline"}
+                                                  "LSTM's test MRR is a quarter lower there (NOTES.md section 3), so it is not the headline"}
                 if top[0].get("score_kernel") and isinstance(out.get("roofline"), dict) and args.batch_sequences != MAX_BATCH:
                     # the same kernel where its launch is long enough to be bytes-bound: at the headline's ~256 K rows a launch is
                     # ~20 us of fixed cost (dispatch, ramp, drain) + rows at 0.62 of the peak (profiles/r04_tail_experiments.md)

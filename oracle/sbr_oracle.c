@@ -55,7 +55,7 @@ typedef struct orc_model {
      *       then each update goes in under exclusion — N Adagrad applications, G += g_q^2 each), where the contract adds
      *       the devices' gradients and applies one update.
      * batch_sequences must be 1 (the reference's schedule).  Used to measure whether the substitutions move test MRR
-     * (tools/mrr_stream_sweep.py --reference-order). */
+     * (tools/mrr_stream_sweep.py --reference-order, NOTES.md section 3). */
     int reference_order;
     float last_lagged_loss; /* orc_fit_end_lagged of the last orc_model_fit */
 } orc_model;

@@ -110,7 +110,7 @@ def test_movielens_mrr_bounds(oracle_lib, name, kind, loss, threads, ref_bounds)
     user_based_split 0.2, the SAME advanced RNG moved into the model, max_len 128, dim 32, lr 0.16,
     l2 4e-4, Adagrad, 10 epochs; batch_sequences = 1 is the reference's per-sequence SGD.  The bound is
     the reference's own (CI branch).  Test MRR over 188 users has a stream-to-stream standard deviation
-    of ~0.01 on this split (24 model streams per case, means 0.089 / 0.085 / 0.100 / 0.106 /
+    of ~0.01 on this split (NOTES.md §3: 24 model streams per case, means 0.089 / 0.085 / 0.100 / 0.106 /
     0.127), which is why the reference itself carries two thresholds per case."""
     data, train, test, rng = movielens_protocol()
     hp = hparams(data.num_items(), 128, 32, int(kind), loss, epochs=10, B=1, seed=rng.state_seed(), ndev=threads)

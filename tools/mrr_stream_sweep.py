@@ -16,7 +16,7 @@ updates — which is why the reference itself carries two thresholds per case (d
 --split varying  seed [k; 16] for the split as well (different test users every time).
 
 Prints mean / sd / min / max per case next to the reference's bounds.  Results of this script are quoted in
-DESIGN.md section 3.
+NOTES.md section 3.
 """
 import argparse
 import os

@@ -14,7 +14,7 @@ users (the reference's protocol: unseen users, history = all but the last item, 
                                  [--json profiles/quality_neutral_batch.json]
 
 Runs on the GPU engine (this is a statement about the optimisation regime, not a parity test).  Prints one
-markdown table (mean +- sd over the model seeds); the numbers are quoted in DESIGN.md section 3.  --json writes the
+markdown table (mean +- sd over the model seeds); the numbers are quoted in NOTES.md section 3.  --json writes the
 largest batch whose mean LSTM test MRR is within 3 % of the smallest batch's — what bench.py reports as
 `value_quality_neutral`.
 """

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one optimiser step under environment switches (DESIGN.md section 7 "A/B switches"): every line is one bench.py process,
+# A/B of one optimiser step under build variants / test hooks (DESIGN.md section 7 "Switches"; the round 1-4 A/B variables are gone): every line is one bench.py process,
 #   tools/step_ab.sh OUT.jsonl "B1 B2 ..." "ENV1=a ENV2=b" "ENV1=c" ...
 # prints batch, switches, ms per step and the per-family kernel times.  None of the switches changes a result bit.
 out=$1; shift

@@ -419,6 +419,7 @@ struct sbr_model {
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     float last_lagged_loss = 0.0f; /* what the reference's fit would have returned for the last sbr_model_fit / sbr_group_fit */
+    bool reference_order = false; /* sbr_model_set_reference_order: negatives from the worker's sequential stream (one sequence per step) */
     int step_fusion = 2; /* one-sequence steps at d <= 32 (sbr_model_set_step_fusion): 0 separate launches, 1 fused launches
                           * (SmallTail + small_back: four per step), 2 runs of steps in one launch where the shape allows */
     DeviceArena eval_arena;        /* prediction-side scratch (guarded by mu) */
@@ -639,6 +640,8 @@ struct sbr_fit_plan {
     int key_bits = 64;
     double* loss_acc = nullptr;
     unsigned long long* ex_acc = nullptr;
+    uint32_t* ref_rng = nullptr;   /* reference order: the worker's xorshift128 state on the device (advanced by the score launch) */
+    bool ref_rng_live = false;     /* ... and it has been advanced since the host last held it */
     unsigned long long* phase_clocks = nullptr; /* [6] epoch_steps_kernel's per-phase s_memtime ticks + steps (sbr_fit_debug_phase_clocks) */
     sbr::SegScratch seg{}; /* long-segment path of the sparse reduction (hot rows) */
     bool dense_pending = false; /* the side stream still owes blk.dense */
@@ -1184,7 +1187,8 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
         uint8_t seed[16];
         sbr_rand_gen_seed16(&m->rng, seed);
         sbr_xs_seed(&p->part_rng[q], seed);
-        p->fit_seed[q] = sbr_xs_u64(&p->part_rng[q]);
+        /* (reference order: the worker's stream is not touched here — its first use is the first epoch's shuffle, :109) */
+        p->fit_seed[q] = m->reference_order ? 0 : sbr_xs_u64(&p->part_rng[q]);
     }
     p->items.assign(item_ids, item_ids + nnz);
     p->bmax = m->hp.batch_sequences;
@@ -1236,6 +1240,7 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
                          hipEventCreateWithFlags(&p->ev_lagged, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&p->ev_hot, hipEventDisableTiming) != hipSuccess)) st = SBR_ERR_HIP;
     if (st == SBR_OK) st = dmalloc(&p->loss_acc, 17);  /* [0] all devices, [1 + q] device q */
+    if (st == SBR_OK && m->reference_order) st = dmalloc(&p->ref_rng, 4);
     if (st == SBR_OK) st = dmalloc(&p->phase_clocks, 6);
     if (st == SBR_OK) hipMemsetAsync(p->phase_clocks, 0, 6 * sizeof(unsigned long long), m->stream);
     if (st == SBR_OK) st = dmalloc(&p->ex_acc, 18);    /* [0] examples, [1] negatives scored, [2 + q] examples of device q */
@@ -1272,7 +1277,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
         p->keys_sorted = nullptr; p->glist = p->gblist = nullptr; p->gfl = nullptr;
     }
     dfree(p->block); dfree(p->keys); dfree(p->keys_sorted); dfree(p->sort_temp);
-    dfree(p->loss_acc); dfree(p->ex_acc); dfree(p->phase_clocks);
+    dfree(p->loss_acc); dfree(p->ex_acc); dfree(p->phase_clocks); dfree(p->ref_rng);
     dfree(p->lag_state); dfree(p->lag_seqsum);
     if (p->ev_seqsum) hipEventDestroy(p->ev_seqsum);
     if (p->ev_lagged) hipEventDestroy(p->ev_lagged);
@@ -1291,9 +1296,22 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
 static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
     sbr_model* m = p->m;
     HIPCHK(hipSetDevice(m->device));
+    if (p->ref_rng && p->ref_rng_live) { /* reference order: the stream the steps drew from shuffles the next epoch (:109) */
+        HIPCHK(hipStreamSynchronize(m->stream));
+        uint32_t st4w[4];
+        HIPCHK(hipMemcpy(st4w, p->ref_rng, sizeof(st4w), hipMemcpyDeviceToHost));
+        sbr_xorshift& r = p->part_rng[p->rank];
+        r.x = st4w[0]; r.y = st4w[1]; r.z = st4w[2]; r.w = st4w[3];
+        p->ref_rng_live = false;
+    }
     for (int q = 0; q < p->ndev; ++q)
         shuffle_pairs(p->seq_start.data() + (size_t)q * p->part_len, p->seq_len.data() + (size_t)q * p->part_len,
                       p->part_len, &p->part_rng[q]);
+    if (p->ref_rng) {
+        const sbr_xorshift& r = p->part_rng[p->rank];
+        const uint32_t st4w[4] = {r.x, r.y, r.z, r.w};
+        HIPCHK(hipMemcpy(p->ref_rng, st4w, sizeof(st4w), hipMemcpyHostToDevice));
+    }
     e.epoch_key_epoch = m->global_epoch;
     m->global_epoch += 1;
     const uint64_t B = p->bmax;
@@ -1459,6 +1477,7 @@ sbr_status sbr_fit_epoch_prepare(sbr_fit_plan* p, uint64_t* out_num_minibatches)
 
 sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p) {
     if (!p || p->pending) return SBR_ERR_INVALID_ARGUMENT;
+    if (p->ref_rng) return SBR_OK; /* reference order: the next epoch's shuffle continues the stream this epoch's steps draw from */
     p->pending = true;
     p->pending_status = SBR_OK;
     p->worker = std::thread([p]() { p->pending_status = build_epoch(p, p->ep[p->cur ^ 1]); });
@@ -1525,7 +1544,8 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM;
     /* ONE subsequence per step at d <= 32 (the reference's own schedule): header, lagged loss figure and the ordering of the step's
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
-    const bool small_tail = m->step_fusion >= 1 && !overlap && p->ndev == 1 && sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
+    const bool small_tail = (m->step_fusion >= 1 || m->reference_order) && !overlap && p->ndev == 1 &&
+                            sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
@@ -1574,6 +1594,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
      * (0: three launches — EWMA + WARP / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
     int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? SBR_EWMA_FUSED_DEFAULT : 0;
     if (ewma_fused && small_tail) ewma_fused = 2; /* a one-sequence step: the backward scan rides along as well */
+    if (m->reference_order) ewma_fused = 0;       /* scan, then the sequential-stream scorer, then the backward scan */
     if (ewma_fused) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
         p->header_accumulated = p->ndev == 1;
@@ -1590,7 +1611,13 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
             p->header_accumulated = p->ndev == 1;
             const sbr::SmallTail tail{bv.header, p->header_accumulated ? p->loss_acc : nullptr, p->header_accumulated ? p->ex_acc : nullptr,
                                       p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
-            sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream, small_tail ? &tail : nullptr);
+            if (m->reference_order) {
+                if (!p->ref_rng || !small_tail || !sbr::launch_score_reference_order(m->mv, mv, bv, p->wb.v, p->ref_rng, mb.R, m->stream, tail))
+                    return SBR_ERR_UNSUPPORTED;
+                p->ref_rng_live = true;
+            } else {
+                sbr::launch_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream, small_tail ? &tail : nullptr);
+            }
         }
     }
     /* the figure the reference's fit returns (sbr_report.hip): a small step folds it into the header launch; otherwise the
@@ -1727,7 +1754,7 @@ sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count) {
     sbr_fit_plan::Epoch& ep = p->ep[p->cur];
     if (first > ep.num_mb || count > ep.num_mb - first) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
-    const bool one_launch = m->step_fusion >= 2 && !m->timing && p->bmax == 1 && ep.d_desc && ep.desc_host.size() == ep.num_mb &&
+    const bool one_launch = m->step_fusion >= 2 && !m->timing && !m->reference_order && p->bmax == 1 && ep.d_desc && ep.desc_host.size() == ep.num_mb &&
                             sbr::epoch_steps_shape_ok(m->mv, p->T - 1);
     if (!one_launch) {
         for (uint64_t mb = first; mb < first + count; ++mb) SBRCHK(sbr_fit_step(p, mb));
@@ -1763,6 +1790,15 @@ sbr_status sbr_fit_debug_phase_clocks(sbr_fit_plan* p, uint64_t out[6]) {
     SBRCHK(ensure_device(p->m));
     HIPCHK(hipStreamSynchronize(p->m->stream));
     HIPCHK(hipMemcpy(out, p->phase_clocks, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SBR_OK;
+}
+
+sbr_status sbr_model_set_reference_order(sbr_model* m, int32_t on) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    if (on && (m->hp.batch_sequences != 1 || m->hp.num_devices != 1 || (m->d != 16 && m->d != 32) ||
+               m->hp.max_sequence_length - 1 > SBR_SMALL_TAIL_MAX_ROWS))
+        return SBR_ERR_UNSUPPORTED; /* one sequence per step on one device, in the one-workgroup step's shapes */
+    m->reference_order = on != 0;
     return SBR_OK;
 }
 

@@ -135,6 +135,10 @@ struct SmallTail {
     uint32_t* nheads;
 };
 bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
+/* Reference order (one sequence per step, one device): negatives from the worker's sequential xorshift stream (rng_state: 4 words on
+ * the device, advanced by exactly the draws consumed), then the SmallTail.  Returns false where the one-sequence form does not exist. */
+bool launch_score_reference_order(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t* rng_state,
+                                  int rows_host, hipStream_t s, const SmallTail& tail);
 /* The optimiser half of a small single-device LSTM step at d <= 32 (one dense-gradient chunk, single-launch sparse update) in ONE
  * launch: dense gradient (per-element row chains) + dense update + sparse update, instead of three. */
 bool small_back_shape_ok(const ModelView& m, int rows_host);

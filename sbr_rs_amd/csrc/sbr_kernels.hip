@@ -482,6 +482,135 @@ __global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, 
     score_tail_body<D, NT>(m, mb, blk, w, epoch_key, tail);
 }
 
+// ---- REFERENCE ORDER (sbr_model_set_reference_order; one sequence per step, one device): the negatives of a step come from the
+// worker's own sequential generator, exactly as /root/reference/src/models/sequence_model.rs:58-65 / :137 draw them —
+// `Uniform::new(0, num_items).sample(thread_rng)` (rand 0.5 as recalled: one xorshift128 u64 per attempt, widening multiply,
+// rejection zone), one draw per try, WARP stopping at the first violating candidate — instead of the contract's counter-keyed
+// draws.  The stream is sequential and its consumption data-dependent (WARP), so one wave walks it: windows of up to 64 draws
+// are generated ahead (every lane runs the same scalar recurrence), their table rows gathered in ONE round trip, and the
+// steps' tries then resolved in order out of LDS; the generator state after exactly the draws consumed goes back to memory
+// (the same state shuffles the worker's partition at the next epoch, :109 — the host reads it back).  Scores, tests, loss and
+// everything downstream are the contract's; the checker has the same mode (tests/test_parity_gpu.py compares the two bit for bit).
+template <int D>
+__global__ __launch_bounds__(256) void score_refstream_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint32_t* rng_state, SmallTail tail) {
+    constexpr int L = D / 4, NGRP = 256 / L, WIN = 64;
+    extern __shared__ __attribute__((aligned(16))) float rl[];
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane % L, grp = tid / L;
+    const int R = mb.R;
+    float* Hs = rl;                              // [R][D]
+    float* Cs = Hs + (size_t)R * D;              // [WIN][D] candidate rows of the window
+    float* posv = Cs + WIN * D;                  // [R]
+    float* negv = posv + R;                      // [R]
+    uint32_t* njs = reinterpret_cast<uint32_t*>(negv + R);
+    uint32_t* trs = njs + R;
+    float* cb = reinterpret_cast<float*>(trs + R);  // [WIN]
+    uint32_t* cand = reinterpret_cast<uint32_t*>(cb + WIN);
+    uint32_t* sts = cand + WIN;                  // [WIN][4] generator state after draw i
+    for (int r0 = 0; r0 < R; r0 += NGRP) {       // positives of every step: a lane group per row (workgroup-uniform trip count)
+        const int r = r0 + grp, rr = r < R ? r : R - 1;
+        const float4 h = ld4(blk.H + (size_t)rr * D + 4 * lg);
+        const uint32_t pi = mb.out_idx[rr];
+        const float pos = m.b[pi] + group_allreduce<L>(dot4(h, ld4(m.E + (size_t)pi * D + 4 * lg)));
+        if (r < R) {
+            st4(Hs + (size_t)r * D + 4 * lg, h);
+            if (lg == 0) posv[r] = pos;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t x = rng_state[0], y = rng_state[1], z = rng_state[2], ww = rng_state[3];
+        const uint64_t range = (uint64_t)m.num_items;
+        const uint64_t zone = ~0ull - ((0ull - range) % range);  // MAX - (MAX - range + 1) % range
+        const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+        int tcur = 0, tries_cur = 0;
+        while (tcur < R) {
+            const int left = (R - tcur) * max_tries - tries_cur;
+            const int want = left < WIN ? left : WIN;
+            for (int i = 0; i < want; ++i) {  // the same scalar recurrence on every lane
+                uint64_t v;
+                for (;;) {
+                    uint32_t t1 = x ^ (x << 11);
+                    x = y; y = z; z = ww;
+                    ww = ww ^ (ww >> 19) ^ (t1 ^ (t1 >> 8));
+                    const uint32_t lo32 = ww;
+                    t1 = x ^ (x << 11);
+                    x = y; y = z; z = ww;
+                    ww = ww ^ (ww >> 19) ^ (t1 ^ (t1 >> 8));
+                    const uint64_t u = (uint64_t)lo32 | ((uint64_t)ww << 32);
+                    const uint64_t plo = u * range;
+                    if (plo <= zone) { v = __umul64hi(u, range); break; }
+                }
+                if (lane == 0) {
+                    cand[i] = (uint32_t)v;
+                    sts[4 * i] = x; sts[4 * i + 1] = y; sts[4 * i + 2] = z; sts[4 * i + 3] = ww;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int idx = lane; idx < want * L; idx += 64) {  // the window's rows: one round trip
+                const int c = idx / L, l4 = idx - c * L;
+                st4(Cs + (size_t)c * D + 4 * l4, ld4(m.E + (size_t)cand[c] * D + 4 * l4));
+            }
+            for (int c = lane; c < want; c += 64) cb[c] = m.b[cand[c]];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int pw = 0;
+            while (pw < want && tcur < R) {  // (every lane group of the wave evaluates the same dot: uniform control flow)
+                const float4 h = ld4(Hs + (size_t)tcur * D + 4 * lg);
+                const float sc = cb[pw] + group_allreduce<L>(dot4(h, ld4(Cs + (size_t)pw * D + 4 * lg)));
+                ++tries_cur;
+                const uint32_t nj = cand[pw];
+                ++pw;
+                const bool stop = tries_cur == max_tries || (m.loss == SBR_LOSS_WARP && sbr_warp_violates(posv[tcur], sc));
+                if (stop) {
+                    if (lane == 0) { njs[tcur] = nj; negv[tcur] = sc; trs[tcur] = (uint32_t)tries_cur; }
+                    ++tcur;
+                    tries_cur = 0;
+                }
+            }
+            if (pw > 0) { x = sts[4 * (pw - 1)]; y = sts[4 * (pw - 1) + 1]; z = sts[4 * (pw - 1) + 2]; ww = sts[4 * (pw - 1) + 3]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) { rng_state[0] = x; rng_state[1] = y; rng_state[2] = z; rng_state[3] = ww; }
+    }
+    __syncthreads();
+    double loss_part = 0.0;
+    unsigned int tries_part = 0;
+    for (int r = tid; r < R; r += 256) {
+        float g, l;
+        if (m.loss == SBR_LOSS_BPR) l = sbr_loss_bpr(posv[r], negv[r], &g);
+        else l = sbr_loss_hinge(posv[r], negv[r], &g);
+        blk.neg[r] = njs[r];
+        blk.coef[r] = g;
+        blk.in_idx[r] = mb.in_idx[r];
+        blk.out_idx[r] = mb.out_idx[r];
+        w.loss[r] = l;
+        w.tries[r] = trs[r];
+        loss_part += (double)l;
+        tries_part += trs[r];
+    }
+    __shared__ double s_loss[4];
+    __shared__ unsigned int s_tries[4];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        loss_part += __shfl_xor(loss_part, off, 64);
+        tries_part += __shfl_xor(tries_part, off, 64);
+    }
+    if (lane == 0) {
+        s_loss[tid >> 6] = loss_part;
+        s_tries[tid >> 6] = tries_part;
+    }
+    __syncthreads();
+    const double lsum = s_loss[0] + s_loss[1] + s_loss[2] + s_loss[3];
+    const unsigned int tsum = s_tries[0] + s_tries[1] + s_tries[2] + s_tries[3];
+    if (tid == 0) {
+        w.part_loss[0] = lsum;
+        w.part_tries[0] = tsum;
+    }
+    small_tail<256>(mb, blk, w, tail, lsum, tsum);
+}
+
 // Single-negative losses (hinge, BPR: one candidate, no retry loop): U rows per lane group and pass, all their gathers
 // in flight together, the ids of the next pass requested before this pass's rows (vector memory operations retire in
 // order, so they have long arrived when the next pass starts).  Without the retry loop the pass is pure memory-level
@@ -3657,6 +3786,16 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                                    epoch_key);
         });
     }
+}
+
+/* reference-order scoring of a one-sequence step (score_refstream_kernel); false: the shape has no such form */
+bool launch_score_reference_order(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t* rng_state,
+                                  int rows_host, hipStream_t s, const SmallTail& tail) {
+    if (!small_tail_shape_ok(m, mb.B, rows_host)) return false;
+    const size_t lds = ((size_t)rows_host * m.d + 64 * (size_t)m.d + 4 * (size_t)rows_host + 64 * 6) * 4;
+    if (m.d == 32) hipLaunchKernelGGL((score_refstream_kernel<32>), dim3(1), dim3(256), lds, s, m, mb, blk, w, rng_state, tail);
+    else hipLaunchKernelGGL((score_refstream_kernel<16>), dim3(1), dim3(256), lds, s, m, mb, blk, w, rng_state, tail);
+    return true;
 }
 
 /* EWMA + single-negative loss: scan and score in one pass per sequence (ewma_seq_kernel); whole = the backward scan too.  The

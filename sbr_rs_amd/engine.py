@@ -383,6 +383,11 @@ class Model:
         mask = 0xFFFFFFFF if families is None else sum(1 << int(KernelFamily[f]) for f in families)
         _check(self._L.sbr_model_timing_select(self._h, mask))
 
+    def set_reference_order(self, on: bool = True):
+        """Negatives from the worker's own sequential xorshift stream (sequence_model.rs:58-65, :137) instead of the counter-keyed
+        draws: one subsequence per step, one device, d <= 32 (sbr_model_set_reference_order)."""
+        _check(self._L.sbr_model_set_reference_order(self._h, 1 if on else 0))
+
     def set_step_fusion(self, level: int):
         """How one-sequence steps at d <= 32 are launched: 0 separate launches, 1 fused launches (four per step), 2 (default)
         runs of steps in one launch where the shape allows (sbr_model_set_step_fusion).  Same bits."""

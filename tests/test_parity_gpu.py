@@ -1413,3 +1413,65 @@ def test_step_runs_in_one_launch_equal_single_steps(loss, d, T, items):
     for q in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.EWMA_ALPHA, Param.EWMA_ALPHA_ACC):
         assert a.get_param(q).tobytes() == b.get_param(q).tobytes(), q
     assert a.counters() == b.counters()
+
+
+@pytest.mark.parametrize("kind,loss,d,T,items", [
+    (ModelKind.EWMA, LOSS_HINGE, 16, 6, 57),           # the oracle's own stream test shape: one draw per step
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 40, 23),    # 23 items: long retry runs, windows refilled inside a step
+    (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 128, 400),
+    (ModelKind.EWMA, LOSS_WARP, 32, 200, 1683),        # up to 199 rows per step: several 64-draw windows per sequence
+])
+def test_reference_order_negatives_follow_the_workers_stream(kind, loss, d, T, items):
+    """sbr_model_set_reference_order: the engine draws a step's negatives from the worker's own sequential xorshift128 stream with
+    rand 0.5's Uniform — one draw per try, WARP stopping at the first violating candidate, the same generator reshuffling the
+    partition every epoch (sequence_model.rs:58-65, :97, :109, :137) — instead of the contract's counter-keyed draws.  Every step's
+    negatives and trip counts, and after two fits every parameter, accumulator and loss figure, against the oracle's
+    reference-order mode (orc_model_set_reference_order), bit for bit."""
+    ptr, it = synthetic_interactions(17, items, T + 25, seed=41, min_len=3, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, B=1, epochs=2)
+    g, o = Model(hp), OracleModel(hp)
+    g.set_reference_order(True)
+    o.set_reference_order(True)
+    pg, po = g.fit_begin(ptr, it), o.fit_begin(ptr, it)
+    for _ in range(2):
+        n = pg.epoch_prepare()
+        assert po.epoch_prepare() == n
+        for mb in range(n):
+            pg.step(mb); po.step(mb)
+            rows = pg.minibatch_rows(mb)
+            for w in (Debug.IN_IDX, Debug.NEGATIVES, Debug.TRIES):
+                assert np.array_equal(pg.debug_fetch(w, rows), po.debug_fetch(w, rows)), (mb, w)
+    assert pg.end_lagged() == po.end_lagged()
+    pg.end(); po.end()
+    assert_params_equal(g, o, kind, "reference order, stepped")
+    for call in range(2):  # whole fits continue from the same state on both sides (the model RNG seeds a fresh worker stream)
+        lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+        assert lg == pytest.approx(lo, rel=1e-6)
+        assert_params_equal(g, o, kind, f"reference order, fit call {call}")
+        assert_lagged_equal(g, o, f"reference order, fit call {call}")
+    with pytest.raises(EngineError):  # the mode is defined for the reference's schedule only
+        Model(hparams(items, T, d, int(kind), loss, B=2)).set_reference_order(True)
+
+
+@pytest.mark.parametrize("name,kind,loss", [("lstm hinge 1 thread", ModelKind.LSTM_NORMAL, LOSS_HINGE), ("lstm warp", ModelKind.LSTM_NORMAL, LOSS_WARP),
+                                            ("ewma hinge", ModelKind.EWMA, LOSS_HINGE), ("ewma warp", ModelKind.EWMA, LOSS_WARP)])
+def test_movielens_protocol_in_reference_order(name, kind, loss):
+    """The reference's MovieLens-100K protocol cases with ONE worker (lstm.rs:450-520, ewma.rs:463-507: seed [42; 16], split 0.2,
+    d = 32, T = 128, ten epochs, one subsequence per optimiser step) with the ENGINE running the crate's own index stream
+    (sbr_model_set_reference_order): parameters and test ranks equal the oracle's reference-order run bit for bit, and the MRR
+    clears the floor tests/test_oracle.py asserts for that mode.  (The two-worker case needs one optimiser application per worker in
+    worker order across devices: the oracle has it, the engine's group driver does not — DESIGN.md section 9.)"""
+    from test_oracle import REFERENCE_ORDER_FLOORS
+
+    data, train, test, rng = movielens_protocol()
+    hp = hparams(data.num_items(), 128, 32, int(kind), loss, epochs=10, B=1, seed=rng.state_seed())
+    g, o = Model(hp), OracleModel(hp)
+    g.set_reference_order(True)
+    o.set_reference_order(True)
+    lg, lo = g.fit(train.user_pointers, train.item_ids), o.fit(train.user_pointers, train.item_ids)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    assert_params_equal(g, o, kind, name)
+    mg, rg = g.mrr_score(test.user_pointers, test.item_ids)
+    mo, ro = o.mrr_score(test.user_pointers, test.item_ids)
+    assert np.array_equal(rg, ro) and mg == mo
+    assert mg > REFERENCE_ORDER_FLOORS[name], (name, mg)

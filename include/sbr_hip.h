@@ -146,13 +146,20 @@ sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count);
  * additionally runs of steps in one launch through sbr_fit_steps / sbr_model_fit where the shape allows.  No result bit depends
  * on it (tests run all three). */
 sbr_status sbr_model_set_step_fusion(sbr_model* m, int32_t level);
-/* REFERENCE ORDER of the negatives (one subsequence per step, one device, embedding_dim <= 32, max_sequence_length <= 256): the
+/* REFERENCE ORDER of the negatives (one subsequence per step, embedding_dim <= 32, max_sequence_length <= 256): the
  * negatives of a step are drawn from the worker's own sequential generator exactly as sequence_model.rs:58-65 / :137 draw them —
  * `Uniform::new(0, num_items).sample(thread_rng)` (rand 0.5 as recalled), one draw per try, the same generator that shuffles the
  * worker's partition every epoch (:109) — instead of the engine's counter-keyed draws (which exist so that draws can be evaluated in
- * parallel).  Everything else is unchanged.  Checked bit for bit against the oracle's reference-order mode; SBR_ERR_UNSUPPORTED outside
+ * parallel).  Everything else of a worker's step is unchanged.  Checked bit for bit against the oracle's reference-order mode; SBR_ERR_UNSUPPORTED outside
  * the shapes above.  Set before sbr_model_fit / sbr_fit_begin. */
 sbr_status sbr_model_set_reference_order(sbr_model* m, int32_t on);
+/* ... with several workers (Parallelism::Synchronous, replicated table): every worker's gradient is applied as its OWN optimiser
+ * step, one after the other in worker order (sequence_model.rs:163-166; n Adagrad applications per step where the contract sums
+ * the devices' gradients and applies one).  sbr_group_fit / sbr_group_step do this when the replicas are in reference order; hosts
+ * that drive one process per GPU gather the devices' local blocks (sbr_fit_block_bytes each, block q at q * bytes; after
+ * sbr_fit_step_local) and call sbr_fit_step_apply_blocks_in_order on every rank. */
+sbr_status sbr_fit_block_bytes(const sbr_fit_plan* p, uint64_t* out_bytes);
+sbr_status sbr_fit_step_apply_blocks_in_order(sbr_fit_plan* p, uint64_t minibatch, const void* device_blocks);
 /* Profiling aid of the one-launch step runs: shader-clock ticks of the run's workgroup summed per phase since sbr_fit_begin —
  * [0] ids, key ordering, gather, [1] scan + scores, [2] backward scan, [3] reduction + updates, [4] closing barrier — and [5] the steps. */
 sbr_status sbr_fit_debug_phase_clocks(sbr_fit_plan* p, uint64_t out[6]);

@@ -1544,7 +1544,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const bool side_header = overlap && !early_sort && place == SORT_OWN_STREAM;
     /* ONE subsequence per step at d <= 32 (the reference's own schedule): header, lagged loss figure and the ordering of the step's
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
-    const bool small_tail = (m->step_fusion >= 1 || m->reference_order) && !overlap && p->ndev == 1 &&
+    const bool small_tail = (m->step_fusion >= 1 || m->reference_order) && !overlap && (p->ndev == 1 || m->reference_order) &&
                             sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
@@ -1793,11 +1793,45 @@ sbr_status sbr_fit_debug_phase_clocks(sbr_fit_plan* p, uint64_t out[6]) {
     return SBR_OK;
 }
 
+/* Reference order across devices (sequence_model.rs:163-166; wyrm's SynchronizedOptimizer as recalled): the workers rendezvous, then
+ * every worker's gradient goes in as its OWN optimiser step, one after the other in worker order — n Adagrad applications per step
+ * (G += g_q^2 each) where the contract adds the devices' gradients and applies one.  device_blocks: the n devices' local blocks of
+ * this step, gathered (block q at q * block bytes); every replica applies the same sequence and stays bit-identical. */
+sbr_status sbr_fit_step_apply_blocks_in_order(sbr_fit_plan* p, uint64_t minibatch, const void* device_blocks) {
+    if (!p || !device_blocks || minibatch >= p->ep[p->cur].num_mb || !p->m->reference_order) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    const uint8_t* all = reinterpret_cast<const uint8_t*>(device_blocks);
+    SBRCHK(join_dense(p));
+    sbr::launch_accumulate_loss(all, p->block_bytes, p->ndev, p->loss_acc, p->ex_acc, m->stream);
+    p->header_accumulated = false;
+    for (int q = 0; q < p->ndev; ++q) {
+        const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + q];
+        uint8_t* base = const_cast<uint8_t*>(all) + (size_t)q * p->block_bytes;
+        const sbr::BlockView bv = block_view(m, base, p->rmax);
+        begin_optimizer_step(m);
+        sbr::launch_own_sort(bv, R, p->keys, p->keys_sorted, p->sort_temp, p->sort_temp_bytes, p->key_bits, p->seg, m->stream, nullptr, 0, 0);
+        sbr::SegScratch sc = p->seg;
+        sc.prelisted = 0u;
+        sbr::launch_seg_apply(m->mv, bv, R, p->keys_sorted, sc, m->stream);
+        sbr::launch_dense_apply(m->mv, base, p->block_bytes, dense_offset_bytes(m, p->rmax), 1, m->stream);
+    }
+    p->sort_off_stream = false;
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+sbr_status sbr_fit_block_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
+    if (!p || !out_bytes) return SBR_ERR_INVALID_ARGUMENT;
+    *out_bytes = p->block_bytes;
+    return SBR_OK;
+}
+
 sbr_status sbr_model_set_reference_order(sbr_model* m, int32_t on) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
-    if (on && (m->hp.batch_sequences != 1 || m->hp.num_devices != 1 || (m->d != 16 && m->d != 32) ||
-               m->hp.max_sequence_length - 1 > SBR_SMALL_TAIL_MAX_ROWS))
-        return SBR_ERR_UNSUPPORTED; /* one sequence per step on one device, in the one-workgroup step's shapes */
+    if (on && (m->hp.batch_sequences != 1 || (m->d != 16 && m->d != 32) || m->hp.max_sequence_length - 1 > SBR_SMALL_TAIL_MAX_ROWS ||
+               (m->hp.num_devices != 1 && (m->hp.parallelism != SBR_PAR_SYNCHRONOUS || m->shared))))
+        return SBR_ERR_UNSUPPORTED; /* one sequence per step in the one-workgroup step's shapes; several workers: Synchronous, replicated */
     m->reference_order = on != 0;
     return SBR_OK;
 }
@@ -2331,8 +2365,8 @@ struct sbr_group_plan {
     std::vector<sbr_model*> models;
     std::vector<Dev> dev;
     uint32_t n = 0;
-    uint64_t chunk = 0, db = 0;
-    bool partitioned = false, async = false;
+    uint64_t chunk = 0, db = 0, block_bytes = 0;
+    bool partitioned = false, async = false, reforder = false;
     bool first = true;               /* no step has been applied yet: nothing to wait for */
     uint64_t nmb = 0;                /* minibatches of the prepared epoch */
     uint32_t epochs_prepared = 0;
@@ -2359,6 +2393,31 @@ struct sbr_group_plan {
         SBRCHK(ensure_device(models[r]));
         if (partitioned) SBRCHK(wait_applied(r, models[r]->stream));
         return sbr_fit_step_local(dev[r].plan, mb);
+    }
+    /* reference order (sbr_model_set_reference_order on every replica): the devices' blocks are gathered and applied as n optimiser
+     * steps in device order on every replica (sbr_fit_step_apply_blocks_in_order) */
+    sbr_status reforder_step(uint64_t mb) {
+        const bool have_local = local_done == (int64_t)mb;
+        SBRCHK(phase([&](uint32_t r) -> sbr_status {
+            SBRCHK(ensure_device(models[r]));
+            SBRCHK(wait_applied(r, models[r]->stream)); /* the peers have copied the previous step's block out of this plan */
+            if (!have_local) SBRCHK(sbr_fit_step_local(dev[r].plan, mb));
+            SBRCHK(ensure_dense_reduced(dev[r].plan));
+            HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
+            return SBR_OK;
+        }));
+        SBRCHK(phase([&](uint32_t q) -> sbr_status {
+            SBRCHK(ensure_device(models[q]));
+            for (uint32_t r = 0; r < n; ++r) {
+                if (r != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[r].scattered, 0));
+                HIPCHK(hipMemcpyAsync(dev[q].recv + (size_t)r * block_bytes, dev[r].plan->block, block_bytes, hipMemcpyDefault, models[q]->stream));
+            }
+            SBRCHK(sbr_fit_step_apply_blocks_in_order(dev[q].plan, mb, dev[q].recv));
+            HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
+            return SBR_OK;
+        }));
+        first = false;
+        return SBR_OK;
     }
     sbr_status single_step(uint64_t mb) {
         if (local_done == (int64_t)mb) return sbr_fit_step_apply(dev[0].plan, mb);
@@ -2492,7 +2551,11 @@ struct sbr_group_plan {
         /* a partitioned table is updated in place by its owners after a rendezvous, so there is no staleness-one pipeline for
          * it: Parallelism::Asynchronous runs the synchronous step there (same everywhere a partitioned table is driven) */
         async = models[0]->hp.parallelism == SBR_PAR_ASYNCHRONOUS && !partitioned;
+        reforder = models[0]->reference_order;
+        for (uint32_t r = 0; r < n; ++r)
+            if (models[r]->reference_order != reforder) return SBR_ERR_INVALID_ARGUMENT;
         for (uint32_t r = 0; r < n; ++r) SBRCHK(sbr_fit_begin(models[r], user_ptr, item_ids, num_users, &dev[r].plan));
+        block_bytes = dev[0].plan->block_bytes;
         SBRCHK(sbr_fit_chunk_bytes(dev[0].plan, &chunk));
         SBRCHK(sbr_fit_dense_bytes(dev[0].plan, &db));
         for (uint32_t r = 0; r < n; ++r) {
@@ -2506,6 +2569,12 @@ struct sbr_group_plan {
                 }
             (void)hipGetLastError();
             if (n == 1) continue; /* single_step: no exchange buffers */
+            if (reforder) { /* the devices' whole blocks travel (one sequence each: tens of KB) */
+                SBRCHK(dmalloc(&v.recv, n * block_bytes));
+                HIPCHK(hipEventCreateWithFlags(&v.scattered, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&v.applied, hipEventDisableTiming));
+                continue;
+            }
             SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.dense_all, n * db));
             if (!partitioned) { /* the replicated exchange moves table-sized chunks; the partitioned one needs none */
                 SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.recv, n * chunk));
@@ -2521,6 +2590,22 @@ struct sbr_group_plan {
     }
     sbr_status epoch_prepare(uint64_t* out_nmb, bool prefetch_next) {
         uint64_t k0 = 0;
+        if (reforder && n > 1) { /* every replica shuffles EVERY worker's partition (it needs the workers' step sizes): each worker's
+                                  * stream, advanced on its own device during the epoch, goes to all of them first */
+            for (uint32_t r = 0; r < n; ++r) {
+                sbr_fit_plan* pr = dev[r].plan;
+                if (!pr->ref_rng || !pr->ref_rng_live) continue;
+                SBRCHK(ensure_device(models[r]));
+                HIPCHK(hipStreamSynchronize(models[r]->stream));
+                uint32_t st4w[4];
+                HIPCHK(hipMemcpy(st4w, pr->ref_rng, sizeof(st4w), hipMemcpyDeviceToHost));
+                for (uint32_t q = 0; q < n; ++q) {
+                    sbr_xorshift& x = dev[q].plan->part_rng[r];
+                    x.x = st4w[0]; x.y = st4w[1]; x.z = st4w[2]; x.w = st4w[3];
+                }
+                pr->ref_rng_live = false;
+            }
+        }
         for (uint32_t r = 0; r < n; ++r) {
             uint64_t k = 0;
             SBRCHK(sbr_fit_epoch_prepare(dev[r].plan, &k));
@@ -2538,7 +2623,7 @@ struct sbr_group_plan {
         if (mb >= nmb) return SBR_ERR_INVALID_ARGUMENT;
         const auto t0 = std::chrono::steady_clock::now();
         /* a group of one has nobody to exchange with: the single-device step (its table may still be a mapped range) */
-        const sbr_status st = n == 1 ? single_step(mb) : partitioned ? partitioned_step(mb) : async ? async_step(mb) : sync_step(mb);
+        const sbr_status st = n == 1 ? single_step(mb) : reforder ? reforder_step(mb) : partitioned ? partitioned_step(mb) : async ? async_step(mb) : sync_step(mb);
         local_done = -1;
         enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         ++steps;

@@ -1459,8 +1459,7 @@ def test_movielens_protocol_in_reference_order(name, kind, loss):
     """The reference's MovieLens-100K protocol cases with ONE worker (lstm.rs:450-520, ewma.rs:463-507: seed [42; 16], split 0.2,
     d = 32, T = 128, ten epochs, one subsequence per optimiser step) with the ENGINE running the crate's own index stream
     (sbr_model_set_reference_order): parameters and test ranks equal the oracle's reference-order run bit for bit, and the MRR
-    clears the floor tests/test_oracle.py asserts for that mode.  (The two-worker case needs one optimiser application per worker in
-    worker order across devices: the oracle has it, the engine's group driver does not — DESIGN.md section 9.)"""
+    clears the floor tests/test_oracle.py asserts for that mode.  (The two-worker case: test_movielens_two_threads_in_reference_order.)"""
     from test_oracle import REFERENCE_ORDER_FLOORS
 
     data, train, test, rng = movielens_protocol()
@@ -1475,3 +1474,53 @@ def test_movielens_protocol_in_reference_order(name, kind, loss):
     mo, ro = o.mrr_score(test.user_pointers, test.item_ids)
     assert np.array_equal(rg, ro) and mg == mo
     assert mg > REFERENCE_ORDER_FLOORS[name], (name, mg)
+
+
+@pytest.mark.parametrize("kind,loss,d,world,T,items,users", [
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 32, 2, 128, 1683, 40),   # the shape of the reference's mrr_test_two_threads
+    (ModelKind.EWMA, LOSS_WARP, 16, 3, 20, 97, 60),
+])
+def test_reference_order_several_workers_apply_one_after_the_other(kind, loss, d, world, T, items, users):
+    """Reference order with num_threads(n) (Parallelism::Synchronous): every worker draws from its OWN sequential stream, the
+    workers rendezvous, and each worker's gradient goes in as its own optimiser step, one after the other in worker order
+    (sequence_model.rs:163-166; n Adagrad applications per step) — sbr_group_fit over replicas in reference order
+    (sbr_fit_step_apply_blocks_in_order) against the oracle's reference-order run with num_devices = n, every replica, bit for bit."""
+    from sbr_rs_amd.engine import group_create, group_fit
+
+    ptr, it = synthetic_interactions(users, items, T + 20, seed=43, min_len=3, zipf=True)
+    hp = hparams(items, T, d, int(kind), loss, B=1, epochs=2, ndev=world)
+    models = group_create(hp, world)
+    for m in models:
+        m.set_reference_order(True)
+    o = OracleModel(hp)
+    o.set_reference_order(True)
+    for call in range(2):
+        lg, lo = group_fit(models, ptr, it), o.fit(ptr, it)
+        assert lg == pytest.approx(lo, rel=1e-6)
+        for q in range(world):
+            assert_params_equal(models[q], o, kind, f"reference order, {world} workers, call {call}, replica {q}")
+            assert_lagged_equal(models[q], o, f"reference order, {world} workers, replica {q}")
+
+
+def test_movielens_two_threads_in_reference_order():
+    """`mrr_test_two_threads` (lstm.rs:473-496: LSTM + hinge, two worker threads, Synchronous) with the engine in reference order:
+    two replicas, two sequential streams, two optimiser applications per step — parameters and ranks equal the oracle's
+    reference-order run, MRR above the floor recorded for that mode."""
+    from sbr_rs_amd.engine import group_create, group_fit
+    from test_oracle import REFERENCE_ORDER_FLOORS
+
+    data, train, test, rng = movielens_protocol()
+    hp = hparams(data.num_items(), 128, 32, int(ModelKind.LSTM_NORMAL), LOSS_HINGE, epochs=10, B=1, seed=rng.state_seed(), ndev=2)
+    models = group_create(hp, 2)
+    for m in models:
+        m.set_reference_order(True)
+    o = OracleModel(hp)
+    o.set_reference_order(True)
+    lg, lo = group_fit(models, train.user_pointers, train.item_ids), o.fit(train.user_pointers, train.item_ids)
+    assert lg == pytest.approx(lo, rel=1e-6)
+    for q in range(2):
+        assert_params_equal(models[q], o, ModelKind.LSTM_NORMAL, f"two threads, replica {q}")
+    mg, rg = models[1].mrr_score(test.user_pointers, test.item_ids)
+    mo, ro = o.mrr_score(test.user_pointers, test.item_ids)
+    assert np.array_equal(rg, ro) and mg == mo
+    assert mg > REFERENCE_ORDER_FLOORS["lstm hinge 2 threads"], mg

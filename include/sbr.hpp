@@ -563,6 +563,17 @@ class ImplicitSequenceModel : public OnlineRankingModel<ImplicitUser> {
     /// of more than two items exists (sequence_model.rs:86-88).
     Result<float, FittingError> fit(const data::CompressedInteractions& interactions) { return replicas_->fit(interactions); }
 
+    /// The crate's own ORDER of work at one subsequence per step (`batch_sequences(1)`, embedding_dim <= 32): a step's negatives
+    /// from the worker's sequential XorShiftRng stream (sequence_model.rs:58-65, :137) and, with `num_threads(n)`, one optimiser
+    /// application per worker in worker order (:163-166) — instead of the engine's counter-keyed draws and summed gradients.
+    /// Call before `fit`.  Throws EngineError(SBR_ERR_UNSUPPORTED) outside the mode's shapes.
+    void set_reference_order(bool on) {
+        for (sbr_model* h : replicas_->handles()) {
+            const sbr_status st = sbr_model_set_reference_order(h, on ? 1 : 0);
+            if (st != SBR_OK) throw EngineError(st, "sbr_model_set_reference_order");
+        }
+    }
+
     /// The number the reference's `fit` would have returned for the last `fit` call: sequence_model.rs:157 reads the
     /// loss node BEFORE :160 runs its forward pass; the nodes are shared running sums (lstm.rs:322-328), so a subsequence
     /// of s steps contributes L_{s-1} of the worker's most recent earlier subsequence with at least s steps.  `fit` itself returns the true mean loss.

@@ -187,6 +187,14 @@ class _ImplicitSequenceModel:
 
         return group_fit(self._replicas(), interactions.user_pointers, interactions.item_ids)
 
+    def set_reference_order(self, on: bool = True):
+        """The crate's own ORDER of work at one subsequence per step (``batch_sequences(1)``, embedding_dim <= 32): negatives from the
+        worker's sequential XorShiftRng stream (sequence_model.rs:58-65, :137) and, with ``num_threads(n)``, one optimiser application
+        per worker in worker order (:163-166).  Call before ``fit``."""
+        for m in self._replicas():
+            m.set_reference_order(on)
+        return self
+
     def last_fit_lagged_loss(self) -> float:
         """The number the reference's ``fit`` would have returned for the last single-process ``fit`` (one device or
         ``num_threads`` replicas): sequence_model.rs:157 reads the loss node before :160 runs its forward pass, so every

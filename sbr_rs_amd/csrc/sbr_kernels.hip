@@ -2807,7 +2807,7 @@ __device__ __forceinline__ void phase_sync() {
 // dense_apply_element, on the same lane layout (d/4 lanes x 4 elements per row), so the bits are theirs.
 #define SBR_EWMA_STEPS_MAX_ROWS 128 /* rows per step: the gather keeps 3 x 128 d / 1 024 + 12 row pieces per thread in registers */
 #define SBR_EWMA_STEPS_LDS_FLOATS(max_rows, d) \
-    (2 * (size_t)(d) + (size_t)(((max_rows) + 3) & ~3) + 8 * (size_t)(max_rows) * (d) + 9 * (size_t)(max_rows) + (d) + 1 + 12 * (size_t)(max_rows))
+    (4 * (size_t)(d) + (size_t)(((max_rows) + 3) & ~3) + 8 * (size_t)(max_rows) * (d) + 9 * (size_t)(max_rows) + (d) + 1 + 12 * (size_t)(max_rows))
 template <int D>
 __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView ev, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail,
                                                          int step_begin, int step_end, int max_rows, unsigned long long* prof) {
@@ -2819,7 +2819,8 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
     /* run-resident state */
     float* alphaL = el;                      // [D]
     float* alphaAcc = alphaL + D;            // [D]
-    float* lagN = alphaAcc + D;              // [max_rows] loss nodes (sbr_report.hip)
+    float* sigA = alphaAcc + D;              // [2 D] sigmoid(alpha) | 1 - sigmoid(alpha) of the step in flight
+    float* lagN = sigA + 2 * D;              // [max_rows] loss nodes (sbr_report.hip)
     float* stepL = lagN + ((max_rows + 3) & ~3);
     for (int k = tid; k < D; k += 256) { alphaL[k] = m.alpha[k]; alphaAcc[k] = m.alpha_acc[k]; }
     for (int t = tid; t < max_rows; t += 256) lagN[t] = tail.lag_state[1 + 2 * t];
@@ -2888,42 +2889,51 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
             const uint32_t po = iout[tid], pn = ineg[tid];
             b0 = m.b[po]; b1 = m.b[pn]; a0 = m.bacc[po]; a1 = m.bacc[pn];
         }
-        /* ... and while it travels: the keys' stable order by row (distinct keys, so the rank of a key among all of them is its
-         * place) and sigmoid(alpha) */
-        for (int e0 = 0; e0 < n3; e0 += 256) {  // workgroup-uniform trip count
-            const int e = e0 + tid;
-            const uint64_t k = e < n3 ? ka[e] : ~0ull;
-            int rank = 0;
-            for (int j0 = 0; j0 < n3; j0 += 64) {
-                /* 64 keys per LDS read (one per lane), then compared one by one out of the lanes' registers: a dependent LDS read
-                 * per key cost a step of ~30 keys 1.6 us */
-                const uint64_t kj = j0 + lane < n3 ? ka[j0 + lane] : ~0ull;
-                const uint32_t klo = (uint32_t)kj, khi = (uint32_t)(kj >> 32);
-                const int cnt = n3 - j0 < 64 ? n3 - j0 : 64;
-                for (int l = 0; l < cnt; ++l) {
-                    const uint64_t other = ((uint64_t)__builtin_amdgcn_readlane(khi, l) << 32) | (uint64_t)__builtin_amdgcn_readlane(klo, l);
-                    rank += other < k ? 1 : 0;
-                }
+        /* ... and while it travels the waves SPECIALISE (a lone wave pays ~9 cycles per instruction, so what a step costs is the
+         * longest instruction sequence any one wave runs between two barriers): waves 0.. rank the keys — the stable order by row
+         * (distinct keys, so the rank of a key among all of them is its place) — while the LAST wave forms sigmoid(alpha) for the
+         * scans */
+        const int wave = tid >> 6;
+        if (wave == 3) {
+            if (lane < D) {
+                const float av = sbr_sigmoidf(alphaL[lane]);
+                sigA[lane] = av;
+                sigA[D + lane] = 1.0f - av;
             }
-            if (e < n3) kb[rank] = k;
         }
-        float a[4], oma[4];
+        if (wave < 3 || n3 > 192) {
+            const int nrank = n3 > 192 ? 256 : 192;  // (up to 192 keys: waves 0-2 hold one key each)
+            for (int e0 = 0; e0 < n3; e0 += nrank) {
+                const int e = e0 + tid;
+                const uint64_t k = e < n3 ? ka[e] : ~0ull;
+                int rank = 0;
+                /* eight keys per batch, their LDS reads independent of each other and of the count (a dependent read per key cost a
+                 * ~30-key step 1.6 us; broadcasting the keys out of lane registers with v_readlane 1.9 us: every scalar read-back
+                 * stalls the vector pipe) */
+                for (int j0 = 0; j0 < n3; j0 += 8) {
+                    uint64_t kk[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a[j] = sbr_sigmoidf(alphaL[4 * lg + j]);
-            oma[j] = 1.0f - a[j];
+                    for (int q = 0; q < 8; ++q) kk[q] = ka[j0 + q < n3 ? j0 + q : n3 - 1];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rank += (j0 + q < n3 && kk[q] < k) ? 1 : 0;
+                }
+                if (e < n3) kb[rank] = k;
+            }
         }
         __syncthreads();
         /* the optimiser state (E_acc) of every segment head's row, requested as soon as the order is known: piece (p, lg) by the
          * thread that will update it — it stays in flight underneath the scan and lands in LDS before the update */
+        const int hq = (n3 + NGRP - 1) / NGRP;  // head rounds this step needs (workgroup-uniform)
         float4 ha[HQ];
 #pragma unroll
         for (int i = 0; i < HQ; ++i) {
-            const int p = i * NGRP + grp;
             ha[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < n3) {
-                const uint32_t row = (uint32_t)(kb[p] >> 32);
-                if (p == 0 || (uint32_t)(kb[p - 1] >> 32) != row) ha[i] = ld4(m.Eacc + (size_t)row * D + 4 * lg);
+            if (i < hq) {
+                const int p = i * NGRP + grp;
+                if (p < n3) {
+                    const uint32_t row = (uint32_t)(kb[p] >> 32);
+                    if (p == 0 || (uint32_t)(kb[p - 1] >> 32) != row) ha[i] = ld4(m.Eacc + (size_t)row * D + 4 * lg);
+                }
             }
         }
 #pragma unroll
@@ -2938,25 +2948,26 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
         if (tid < n) { bp[tid] = b0; bn[tid] = b1; bpa[tid] = a0; bna[tid] = a1; }
         __syncthreads();
         SBR_PHASE_CLOCK(0)
-        /* ---- scan (ewma.rs:302-313): one lane group, s_t to LDS */
-        if (tid < L) {
-            float4 s = ld4(X + 4 * lg);
-            st4(H + 4 * lg, s);
-            float4 xn = ld4(X + (size_t)(n > 1 ? 1 : 0) * D + 4 * lg);
+        /* ---- scan (ewma.rs:302-313): ONE ELEMENT PER LANE of wave 0 (the d chains are independent: same operations per element
+         * as the four-per-lane form, a quarter of the instructions on the wave that everybody waits for), s_t to LDS */
+        if (tid < D) {
+            const float av = sigA[tid], omav = sigA[D + tid];
+            float sv = X[tid];
+            H[tid] = sv;
+            float xn = X[(size_t)(n > 1 ? 1 : 0) * D + tid];
             for (int t = 1; t < n; ++t) {
-                const float4 x = xn;
-                xn = ld4(X + (size_t)(t + 1 < n ? t + 1 : t) * D + 4 * lg);  // the next row's LDS read under this row's arithmetic
-                s.x = sbr_fma(a[0], s.x, oma[0] * x.x);
-                s.y = sbr_fma(a[1], s.y, oma[1] * x.y);
-                s.z = sbr_fma(a[2], s.z, oma[2] * x.z);
-                s.w = sbr_fma(a[3], s.w, oma[3] * x.w);
-                st4(H + (size_t)t * D + 4 * lg, s);
+                const float x = xn;
+                xn = X[(size_t)(t + 1 < n ? t + 1 : t) * D + tid];  // the next row's LDS read under this row's arithmetic
+                sv = sbr_fma(av, sv, omav * x);
+                H[(size_t)t * D + tid] = sv;
             }
         }
 #pragma unroll
         for (int i = 0; i < HQ; ++i) {
-            const int p = i * NGRP + grp;
-            if (p < n3) st4(A + (size_t)p * D + 4 * lg, ha[i]);
+            if (i < hq) {
+                const int p = i * NGRP + grp;
+                if (p < n3) st4(A + (size_t)p * D + 4 * lg, ha[i]);
+            }
         }
         __syncthreads();
         /* ---- scores, loss, dloss/ds of every step (ewma.rs:315-335): a lane group per row */
@@ -2977,44 +2988,33 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
         }
         __syncthreads();
         SBR_PHASE_CLOCK(1)
-        /* ---- backward scan (ewma_backward_seq): one lane group; dX over DS, dalpha partial to LDS.  Wave 1 meanwhile: loss bookkeeping */
-        if (tid < L) {
-            float carry[4] = {0.f, 0.f, 0.f, 0.f}, da[4] = {0.f, 0.f, 0.f, 0.f};
-            float4 dsn = ld4(DS + (size_t)(n - 1) * D + 4 * lg), xnn = ld4(X + (size_t)(n - 1) * D + 4 * lg),
-                   spn = ld4(H + (size_t)(n > 1 ? n - 2 : 0) * D + 4 * lg);
+        /* ---- backward scan (ewma_backward_seq): one element per lane of wave 0; dX over DS, dalpha partial to LDS.  Wave 1 meanwhile:
+         * the loss bookkeeping */
+        if (tid < D) {
+            const float av = sigA[tid], omav = sigA[D + tid];
+            float carry = 0.0f, da = 0.0f;
+            float dsn = DS[(size_t)(n - 1) * D + tid], xnn = X[(size_t)(n - 1) * D + tid], spn = H[(size_t)(n > 1 ? n - 2 : 0) * D + tid];
             for (int t = n - 1; t >= 0; --t) {
-                const float4 dsv = dsn, xv_ = xnn, spv_ = spn;
+                float ds = dsn;
+                const float xv_ = xnn, spv_ = spn;
                 {   // step t - 1's operands under step t's arithmetic
                     const int tp = t > 0 ? t - 1 : 0;
-                    dsn = ld4(DS + (size_t)tp * D + 4 * lg);
-                    xnn = ld4(X + (size_t)tp * D + 4 * lg);
-                    spn = ld4(H + (size_t)(tp > 0 ? tp - 1 : 0) * D + 4 * lg);
+                    dsn = DS[(size_t)tp * D + tid];
+                    xnn = X[(size_t)tp * D + tid];
+                    spn = H[(size_t)(tp > 0 ? tp - 1 : 0) * D + tid];
                 }
-                float ds[4] = {dsv.x, dsv.y, dsv.z, dsv.w};
-                if (t != n - 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ds[j] = ds[j] + 0.0f;
-                }
-                float4 dx;
+                ds = t != n - 1 ? ds + carry : ds + 0.0f;
+                float dx;
                 if (t > 0) {
-                    const float xs[4] = {xv_.x, xv_.y, xv_.z, xv_.w}, sps[4] = {spv_.x, spv_.y, spv_.z, spv_.w};
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = oma[j] * ds[j];
-                        carry[j] = a[j] * ds[j];
-                        da[j] = sbr_fma(ds[j], sps[j] - xs[j], da[j]);
-                    }
-                    dx = make_float4(o[0], o[1], o[2], o[3]);
+                    dx = omav * ds;
+                    carry = av * ds;
+                    da = sbr_fma(ds, spv_ - xv_, da);
                 } else {
-                    dx = make_float4(ds[0], ds[1], ds[2], ds[3]);
+                    dx = ds;
                 }
-                st4(DS + (size_t)t * D + 4 * lg, dx);
+                DS[(size_t)t * D + tid] = dx;
             }
-            st4(dab + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
+            dab[tid] = da;
         } else if (tid >= 64 && tid < 128) { /* wave 1: the step's loss figures (block_header_kernel / small_tail) */
             double lp = 0.0;
             for (int r = lane; r < n; r += 64) lp += (double)lossv[r];
@@ -3053,11 +3053,16 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
         SBR_PHASE_CLOCK(2)
         /* ---- dalpha and its update (ewma_dab_final_kernel with one sequence + dense_apply_element), in LDS */
         float galpha = 0.0f;
-        if (tid < D) {
+        if (wave == 3 && lane < D) { /* (the last wave: its lanes have no segments to reduce before the others do) */
             float pcv = 0.0f;
-            pcv = pcv + dab[tid];
-            const float av = sbr_sigmoidf(alphaL[tid]);
+            pcv = pcv + dab[lane];
+            const float av = sigA[lane];  // = sbr_sigmoidf(alpha): alpha does not move between the scans and here
             galpha = pcv * (av * (1.0f - av));
+            float wv = alphaL[lane], G = alphaAcc[lane];
+            sbr_adagrad(&wv, &G, galpha, m.lr, m.l2);
+            alphaL[lane] = wv;
+            alphaAcc[lane] = G;
+            if (last) blk.dense[lane] = galpha;
         }
         /* ---- sparse update: a lane group per SEGMENT of the ordered keys (a position whose row differs from its predecessor's starts
          * one); entries in (packed row, kind) order, the first initialises, SBR_SEG_CHUNK-entry chunk partials added in order.  The
@@ -3117,13 +3122,6 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
                 m.b[row] = bv;
                 m.bacc[row] = ba;
             }
-        }
-        if (tid < D) { /* dense_apply_element, EWMA branch (Adagrad), on the run-resident copy */
-            float wv = alphaL[tid], G = alphaAcc[tid];
-            sbr_adagrad(&wv, &G, galpha, m.lr, m.l2);
-            alphaL[tid] = wv;
-            alphaAcc[tid] = G;
-            if (last) blk.dense[tid] = galpha;
         }
         SBR_PHASE_CLOCK(3)
         if (last) { /* the block of the run's last step, for sbr_fit_debug_fetch / sbr_fit_sparse_stats */

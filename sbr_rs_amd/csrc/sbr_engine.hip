@@ -1218,7 +1218,7 @@ sbr_status sbr_fit_begin(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     }
     {   /* a long segment has more than SBR_SEG_CHUNK entries: at most max_entries / chunk of them, and
          * their chunks number at most max_entries / chunk + (number of long segments) */
-        const uint64_t cap = max_entries / SBR_SEG_CHUNK + 2, units = 2 * cap;
+        const uint64_t cap = max_entries / SBR_SEG_ROUTE + 2, units = cap + max_entries / SBR_SEG_CHUNK + 2; /* routed segments; their chunks */
         p->seg.cap = (uint32_t)cap;
         if (st == SBR_OK) st = dmalloc(&p->seg.counters, 4);
         if (st == SBR_OK) st = dmalloc(&p->seg.long_start, cap);

@@ -2645,7 +2645,7 @@ __device__ __forceinline__ void seg_short_rows(const BlockView& blk, const uint6
             emit.template row<D>(row, p, lg, g, has_b, gb, pre);
             continue;
         }
-        if (len > SBR_SEG_CHUNK) { /* long segment: registered for the chunked path (or listed already: seg_long_list_kernel) */
+        if (!INLINE_LONG && len > SBR_SEG_ROUTE) { /* long segment: registered for the chunked path (or listed already: seg_long_list_kernel) */
             if (lg == 0 && !sc.prelisted) {
                 const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
                 if (slot < sc.cap) {
@@ -3168,7 +3168,7 @@ __global__ __launch_bounds__(256) void seg_long_list_kernel(SegScratch sc) {
     const uint32_t nheads = *sc.nheads;
     for (uint32_t h = blockIdx.x * 256 + threadIdx.x; h < nheads; h += gridDim.x * 256) {
         const uint32_t p0 = sc.head_pos[h], p1 = sc.head_pos[h + 1];
-        if (p1 - p0 > SBR_SEG_CHUNK) {
+        if (p1 - p0 > SBR_SEG_ROUTE) {
             const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
             if (slot < sc.cap) {
                 sc.long_start[slot] = p0;

@@ -306,6 +306,26 @@ sbr_status sbr_fit_lists_import(sbr_fit_plan* p, uint32_t peer_rank, const int32
 sbr_status sbr_fit_step_reduce_own(sbr_fit_plan* p, uint64_t minibatch, uint32_t* host_bounds, void* device_dense_out);
 sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds, const void* device_dense_all);
 
+/* The rendezvous of a step through RCCL INSIDE the library — for hosts that run one process per GPU and have no collective library
+ * of their own (≙ the synchronised optimiser step of sequence_model.rs:92, 163-166 across processes; xGMI within a node).  librccl
+ * is opened at run time; hosts that bring their own transport (torch.distributed, MPI: the sbr_fit_step_scatter / _owner_reduce /
+ * _apply_* halves above) never load it.
+ *   sbr_comm_unique_id    rank 0 makes the 128-byte id; the host hands it to the other ranks (a file, a socket, an environment
+ *                         variable: any channel)
+ *   sbr_comm_create       every rank, on its own device (sbr_set_device first), with the same id
+ *   sbr_fit_step_exchange after sbr_fit_step_local: scatter -> all-to-all -> owner reduce -> all-gather -> table update, dense
+ *                         block -> all-gather -> dense update, all queued on the model's stream; same bits as every other transport
+ *   sbr_model_fit_comm    the whole fit of this rank (sbr_model_fit for num_devices = world across processes); the loss is the
+ *                         all-rank figure, sbr_model_last_fit_lagged_loss holds THIS rank's term of the reference's figure
+ * Replicated table, Parallelism::Synchronous order of work.  SBR_ERR_UNSUPPORTED: no librccl on this host. */
+typedef struct sbr_comm sbr_comm;
+sbr_status sbr_comm_unique_id(uint8_t out_id[128]);
+sbr_status sbr_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, sbr_comm** out);
+void sbr_comm_destroy(sbr_comm* c);
+sbr_status sbr_fit_step_exchange(sbr_fit_plan* p, uint64_t minibatch, sbr_comm* c);
+sbr_status sbr_model_fit_comm(sbr_model* m, sbr_comm* c, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
+                              float* out_loss);
+
 /* Device pointer / stream plumbing for the host side (torch only supplies memory + streams). */
 sbr_status sbr_model_set_stream(sbr_model* m, void* hip_stream);
 sbr_status sbr_model_synchronize(sbr_model* m);

@@ -37,6 +37,10 @@ def load():
         "sbr_fit_steps": [vp, C.c_uint64, C.c_uint64],
         "sbr_model_set_step_fusion": [vp, C.c_int32],
         "sbr_model_set_reference_order": [vp, C.c_int32],
+        "sbr_comm_unique_id": [vp],
+        "sbr_comm_create": [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)],
+        "sbr_fit_step_exchange": [vp, C.c_uint64, vp],
+        "sbr_model_fit_comm": [vp, vp, vp, vp, C.c_uint64, fp],
         "sbr_fit_block_bytes": [vp, u64p],
         "sbr_fit_step_apply_blocks_in_order": [vp, C.c_uint64, vp],
         "sbr_fit_debug_phase_clocks": [vp, u64p],
@@ -119,6 +123,8 @@ def load():
     L.sbr_model_destroy.restype = None
     L.sbr_fit_plan_destroy.argtypes = [vp]
     L.sbr_fit_plan_destroy.restype = None
+    L.sbr_comm_destroy.argtypes = [vp]
+    L.sbr_comm_destroy.restype = None
     L.sbr_group_plan_destroy.argtypes = [vp]
     L.sbr_group_plan_destroy.restype = None
     L.sbr_status_string.argtypes = [C.c_int]
@@ -147,5 +153,5 @@ DECLARED_SYMBOLS = [
     "sbr_fit_lists_export", "sbr_fit_lists_import", "sbr_fit_step_reduce_own", "sbr_fit_step_owner_apply", "sbr_selftest_math",
     "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort", "sbr_release_cached_memory",
     "sbr_group_fit_begin", "sbr_group_epoch_prepare", "sbr_group_step", "sbr_group_step_local", "sbr_group_member_plan",
-    "sbr_fit_steps", "sbr_model_set_reference_order", "sbr_fit_block_bytes", "sbr_fit_step_apply_blocks_in_order", "sbr_model_set_step_fusion", "sbr_fit_debug_phase_clocks", "sbr_group_synchronize", "sbr_group_plan_set_host_threads", "sbr_group_plan_stats", "sbr_group_fit_end", "sbr_group_plan_destroy",
+    "sbr_fit_steps", "sbr_comm_unique_id", "sbr_comm_create", "sbr_comm_destroy", "sbr_fit_step_exchange", "sbr_model_fit_comm", "sbr_model_set_reference_order", "sbr_fit_block_bytes", "sbr_fit_step_apply_blocks_in_order", "sbr_model_set_step_fusion", "sbr_fit_debug_phase_clocks", "sbr_group_synchronize", "sbr_group_plan_set_host_threads", "sbr_group_plan_stats", "sbr_group_fit_end", "sbr_group_plan_destroy",
 ]

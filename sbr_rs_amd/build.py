@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

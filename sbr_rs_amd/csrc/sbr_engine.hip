@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -2131,6 +2132,152 @@ sbr_status sbr_model_fit(sbr_model* m, const uint64_t* user_ptr, const uint32_t*
     }
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
     if (st == SBR_OK) st = sbr_fit_end_lagged(p, &m->last_lagged_loss);
+    sbr_fit_plan_destroy(p);
+    return st;
+}
+
+/* ---- the rendezvous of a step through RCCL INSIDE the library (one process per GPU; xGMI within a node) --------------------
+ * ≙ the synchronised optimiser step of sequence_model.rs:92, 163-166 across processes.  A C / Rust host that runs one process per
+ * GPU needs no collective library of its own: rank 0 makes an id (sbr_comm_unique_id), the host hands its 128 bytes to the other
+ * ranks through whatever channel it has (a file, a socket, MPI), every rank calls sbr_comm_create on its device, and a step is
+ * sbr_fit_step_local + sbr_fit_step_exchange.  librccl is opened at run time (dlopen): the engine has no link-time dependency on
+ * it and hosts that bring their own transport (torch.distributed, MPI) never load it. */
+namespace {
+struct RcclId128 { char b[128]; }; /* ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank */
+struct RcclApi {
+    typedef RcclId128 Id128;
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    bool ok = false;
+};
+RcclApi* rccl_api() {
+    static RcclApi* api = [] {
+        RcclApi* a = new RcclApi;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a->lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a->lib) break;
+        }
+        if (!a->lib) return a;
+        auto sym = [&](const char* n) { return dlsym(a->lib, n); };
+        a->GetUniqueId = reinterpret_cast<decltype(a->GetUniqueId)>(sym("ncclGetUniqueId"));
+        a->CommInitRank = reinterpret_cast<decltype(a->CommInitRank)>(sym("ncclCommInitRank"));
+        a->CommDestroy = reinterpret_cast<decltype(a->CommDestroy)>(sym("ncclCommDestroy"));
+        a->GroupStart = reinterpret_cast<decltype(a->GroupStart)>(sym("ncclGroupStart"));
+        a->GroupEnd = reinterpret_cast<decltype(a->GroupEnd)>(sym("ncclGroupEnd"));
+        a->Send = reinterpret_cast<decltype(a->Send)>(sym("ncclSend"));
+        a->Recv = reinterpret_cast<decltype(a->Recv)>(sym("ncclRecv"));
+        a->AllGather = reinterpret_cast<decltype(a->AllGather)>(sym("ncclAllGather"));
+        a->ok = a->GetUniqueId && a->CommInitRank && a->CommDestroy && a->GroupStart && a->GroupEnd && a->Send && a->Recv && a->AllGather;
+        return a;
+    }();
+    return api;
+}
+constexpr int kNcclUint8 = 1; /* ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1) */
+}  // namespace
+
+struct sbr_comm {
+    void* comm = nullptr;
+    uint32_t world = 0, rank = 0;
+    int device = 0;
+    uint8_t *send = nullptr, *recv = nullptr, *own = nullptr, *table = nullptr, *dense = nullptr, *dense_all = nullptr;
+    uint64_t chunk = 0, db = 0; /* sizes the buffers were made for */
+};
+
+sbr_status sbr_comm_unique_id(uint8_t out_id[128]) {
+    if (!out_id) return SBR_ERR_INVALID_ARGUMENT;
+    RcclApi& a = *rccl_api();
+    if (!a.ok) return SBR_ERR_UNSUPPORTED; /* no librccl on this host */
+    return a.GetUniqueId(out_id) == 0 ? SBR_OK : SBR_ERR_HIP;
+}
+
+sbr_status sbr_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, sbr_comm** out) {
+    if (!id || !out || world == 0 || world > 16 || rank >= world) return SBR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    RcclApi& a = *rccl_api();
+    if (!a.ok) return SBR_ERR_UNSUPPORTED;
+    sbr_comm* c = new (std::nothrow) sbr_comm;
+    if (!c) return SBR_ERR_OUT_OF_MEMORY;
+    c->world = world; c->rank = rank;
+    (void)hipGetDevice(&c->device);
+    RcclApi::Id128 uid;
+    std::memcpy(uid.b, id, 128);
+    if (a.CommInitRank(&c->comm, (int)world, uid, (int)rank) != 0) { delete c; return SBR_ERR_HIP; }
+    *out = c;
+    return SBR_OK;
+}
+
+void sbr_comm_destroy(sbr_comm* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    if (c->comm) rccl_api()->CommDestroy(c->comm);
+    dfree(c->send); dfree(c->recv); dfree(c->own); dfree(c->table); dfree(c->dense); dfree(c->dense_all);
+    delete c;
+}
+
+/* the exchange and the update of one optimiser step (after sbr_fit_step_local): scatter -> all-to-all -> owner reduce -> all-gather
+ * of the reduced chunks -> item-table update; the dense block joins the dense-gradient GEMM late -> all-gather -> dense update.
+ * Everything is queued on the model's stream; the call does not block the host. */
+sbr_status sbr_fit_step_exchange(sbr_fit_plan* p, uint64_t minibatch, sbr_comm* c) {
+    if (!p || !c || (int)c->world != p->ndev || (int)c->rank != p->rank || minibatch >= p->ep[p->cur].num_mb || p->m->shared)
+        return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    RcclApi& a = *rccl_api();
+    uint64_t chunk = 0, db = 0;
+    SBRCHK(sbr_fit_chunk_bytes(p, &chunk));
+    SBRCHK(sbr_fit_dense_bytes(p, &db));
+    const uint32_t n = c->world;
+    if (c->chunk != chunk || c->db != db) {
+        HIPCHK(hipStreamSynchronize(m->stream));
+        dfree(c->send); dfree(c->recv); dfree(c->own); dfree(c->table); dfree(c->dense); dfree(c->dense_all);
+        c->send = c->recv = c->own = c->table = c->dense = c->dense_all = nullptr;
+        SBRCHK(dmalloc(&c->send, n * chunk)); SBRCHK(dmalloc(&c->recv, n * chunk));
+        SBRCHK(dmalloc(&c->own, chunk)); SBRCHK(dmalloc(&c->table, n * chunk));
+        SBRCHK(dmalloc(&c->dense, db)); SBRCHK(dmalloc(&c->dense_all, n * db));
+        c->chunk = chunk; c->db = db;
+    }
+    hipStream_t st = m->stream;
+    SBRCHK(sbr_fit_step_scatter(p, minibatch, c->send));
+    if (a.GroupStart() != 0) return SBR_ERR_HIP; /* all-to-all: chunk q of this rank -> rank q */
+    for (uint32_t q = 0; q < n; ++q) {
+        if (a.Send(c->send + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st) != 0) return SBR_ERR_HIP;
+        if (a.Recv(c->recv + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st) != 0) return SBR_ERR_HIP;
+    }
+    if (a.GroupEnd() != 0) return SBR_ERR_HIP;
+    SBRCHK(sbr_fit_step_owner_reduce(p, c->recv, c->own));
+    if (a.AllGather(c->own, c->table, chunk, kNcclUint8, c->comm, st) != 0) return SBR_ERR_HIP;
+    SBRCHK(sbr_fit_step_apply_rows(p, c->table));
+    SBRCHK(sbr_fit_step_dense(p, c->dense));
+    if (a.AllGather(c->dense, c->dense_all, db, kNcclUint8, c->comm, st) != 0) return SBR_ERR_HIP;
+    SBRCHK(sbr_fit_step_apply_dense(p, c->dense_all));
+    return SBR_OK;
+}
+
+/* the whole fit of THIS rank through the library's own transport: ≙ fit with num_threads(world) across processes */
+sbr_status sbr_model_fit_comm(sbr_model* m, sbr_comm* c, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users, float* out_loss) {
+    if (!m || !c || m->hp.num_devices != c->world || m->hp.device_rank != c->rank) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_fit_plan* p = nullptr;
+    SBRCHK(sbr_fit_begin(m, user_ptr, item_ids, num_users, &p));
+    sbr_status st = SBR_OK;
+    for (uint32_t e = 0; e < m->hp.num_epochs && st == SBR_OK; ++e) {
+        uint64_t nmb = 0;
+        st = sbr_fit_epoch_prepare(p, &nmb);
+        if (st == SBR_OK && e + 1 < m->hp.num_epochs) st = sbr_fit_epoch_prefetch(p);
+        for (uint64_t mb = 0; mb < nmb && st == SBR_OK; ++mb) {
+            st = sbr_fit_step_local(p, mb);
+            if (st == SBR_OK) st = sbr_fit_step_exchange(p, mb, c);
+        }
+    }
+    if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
+    if (st == SBR_OK) st = sbr_fit_end_lagged(p, &m->last_lagged_loss); /* this rank's term; hosts add the ranks' terms in rank order */
     sbr_fit_plan_destroy(p);
     return st;
 }

@@ -142,6 +142,47 @@ class GroupPlan:
             pass
 
 
+class Comm:
+    """RCCL inside the library (sbr_comm_*): for hosts with one process per GPU and no collective library of their own.
+    ``Comm.unique_id()`` on rank 0, the 128 bytes to every rank by any channel, ``Comm(id, world, rank)`` on every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(_lib.load().sbr_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, world: int, rank: int):
+        if len(uid) != 128:
+            raise ValueError("the id is 128 bytes")
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _check(self._L.sbr_comm_create((C.c_uint8 * 128)(*uid), world, rank, C.byref(h)))
+        self._h, self.world, self.rank = h, world, rank
+
+    def fit(self, model: "Model", user_ptr, item_ids) -> float:
+        """This rank's whole fit through the library's own transport (sbr_model_fit_comm)."""
+        up = np.ascontiguousarray(user_ptr, dtype=np.uint64)
+        it = np.ascontiguousarray(item_ids, dtype=np.uint32)
+        loss = C.c_float()
+        _check(self._L.sbr_model_fit_comm(model._h, self._h, _ptr(up), _ptr(it), len(up) - 1, C.byref(loss)))
+        return loss.value
+
+    def step_exchange(self, plan: "FitPlan", mb: int):
+        _check(self._L.sbr_fit_step_exchange(plan._h, mb, self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sbr_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _DBG_U32 = {1, 7, 8, 9}
 
 

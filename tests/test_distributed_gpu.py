@@ -188,3 +188,35 @@ def test_bench_group_driver_two_replicas(extra):
     assert line["host_enqueue_ms_per_step"] > 0 and set(line["modes"]) == {"library_default", "one_host_thread", "host_thread_per_device"}
     assert line["modes"]["host_thread_per_device"]["host_threads"] == 2 and line["modes"]["one_host_thread"]["host_threads"] == 1
     assert line["value"] > 0 and line["modes"]["library_default"]["interactions_timed"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,loss", [(0, LOSS_WARP), (2, LOSS_HINGE)])
+def test_rccl_inside_the_library_world_one(kind, loss):
+    """sbr_comm_*: the step's rendezvous through RCCL opened by the library itself (no torch.distributed, no host transport) — a
+    communicator of ONE rank on cuda:0 (RCCL refuses two ranks on one device, and every box of this pool has one): the whole fit
+    through sbr_model_fit_comm (scatter, ncclSend / ncclRecv all-to-all, owner reduce, ncclAllGather of the reduced chunk and of the
+    dense block, the two updates) must equal the plain single-device fit bit for bit, and the step-wise form
+    (sbr_fit_step_local + sbr_fit_step_exchange) as well."""
+    from sbr_rs_amd._abi import Param
+    from sbr_rs_amd.engine import Comm, Model
+
+    c = CASE
+    ptr, items = synthetic_interactions(c["users"], c["items"], c["T"] + 4, seed=c["seed"], zipf=True)
+    hp = hparams(c["items"], c["T"], c["d"], kind, loss, epochs=c["epochs"], B=c["B"])
+    plain, through, stepped = Model(hp), Model(hp), Model(hp)
+    comm = Comm(Comm.unique_id(), 1, 0)
+    lp = plain.fit(ptr, items)
+    lt = comm.fit(through, ptr, items)
+    plan = stepped.fit_begin(ptr, items)
+    for _ in range(c["epochs"]):
+        for mb in range(plan.epoch_prepare()):
+            plan.step_local(mb)
+            comm.step_exchange(plan, mb)
+    ls, _ = plan.end()
+    assert lt == pytest.approx(lp, rel=1e-6) and ls == pytest.approx(lp, rel=1e-6)
+    for p in PARAMS[kind]:
+        a = plain.get_param(p)
+        assert np.array_equal(a.view(np.uint32), through.get_param(p).view(np.uint32)), p.name
+        assert np.array_equal(a.view(np.uint32), stepped.get_param(p).view(np.uint32)), p.name
+    comm.close()

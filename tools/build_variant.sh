@@ -10,5 +10,5 @@ for f in sbr_kernels sbr_sort sbr_wave sbr_report sbr_engine; do
     -Wno-unused-value $flags -c "$root/sbr_rs_amd/csrc/$f.hip" -o "$out/$f.o" &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$root/sbr_rs_amd/libsbr_hip_$name.so" "$out"/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o "$root/sbr_rs_amd/libsbr_hip_$name.so" "$out"/*.o -ldl
 echo "$root/sbr_rs_amd/libsbr_hip_$name.so"

@@ -137,9 +137,10 @@ sbr_status sbr_fit_epoch_prefetch(sbr_fit_plan* p);
 sbr_status sbr_fit_step(sbr_fit_plan* p, uint64_t minibatch);
 /* `count` consecutive optimiser steps from `first` (= that many sbr_fit_step calls; sbr_model_fit runs every epoch as ONE such
  * call).  At the reference's own schedule — one subsequence per optimiser step, sequence_model.rs:111-169 (batch_sequences = 1) — with
- * embedding_dim <= 32, EWMA, a single-negative loss (hinge, BPR), Adagrad and max_sequence_length <= 129, a run of steps is ONE
- * kernel launch: one workgroup walks the steps with each step's working set in LDS (one gather per step; nobody else touches the
- * parameters at one sequence per step).  Same bits as the separate launches.  Single device. */
+ * a single-negative loss (hinge, BPR) and Adagrad, a run of steps is ONE kernel launch — EWMA at embedding_dim <= 32 and
+ * max_sequence_length <= 129; the LSTM (Normal) at embedding_dim 32 for steps of at most 48 rows (longer steps inside an epoch take
+ * the separate launches, the run resumes behind them): one workgroup walks the steps with each step's working set in LDS (one gather
+ * per step; nobody else touches the parameters at one sequence per step).  Same bits as the separate launches.  Single device. */
 sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count);
 /* How one-sequence steps at embedding_dim <= 32 are launched: 0 = one launch per kernel family (eight per step), 1 = fused
  * launches (LSTM four per step: forward, scoring + header + key ordering, BPTT, gradient + updates; EWMA two), 2 (default) =

@@ -1755,33 +1755,51 @@ sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count) {
     sbr_fit_plan::Epoch& ep = p->ep[p->cur];
     if (first > ep.num_mb || count > ep.num_mb - first) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
-    const bool one_launch = m->step_fusion >= 2 && !m->timing && !m->reference_order && p->bmax == 1 && ep.d_desc && ep.desc_host.size() == ep.num_mb &&
-                            sbr::epoch_steps_shape_ok(m->mv, p->T - 1);
-    if (!one_launch) {
+    const bool runs_ok = m->step_fusion >= 2 && !m->timing && !m->reference_order && p->bmax == 1 && ep.d_desc && ep.desc_host.size() == ep.num_mb;
+    const bool ewma_runs = runs_ok && sbr::epoch_steps_shape_ok(m->mv, p->T - 1);
+    const bool lstm_runs = runs_ok && !ewma_runs && sbr::lstm_steps_shape_ok(m->mv, p->T - 1);
+    if (!ewma_runs && !lstm_runs) {
         for (uint64_t mb = first; mb < first + count; ++mb) SBRCHK(sbr_fit_step(p, mb));
         return SBR_OK;
     }
     if (!count) return SBR_OK;
     SBRCHK(ensure_device(m));
-    if (p->lag_busy) { /* an earlier step's chain on the ordering's stream still owns lag_state */
-        HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
-        p->lag_busy = false;
-    }
-    if (p->sorted_event_live) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0)); /* (a larger step before: its ordering owned the keys) */
-    SBRCHK(join_dense(p));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     const sbr::EpochView ev{ep.dp.off, ep.dp.steps, ep.dp.prev_row, ep.dp.in_idx, ep.dp.out_idx, ep.dp.ctr, ep.d_desc};
     const sbr::SmallTail tail{bv.header, p->loss_acc, p->ex_acc, p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
     const uint64_t epoch_key = sbr_epoch_key(p->fit_seed[p->rank], ep.epoch_key_epoch);
-    for (uint64_t b = first; b < first + count; b += SBR_EPOCH_STEPS_PER_LAUNCH) {
-        const uint64_t e = std::min(first + count, b + (uint64_t)SBR_EPOCH_STEPS_PER_LAUNCH);
-        sbr::launch_epoch_steps(m->mv, ev, bv, p->wb.v, epoch_key, tail, (int)b, (int)e, p->T - 1, p->phase_clocks, m->stream);
+    const uint32_t row_cap = ewma_runs ? (uint32_t)(p->T - 1) : (uint32_t)sbr::lstm_steps_max_rows();
+    /* maximal runs of consecutive steps the one-launch form takes (the LSTM form: steps of at most row_cap rows); a longer step goes
+     * through the separate launches and the next run starts behind it */
+    uint64_t b = first;
+    const uint64_t end = first + count;
+    while (b < end) {
+        if (ep.desc_host[b].rows > row_cap) {
+            SBRCHK(sbr_fit_step(p, b));
+            ++b;
+            continue;
+        }
+        uint64_t e = b;
+        uint32_t run_max = 0;
+        while (e < end && e - b < SBR_EPOCH_STEPS_PER_LAUNCH && ep.desc_host[e].rows <= row_cap) {
+            run_max = std::max(run_max, ep.desc_host[e].rows);
+            ++e;
+        }
+        if (p->lag_busy) { /* an earlier step's chain on the ordering's stream still owns lag_state */
+            HIPCHK(hipStreamWaitEvent(m->stream, p->ev_lagged, 0));
+            p->lag_busy = false;
+        }
+        if (p->sorted_event_live) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_sorted, 0)); /* (a larger step before: its ordering owned the keys) */
+        SBRCHK(join_dense(p));
+        if (ewma_runs) sbr::launch_epoch_steps(m->mv, ev, bv, p->wb.v, epoch_key, tail, (int)b, (int)e, p->T - 1, p->phase_clocks, m->stream);
+        else sbr::launch_lstm_steps(m->mv, ev, bv, p->wb.v, epoch_key, tail, (int)b, (int)e, p->T - 1, (int)run_max, p->phase_clocks, m->stream);
+        m->opt_steps += e - b; /* Adagrad: no per-step host-side corrections */
+        p->hot_prelisted = p->sort_off_stream = p->dw_deferred = p->header_accumulated = false;
+        p->dense_unreduced_chunks = 0;
+        p->last_R = ep.mbs[e - 1].R;
+        p->last_block = p->block;
+        b = e;
     }
-    m->opt_steps += count; /* Adagrad: no per-step host-side corrections */
-    p->hot_prelisted = p->sort_off_stream = p->dw_deferred = p->header_accumulated = false;
-    p->dense_unreduced_chunks = 0;
-    p->last_R = ep.mbs[first + count - 1].R;
-    p->last_block = p->block;
     HIPCHK(hipGetLastError());
     return SBR_OK;
 }

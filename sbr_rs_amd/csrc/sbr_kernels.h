@@ -166,6 +166,13 @@ struct EpochView {
     const StepDesc* desc;
 };
 #define SBR_EPOCH_STEPS_MAX_LDS (150 * 1024)  /* dynamic LDS of the run's workgroup */
+/* The same for the LSTM (Normal, d = 32, single-negative loss, Adagrad: the reference's Criterion shape): lstm_steps_kernel walks a
+ * run of steps of at most lstm_steps_max_rows() rows each; lag_rows = max_sequence_length - 1 (the loss nodes of sbr_report.hip). */
+bool lstm_steps_shape_ok(const ModelView& m, int lag_rows_host);
+int lstm_steps_max_rows();
+void launch_lstm_steps(const ModelView& m, const EpochView& ev, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                       const SmallTail& tail, int step_begin, int step_end, int lag_rows_host, int run_max_rows_host,
+                       unsigned long long* phase_clocks, hipStream_t s);
 bool epoch_steps_shape_ok(const ModelView& m, int max_rows_host);
 void launch_epoch_steps(const ModelView& m, const EpochView& ev, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                         const SmallTail& tail, int step_begin, int step_end, int max_rows_host,

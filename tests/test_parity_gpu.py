@@ -1385,6 +1385,49 @@ def test_one_sequence_steps_fused_launches(kind, loss, d, opt, T, items, fused):
     assert g.user_representation(hist).tobytes() == o.user_representation(hist).tobytes()   # (the packed weight copies were re-emitted)
 
 
+@pytest.mark.parametrize("T,items,users", [(128, 1683, 60), (40, 31, 40), (12, 9, 40)])
+@pytest.mark.parametrize("loss", [LOSS_HINGE, LOSS_BPR])
+def test_lstm_step_runs_in_one_launch_equal_single_steps(loss, T, items, users):
+    """The LSTM's one-launch step runs (lstm_steps_kernel: Normal, d = 32, single-negative loss, Adagrad — the reference's Criterion
+    shape): sbr_fit_steps over a whole epoch equals the same steps taken one by one through the four launches, every parameter and
+    accumulator and the last step's block, bit for bit.  Steps of more than 48 rows inside the epoch (T = 128: sequences of up to
+    127 steps among the short ones) take the separate launches and the run resumes behind them; 31 and 9 items: rows repeated many
+    times inside a step."""
+    ptr, it = synthetic_interactions(users, items, T + 22, seed=7, min_len=3, zipf=True)
+    if T == 128:  # mostly short sequences (the Criterion shape) with a few long ones between them
+        lens = np.diff(ptr).astype(np.int64)
+        keep = np.where(np.arange(lens.size) % 7 == 0, lens, np.minimum(lens, 3 + np.arange(lens.size) % 30))
+        new_ptr = np.concatenate([[0], np.cumsum(keep)]).astype(np.uint64)
+        it = np.concatenate([it[int(ptr[u]):int(ptr[u]) + int(keep[u])] for u in range(lens.size)]).astype(np.uint32)
+        ptr = new_ptr
+    hp = hparams(items, T, 32, int(ModelKind.LSTM_NORMAL), loss, B=1, epochs=1)
+    a, b = Model(hp), Model(hp)
+    b.set_step_fusion(1)
+    pa, pb = a.fit_begin(ptr, it), b.fit_begin(ptr, it)
+    for epoch in range(2):
+        n = pa.epoch_prepare()
+        assert pb.epoch_prepare() == n and n > 12
+        pa.steps(0, 5); pa.steps(5, n - 5)
+        for mb in range(n):
+            pb.step(mb)
+    clocks = pa.phase_clocks()
+    assert 0 < clocks[5] <= 2 * n and pb.phase_clocks()[5] == 0
+    if T != 128:
+        assert clocks[5] == 2 * n
+    rows = pa.minibatch_rows(n - 1)
+    for w in (Debug.IN_IDX, Debug.OUT_IDX, Debug.HIDDEN, Debug.NEGATIVES, Debug.COEF, Debug.DINPUT, Debug.DENSE_GRAD, Debug.LOSS, Debug.TRIES, Debug.DZ):
+        assert pa.debug_fetch(w, rows).tobytes() == pb.debug_fetch(w, rows).tobytes(), w
+    assert pa.sparse_stats() == pb.sparse_stats()
+    assert pa.counters() == pb.counters()
+    assert pa.end_lagged() == pb.end_lagged()
+    assert pa.end() == pb.end()
+    for q in (Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.ITEM_BIAS_ACC, Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B, Param.LSTM_B_ACC):
+        assert a.get_param(q).tobytes() == b.get_param(q).tobytes(), q
+    assert a.counters() == b.counters()
+    hist = it[int(ptr[2]):int(ptr[3])]
+    assert a.user_representation(hist).tobytes() == b.user_representation(hist).tobytes()   # (the packed weight copies were re-emitted)
+
+
 @pytest.mark.parametrize("loss,d,T,items", [(LOSS_HINGE, 32, 128, 1683), (LOSS_BPR, 16, 129, 60), (LOSS_HINGE, 32, 12, 9)])
 def test_step_runs_in_one_launch_equal_single_steps(loss, d, T, items):
     """sbr_fit_steps over arbitrary runs (a prefix, an empty run, the middle, the rest) equals the same steps taken one by one,

@@ -41,7 +41,7 @@ def main():
         import criterion_bench as cb
 
         data = cb.sample_data(10_000)
-        for kind in ("ewma",):  # (the LSTM takes the four-launch form: no phase clocks)
+        for kind in ("lstm", "ewma"):
             m = cb.build(kind, data.num_items(), 1)
             run(f"criterion {kind}", m.params, data.user_pointers, data.item_ids, 3)
     else:

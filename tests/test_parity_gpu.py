@@ -1567,3 +1567,30 @@ def test_movielens_two_threads_in_reference_order():
     mo, ro = o.mrr_score(test.user_pointers, test.item_ids)
     assert np.array_equal(rg, ro) and mg == mo
     assert mg > REFERENCE_ORDER_FLOORS["lstm hinge 2 threads"], mg
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_step_runs_randomised(seed):
+    """Randomised one-sequence-per-step fits through sbr_model_fit (the one-launch step runs where the shape allows, the fused
+    launches elsewhere and for the steps a run skips) against the oracle: model (EWMA / LSTM Normal at d = 32, EWMA at d = 16),
+    loss (hinge / BPR), max_sequence_length 4..140, catalogues from 5 items (every row repeated inside a step) to 3 000, sequence
+    lengths around and across the 48-row cut of the LSTM runs, two epochs and a second fit call — every parameter, accumulator and
+    loss figure bit for bit."""
+    rs = np.random.RandomState(1000 + seed)
+    kind = [ModelKind.EWMA, ModelKind.LSTM_NORMAL, ModelKind.LSTM_NORMAL][seed % 3]
+    d = 32 if kind != ModelKind.EWMA or seed % 2 else 16
+    loss = LOSS_HINGE if rs.rand() < 0.5 else LOSS_BPR
+    T = int(rs.choice([4, 9, 33, 49, 50, 64, 129, 140]))
+    items = int(rs.choice([5, 17, 200, 3000]))
+    users = int(rs.randint(8, 40))
+    lens = rs.randint(3, T + 30, size=users)
+    lens[rs.rand(users) < 0.5] = rs.randint(3, 14)          # mostly short sequences, a few long ones between them
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    it = (rs.zipf(1.3, size=int(ptr[-1])) % items).astype(np.uint32)
+    hp = hparams(items, T, d, int(kind), loss, B=1, epochs=2, lr=float(rs.choice([0.05, 0.16])), l2=float(rs.choice([0.0, 4e-4])))
+    g, o = Model(hp), OracleModel(hp)
+    for call in range(2):
+        lg, lo = g.fit(ptr, it), o.fit(ptr, it)
+        assert lg == pytest.approx(lo, rel=1e-6), (call, lg, lo)
+        assert_params_equal(g, o, kind, f"seed {seed} call {call}: {kind.name} d {d} T {T} items {items}")
+        assert_lagged_equal(g, o, f"seed {seed} call {call}")

@@ -17,8 +17,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsbr_hip.so")
-SOURCES = ["sbr_kernels.hip", "sbr_sort.hip", "sbr_wave.hip", "sbr_report.hip", "sbr_engine.hip"]
-HEADERS = ["sbr_kernels.h", "sbr_numerics.h", "sbr_approx.h", "sbr_ziggurat_tables.h", os.path.join("..", "..", "include", "sbr_hip.h")]
+SOURCES = ["sbr_kernels.hip", "sbr_steps.hip", "sbr_sort.hip", "sbr_wave.hip", "sbr_report.hip", "sbr_engine.hip"]
+HEADERS = ["sbr_kernels.h", "sbr_device.h", "sbr_wave_seq.h", "sbr_numerics.h", "sbr_approx.h", "sbr_ziggurat_tables.h", os.path.join("..", "..", "include", "sbr_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SBR_EXTRA_FLAGS", "").split()
 

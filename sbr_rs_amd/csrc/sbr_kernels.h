@@ -155,7 +155,7 @@ bool small_back_shape_ok(const ModelView& m, int rows_host);
 /* A RUN of consecutive one-sequence optimiser steps (the reference's own schedule, sequence_model.rs:111-169) at d <= 32 in ONE
  * launch: one workgroup walks the steps with each step's working set in LDS — one gather of the step's 3 n rows and of the touched
  * rows' optimiser state, then scan, scores, backward scan, dalpha, key ordering, per-row reduction and the Adagrad updates out of
- * LDS (ewma_steps_kernel, sbr_kernels.hip).  EWMA with a single-negative loss, Adagrad, at most SBR_EWMA_STEPS_MAX_ROWS rows per
+ * LDS (ewma_steps_kernel, sbr_steps.hip).  EWMA with a single-negative loss, Adagrad, at most SBR_EWMA_STEPS_MAX_ROWS rows per
  * step.  desc[i] = the i-th step of the epoch's packed arrays (one sequence each). */
 struct StepDesc { uint32_t rows, row_base, off_base, seq_base; };
 struct EpochView {

@@ -1,7 +1,6 @@
 /* sbr_wave_seq.h — the recurrent pass of ONE sequence on one wavefront (forward and backward), as device functions: the bodies of
  * lstm_fwd_wave_kernel / lstm_bwd_wave_kernel (sbr_wave.hip: a workgroup of 256 threads per sequence, the design notes are there)
- * and of the recurrence phases of the one-launch step loop (epoch_steps_kernel, sbr_kernels.hip), which runs a whole one-sequence
- * optimiser step — forward, scoring, BPTT, dense and sparse update — in one workgroup (the reference's own schedule,
+ * (the one-launch step runs of sbr_steps.hip use the same forms out of LDS-resident operands; the reference's own schedule,
  * /root/reference/src/models/sequence_model.rs:111-169).  `lds`: the caller's dynamic shared memory;
  * forward needs (seg (D + NG D) + NG D + D + seg) floats, backward (7 seg D + D + NG D + seg). */
 #ifndef SBR_WAVE_SEQ_H

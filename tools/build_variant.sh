@@ -5,7 +5,7 @@ set -e
 name=$1; flags=$2
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build/variant_$name; mkdir -p "$out"
-for f in sbr_kernels sbr_sort sbr_wave sbr_report sbr_engine; do
+for f in sbr_kernels sbr_steps sbr_sort sbr_wave sbr_report sbr_engine; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result \
     -Wno-unused-value $flags -c "$root/sbr_rs_amd/csrc/$f.hip" -o "$out/$f.o" &
 done

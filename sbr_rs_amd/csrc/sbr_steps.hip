@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void score_refstream_kernel(ModelView m, MbVie
 // dense_apply_element, on the same lane layout (d/4 lanes x 4 elements per row), so the bits are theirs.
 #define SBR_EWMA_STEPS_MAX_ROWS 128 /* rows per step: the gather keeps 3 x 128 d / 1 024 + 12 row pieces per thread in registers */
 #define SBR_EWMA_STEPS_LDS_FLOATS(max_rows, d) \
-    (4 * (size_t)(d) + (size_t)(((max_rows) + 3) & ~3) + 8 * (size_t)(max_rows) * (d) + 9 * (size_t)(max_rows) + (d) + 1 + 12 * (size_t)(max_rows))
+    (4 * (size_t)(d) + 25 * (size_t)(((max_rows) + 3) & ~3) + 16 + 8 * (size_t)(max_rows) * (d) + 6 * (size_t)(max_rows) + (d) + 4)
 template <int D>
 __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView ev, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail,
                                                          int step_begin, int step_end, int max_rows, unsigned long long* prof) {
@@ -185,7 +185,14 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
     float* alphaAcc = alphaL + D;            // [D]
     float* sigA = alphaAcc + D;              // [2 D] sigmoid(alpha) | 1 - sigmoid(alpha) of the step in flight
     float* lagN = sigA + 2 * D;              // [max_rows] loss nodes (sbr_report.hip)
-    float* stepL = lagN + ((max_rows + 3) & ~3);
+    /* index work of a step — ids, keys, their order — is done a step AHEAD by waves 2-3, which have nothing else to do while wave 0
+     * scans: two buffers of ids and ordered keys, one scratch of unordered keys */
+    const int MR4 = (max_rows + 3) & ~3;
+    uint32_t* idsBuf = reinterpret_cast<uint32_t*>(lagN + MR4);            // [2][3 MR4]
+    uint64_t* kaS = reinterpret_cast<uint64_t*>(idsBuf + 6 * MR4);         // [3 MR4 + 8] (eight sentinels behind the keys)
+    uint64_t* kbBuf = kaS + 3 * MR4 + 8;                                   // [2][3 MR4]
+    float* stepL = reinterpret_cast<float*>(kbBuf + 6 * MR4);
+    const int t2 = tid - 128;  // waves 2-3: row of the step they prepare
     for (int k = tid; k < D; k += 256) { alphaL[k] = m.alpha[k]; alphaAcc[k] = m.alpha_acc[k]; }
     for (int t = tid; t < max_rows; t += 256) lagN[t] = tail.lag_state[1 + 2 * t];
     float lag_acc = tail.lag_state[0];
@@ -195,10 +202,61 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
     unsigned long long pc[5] = {0, 0, 0, 0, 0};
     unsigned long long tq = clock64();
 #define SBR_PHASE_CLOCK(i) { const unsigned long long now = clock64(); pc[i] += now - tq; tq = now; }
-    /* the ids of the first step (later ones are requested a step ahead) */
+    /* ids, keys and key order of a step (waves 2-3; the keys' stable order by row: distinct keys, so the rank of a key among all of
+     * them is its place — eight keys per batch, their LDS reads independent of each other and of the count: a dependent read per
+     * key cost a ~30-key step 1.6 us, a v_readlane broadcast of the keys 1.9 us) */
+    auto index_ids = [&](const StepDesc& d, int buf) {
+        if (t2 >= 0 && t2 < (int)d.rows) {
+            const uint32_t vin = ev.in_idx[d.row_base + t2], vout = ev.out_idx[d.row_base + t2];
+            const uint32_t ng = sbr_neg_draw(epoch_key, ev.ctr[d.row_base + t2], 0u, m.num_items);
+            uint32_t* ib = idsBuf + (size_t)buf * 3 * MR4;
+            ib[t2] = vin; ib[d.rows + t2] = vout; ib[2 * d.rows + t2] = ng;
+            kaS[3 * t2] = ((uint64_t)vin << 32) | (uint32_t)(3 * t2);
+            kaS[3 * t2 + 1] = ((uint64_t)vout << 32) | (uint32_t)(3 * t2 + 1);
+            kaS[3 * t2 + 2] = ((uint64_t)ng << 32) | (uint32_t)(3 * t2 + 2);
+        }
+        if (t2 >= 0 && t2 < 8) kaS[3 * d.rows + t2] = ~0ull;  // sentinels: the ranking reads whole batches of eight keys
+    };
+    auto index_rank = [&](const StepDesc& d, int buf) {
+        if (t2 < 0) return;
+        const int m3 = 3 * (int)d.rows;
+        uint64_t* kbn = kbBuf + (size_t)buf * 3 * MR4;
+        /* a thread ranks up to three keys (t2, t2 + 128, t2 + 256) in ONE pass over the keys: eight keys per batch, their LDS reads
+         * independent of each other and of the counts */
+        const uint64_t key0 = t2 < m3 ? kaS[t2] : ~0ull;
+        if (m3 <= 128) {
+            int r0 = 0;
+            for (int j0 = 0; j0 < m3; j0 += 8) {
+                uint64_t kk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kk[q] = kaS[j0 + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) r0 += kk[q] < key0 ? 1 : 0;
+            }
+            if (t2 < m3) kbn[r0] = key0;
+        } else {
+            const uint64_t key1 = t2 + 128 < m3 ? kaS[t2 + 128] : ~0ull, key2 = t2 + 256 < m3 ? kaS[t2 + 256] : ~0ull;
+            int r0 = 0, r1 = 0, r2 = 0;
+            for (int j0 = 0; j0 < m3; j0 += 8) {
+                uint64_t kk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kk[q] = kaS[j0 + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    r0 += kk[q] < key0 ? 1 : 0;
+                    r1 += kk[q] < key1 ? 1 : 0;
+                    r2 += kk[q] < key2 ? 1 : 0;
+                }
+            }
+            if (t2 < m3) kbn[r0] = key0;
+            if (t2 + 128 < m3) kbn[r1] = key1;
+            if (t2 + 256 < m3) kbn[r2] = key2;
+        }
+    };
     StepDesc sd = ev.desc[step_begin];
-    uint32_t nin = 0, nout = 0, nctr = 0;
-    if (tid < (int)sd.rows) { nin = ev.in_idx[sd.row_base + tid]; nout = ev.out_idx[sd.row_base + tid]; nctr = ev.ctr[sd.row_base + tid]; }
+    index_ids(sd, step_begin & 1);
+    __syncthreads();
+    index_rank(sd, step_begin & 1);
     __syncthreads();
     for (int st = step_begin; st < step_end; ++st) {
         const int n = (int)sd.rows, n3 = 3 * n;
@@ -209,33 +267,22 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
         float* H = N + (size_t)n * D;        // [n][D] s_t
         float* DS = H + (size_t)n * D;       // [n][D] dloss/ds_t, then dX_t in place
         float* A = DS + (size_t)n * D;       // [3n][D] optimiser state (E_acc) of the row at segment head p
-        uint32_t* iin = reinterpret_cast<uint32_t*>(A + (size_t)n3 * D);
-        uint32_t* iout = iin + n;
-        uint32_t* ineg = iout + n;
-        float* bp = reinterpret_cast<float*>(ineg + n);  // b[out_t], b[neg_t] and their optimiser state
+        const int cur = st & 1;
+        const uint32_t* iin = idsBuf + (size_t)cur * 3 * MR4;
+        const uint32_t* iout = iin + n;
+        const uint32_t* ineg = iout + n;
+        const uint64_t* kb = kbBuf + (size_t)cur * 3 * MR4;
+        float* bp = A + (size_t)n3 * D;      // b[out_t], b[neg_t] and their optimiser state
         float* bn = bp + n;
         float* bpa = bn + n;
         float* bna = bpa + n;
         float* coef = bna + n;
         float* lossv = coef + n;
         float* dab = lossv + n;              // [D]
-        uint64_t* ka = reinterpret_cast<uint64_t*>(dab + D + ((9 * n + D) & 1));  // 8-byte aligned: stepL and n D are multiples of 4
-        uint64_t* kb = ka + n3;
-        /* ---- ids (registers -> LDS), keys; the next step's ids are requested now */
-        if (tid < n) {
-            const uint32_t ng = sbr_neg_draw(epoch_key, nctr, 0u, m.num_items);
-            iin[tid] = nin; iout[tid] = nout; ineg[tid] = ng;
-            ka[3 * tid] = ((uint64_t)nin << 32) | (uint32_t)(3 * tid);
-            ka[3 * tid + 1] = ((uint64_t)nout << 32) | (uint32_t)(3 * tid + 1);
-            ka[3 * tid + 2] = ((uint64_t)ng << 32) | (uint32_t)(3 * tid + 2);
-        }
         StepDesc sdn = sd;
-        if (!last) {
-            sdn = ev.desc[st + 1];
-            if (tid < (int)sdn.rows) { nin = ev.in_idx[sdn.row_base + tid]; nout = ev.out_idx[sdn.row_base + tid]; nctr = ev.ctr[sdn.row_base + tid]; }
-        }
-        __syncthreads();
-        /* ---- the gather of the 3 n rows is requested first (16-byte pieces into registers, up to RQ per thread and array) ... */
+        if (!last) sdn = ev.desc[st + 1];
+        /* ---- ONE batch of requests: the 3 n rows (16-byte pieces into registers, up to RQ per thread and array), the biases and
+         * their optimiser state, and E_acc of every segment head's row (the order of this step's keys was made a step ago) */
         const int nq = n * L;  // pieces per array
         float4 vx[RQ], vp[RQ], vn[RQ];
 #pragma unroll
@@ -253,10 +300,8 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
             const uint32_t po = iout[tid], pn = ineg[tid];
             b0 = m.b[po]; b1 = m.b[pn]; a0 = m.bacc[po]; a1 = m.bacc[pn];
         }
-        /* ... and while it travels the waves SPECIALISE (a lone wave pays ~9 cycles per instruction, so what a step costs is the
-         * longest instruction sequence any one wave runs between two barriers): waves 0.. rank the keys — the stable order by row
-         * (distinct keys, so the rank of a key among all of them is its place) — while the LAST wave forms sigmoid(alpha) for the
-         * scans */
+        /* (a lone wave pays ~9 cycles per instruction, so what a step costs is the longest instruction sequence any one wave runs
+         * between two barriers: the waves specialise) — the last wave forms sigmoid(alpha) for the scans while the rows travel */
         const int wave = tid >> 6;
         if (wave == 3) {
             if (lane < D) {
@@ -265,28 +310,8 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
                 sigA[D + lane] = 1.0f - av;
             }
         }
-        if (wave < 3 || n3 > 192) {
-            const int nrank = n3 > 192 ? 256 : 192;  // (up to 192 keys: waves 0-2 hold one key each)
-            for (int e0 = 0; e0 < n3; e0 += nrank) {
-                const int e = e0 + tid;
-                const uint64_t k = e < n3 ? ka[e] : ~0ull;
-                int rank = 0;
-                /* eight keys per batch, their LDS reads independent of each other and of the count (a dependent read per key cost a
-                 * ~30-key step 1.6 us; broadcasting the keys out of lane registers with v_readlane 1.9 us: every scalar read-back
-                 * stalls the vector pipe) */
-                for (int j0 = 0; j0 < n3; j0 += 8) {
-                    uint64_t kk[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) kk[q] = ka[j0 + q < n3 ? j0 + q : n3 - 1];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) rank += (j0 + q < n3 && kk[q] < k) ? 1 : 0;
-                }
-                if (e < n3) kb[rank] = k;
-            }
-        }
-        __syncthreads();
-        /* the optimiser state (E_acc) of every segment head's row, requested as soon as the order is known: piece (p, lg) by the
-         * thread that will update it — it stays in flight underneath the scan and lands in LDS before the update */
+        /* the optimiser state (E_acc) of every segment head's row: piece (p, lg) by the thread that will update it — it stays in
+         * flight underneath the scan and lands in LDS before the update */
         const int hq = (n3 + NGRP - 1) / NGRP;  // head rounds this step needs (workgroup-uniform)
         float4 ha[HQ];
 #pragma unroll
@@ -333,6 +358,7 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
                 if (p < n3) st4(A + (size_t)p * D + 4 * lg, ha[i]);
             }
         }
+        if (!last) index_ids(sdn, cur ^ 1);  /* waves 2-3, beside wave 0's scan */
         __syncthreads();
         /* ---- scores, loss, dloss/ds of every step (ewma.rs:315-335): a lane group per row */
         for (int r0 = 0; r0 < n; r0 += NGRP) {  // workgroup-uniform trip count (the DPP reductions want whole groups)
@@ -412,6 +438,8 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
                     w.part_tries[0] = (unsigned int)n;
                 }
             }
+        } else if (!last) {
+            index_rank(sdn, cur ^ 1);  /* waves 2-3, beside the backward scan */
         }
         __syncthreads();
         SBR_PHASE_CLOCK(2)

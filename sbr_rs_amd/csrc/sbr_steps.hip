@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void ewma_steps_kernel(ModelView m, EpochView 
 // update rewrites LDS and global memory); the packed weight copies (Wp / WTp) are re-emitted once after the run.  Arithmetic: operation for operation that of the
 // launches it replaces, so the bits are theirs (tests run both).
 #define SBR_LSTM_STEPS_MAX_ROWS 48 /* rows per step: one 16-byte piece per thread and gathered array, 3 head rounds per lane group; LDS */
-#define SBR_LSTM_STEPS_LDS_FLOATS(max_rows) ((size_t)(((max_rows) + 3) & ~3) + 128 + 65 * 128 + (size_t)(max_rows) * (32 * 7 + 128 * 2 + 96) + 32 + 9 * (size_t)(max_rows) + 1 + 12 * (size_t)(max_rows))
+#define SBR_LSTM_STEPS_LDS_FLOATS(max_rows) ((size_t)(((max_rows) + 3) & ~3) + 128 + 65 * 128 + 24 * SBR_LSTM_STEPS_MAX_ROWS + 16 + (size_t)(max_rows) * (32 * 7 + 128 * 2 + 96) + 32 + 9 * (size_t)(max_rows) + 1 + 12 * (size_t)(max_rows))
 __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView ev, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail,
                                                          int step_begin, int step_end, int max_rows /* loss nodes: max_sequence_length - 1 */,
                                                          unsigned long long* prof) {
@@ -583,7 +583,14 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
     float* Zs = lagN + ((max_rows + 3) & ~3);           // [NGD] dz of the backward step in flight
     float* WL = Zs + NGD;                               // [2D][NGD] the LSTM weights, resident for the run (rows [x ; h])
     float* bWL = WL + (size_t)K2 * NGD;                 // [NGD]
-    float* stepL = bWL + NGD;
+    /* a step's index work — ids, the negatives' hash, the keys and their order — is done a step AHEAD (ids and keys beside the
+     * x half, the ranking on waves 1-3 beside wave 0's forward recurrence): two buffers of ids and ordered keys, one scratch of
+     * unordered keys with eight sentinels behind them */
+    constexpr int MR = SBR_LSTM_STEPS_MAX_ROWS;
+    uint32_t* idsBuf = reinterpret_cast<uint32_t*>(bWL + NGD);           // [2][3 MR]
+    uint64_t* kaS = reinterpret_cast<uint64_t*>(idsBuf + 6 * MR);        // [3 MR + 8]
+    uint64_t* kbBuf = kaS + 3 * MR + 8;                                  // [2][3 MR]
+    float* stepL = reinterpret_cast<float*>(kbBuf + 6 * MR);
     for (int t = tid; t < max_rows; t += NT) lagN[t] = tail.lag_state[1 + 2 * t];
     for (int i = tid; i < K2 * NGD / 4; i += NT) st4(WL + 4 * (size_t)i, ld4(m.W + 4 * (size_t)i));
     if (tid < NGD) bWL[tid] = m.bW[tid];
@@ -597,6 +604,34 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
     StepDesc sd = ev.desc[step_begin];
     uint32_t nin = 0, nout = 0, nctr = 0;
     if (tid < (int)sd.rows) { nin = ev.in_idx[sd.row_base + tid]; nout = ev.out_idx[sd.row_base + tid]; nctr = ev.ctr[sd.row_base + tid]; }
+    auto index_ids = [&](const StepDesc& d, int buf) {  // threads < rows hold the step's ids in registers
+        if (tid < (int)d.rows) {
+            const uint32_t ng = sbr_neg_draw(epoch_key, nctr, 0u, m.num_items);
+            uint32_t* ib = idsBuf + (size_t)buf * 3 * MR;
+            ib[tid] = nin; ib[d.rows + tid] = nout; ib[2 * d.rows + tid] = ng;
+            kaS[3 * tid] = ((uint64_t)nin << 32) | (uint32_t)(3 * tid);
+            kaS[3 * tid + 1] = ((uint64_t)nout << 32) | (uint32_t)(3 * tid + 1);
+            kaS[3 * tid + 2] = ((uint64_t)ng << 32) | (uint32_t)(3 * tid + 2);
+        }
+        if (tid >= 64 && tid < 72) kaS[3 * d.rows + (tid - 64)] = ~0ull;  // sentinels: the ranking reads whole batches of eight keys
+    };
+    auto index_rank = [&](const StepDesc& d, int buf) {  // waves 1-3: one key per thread (3 rows <= 144 keys)
+        const int e = tid - 64, m3 = 3 * (int)d.rows;
+        if (e < 0 || e >= 192) return;
+        const uint64_t key = e < m3 ? kaS[e] : ~0ull;
+        int rank = 0;
+        for (int j0 = 0; j0 < m3; j0 += 8) {
+            uint64_t kk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) kk[q] = kaS[j0 + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rank += kk[q] < key ? 1 : 0;
+        }
+        if (e < m3) (kbBuf + (size_t)buf * 3 * MR)[rank] = key;
+    };
+    index_ids(sd, step_begin & 1);
+    __syncthreads();
+    index_rank(sd, step_begin & 1);
     __syncthreads();
     for (int st = step_begin; st < step_end; ++st) {
         const int n = (int)sd.rows, n3 = 3 * n;
@@ -611,33 +646,25 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
         float* G = DH + (size_t)n * D;                   // [n][4D]  gate values
         float* PZ = G + (size_t)n * NGD;                 // [n][4D]  bias + x part of the pre-activations, then dz_t
         float* A = PZ + (size_t)n * NGD;                 // [3n][D]  optimiser state (E_acc) of the row at segment head p
-        uint32_t* iin = reinterpret_cast<uint32_t*>(A + (size_t)n3 * D);
-        uint32_t* iout = iin + n;
-        uint32_t* ineg = iout + n;
-        float* bp = reinterpret_cast<float*>(ineg + n);
+        const int cur = st & 1;
+        const uint32_t* iin = idsBuf + (size_t)cur * 3 * MR;
+        const uint32_t* iout = iin + n;
+        const uint32_t* ineg = iout + n;
+        const uint64_t* kb = kbBuf + (size_t)cur * 3 * MR;
+        float* bp = A + (size_t)n3 * D;
         float* bn = bp + n;
         float* bpa = bn + n;
         float* bna = bpa + n;
         float* coef = bna + n;
         float* lossv = coef + n;
-        uint64_t* ka = reinterpret_cast<uint64_t*>(lossv + n + ((9 * n + D) & 1));  // 8-byte aligned (D of Cc's extra row)
-        uint64_t* kb = ka + n3;
-        /* ---- ids (registers -> LDS), keys; the next step's ids are requested now */
-        if (tid < n) {
-            const uint32_t ng = sbr_neg_draw(epoch_key, nctr, 0u, m.num_items);
-            iin[tid] = nin; iout[tid] = nout; ineg[tid] = ng;
-            ka[3 * tid] = ((uint64_t)nin << 32) | (uint32_t)(3 * tid);
-            ka[3 * tid + 1] = ((uint64_t)nout << 32) | (uint32_t)(3 * tid + 1);
-            ka[3 * tid + 2] = ((uint64_t)ng << 32) | (uint32_t)(3 * tid + 2);
-        }
-        if (tid < D) Cc[tid] = 0.0f;  // c_{-1}
+        /* the next step's ids are requested now (registers of threads < rows; they become LDS ids and keys beside the x half) */
         StepDesc sdn = sd;
         if (!last) {
             sdn = ev.desc[st + 1];
             if (tid < (int)sdn.rows) { nin = ev.in_idx[sdn.row_base + tid]; nout = ev.out_idx[sdn.row_base + tid]; nctr = ev.ctr[sdn.row_base + tid]; }
         }
-        __syncthreads();
-        /* ---- the gather (one 16-byte piece per thread and array) and this step's weights are requested ... */
+        /* ---- ONE batch of requests: the 3 n rows (one 16-byte piece per thread and array), the biases and their optimiser state,
+         * E_acc of every segment head's row (the order of this step's keys was made a step ago) */
         const int nq = n * L;
         float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vp = vx, vn = vx;
         if (tid < nq) {
@@ -652,21 +679,6 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
             b0 = m.b[po]; b1 = m.b[pn]; a0 = m.bacc[po]; a1 = m.bacc[pn];
         }
         const int stream = tid / NGD, jx = tid % NGD;
-        /* ... and while they travel waves 1-3 rank the keys (the stable order by row) */
-        if (wave >= 1 && wave <= 3) {
-            const int e = tid - 64;
-            const uint64_t k = e < n3 ? ka[e] : ~0ull;
-            int rank = 0;
-            for (int j0 = 0; j0 < n3; j0 += 8) {
-                uint64_t kk[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) kk[q] = ka[j0 + q < n3 ? j0 + q : n3 - 1];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rank += (j0 + q < n3 && kk[q] < k) ? 1 : 0;
-            }
-            if (e < n3) kb[rank] = k;
-        }
-        __syncthreads();
         const int hq = (n3 + NGRP - 1) / NGRP;
         float4 ha[HQ];
 #pragma unroll
@@ -686,6 +698,7 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
             st4(N + 4 * (size_t)tid, vn);
         }
         if (tid < n) { bp[tid] = b0; bn[tid] = b1; bpa[tid] = a0; bna[tid] = a1; }
+        if (tid < D) Cc[tid] = 0.0f;  // c_{-1}
         __syncthreads();
         SBR_PHASE_CLOCK(0)
         /* ---- x half: P_t = bW + x_t Wx (the k order puts it first, so it does not depend on the recurrence): thread (stream, jx)
@@ -715,8 +728,10 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
                 if (p < n3) st4(A + (size_t)p * D + 4 * lg, ha[i]);
             }
         }
+        if (!last) index_ids(sdn, cur ^ 1);
         __syncthreads();
-        /* ---- forward recurrence: wave 0 alone, no barriers (lstm_fwd_wave_seq, d = 32 with four gates) */
+        /* ---- forward recurrence: wave 0 alone, no barriers (lstm_fwd_wave_seq, d = 32 with four gates); waves 1-3 meanwhile order
+         * the next step's keys */
         if (wave == 0) {
             v2f w2[D];  // the h rows of gate columns lane and 64 + lane
 #pragma unroll
@@ -758,6 +773,8 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
                     H[(size_t)i * D + u] = h_prev;
                 }
             }
+        } else if (!last) {
+            index_rank(sdn, cur ^ 1);
         }
         __syncthreads();
         SBR_PHASE_CLOCK(1)

@@ -573,8 +573,8 @@ sbr_status alloc_work(const sbr_model* m, uint64_t rmax, uint64_t bmax, bool tra
         SBRCHK(dmalloc(&v.dH, rmax * d));
         SBRCHK(dmalloc(&v.loss, rmax));
         SBRCHK(dmalloc(&v.tries, rmax));
-        SBRCHK(dmalloc(&v.part_loss, 8192));
-        SBRCHK(dmalloc(&v.part_tries, 8192));
+        SBRCHK(dmalloc(&v.part_loss, 2048));
+        SBRCHK(dmalloc(&v.part_tries, 2048));
         if (m->ng) {
             const uint64_t rchunk = (rmax + SBR_DW_CHUNK_ROWS - 1) / SBR_DW_CHUNK_ROWS * SBR_DW_CHUNK_ROWS;
             SBRCHK(dmalloc(&v.dZ, rchunk * d * (uint64_t)m->ng)); /* the dense-gradient GEMM reads dZ to the end of the last chunk */

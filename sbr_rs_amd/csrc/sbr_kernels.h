@@ -63,7 +63,7 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     float* partials;        /* dense-gradient chunk partials */
     float* loss;            /* [Rmax] */
     uint32_t* tries;        /* [Rmax] */
-    double* part_loss;      /* per-workgroup partials of the score kernel [8192] */
+    double* part_loss;      /* per-workgroup partials of the score kernel [2048] */
     unsigned int* part_tries;
     float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM, 64-bit address path) */
     int fold_max_tiles;     /* the recurrent kernels fold their length-sorted tile list up to this many tiles */

@@ -84,6 +84,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // SmallTail of a one-sequence step are in sbr_device.h: sbr_steps.hip shares them)
 
 
+// Streaming (non-temporal, `nt`) forms of the 16-byte row accesses, per kernel family by measurement
+// (profiles/r05_streaming_gathers.md; the SBR_NT_* macros are build-time A/B hooks, tools/build_variant.sh):
+//   score kernels (table rows gathered once, h rows read once): ON — the launch is 10-12 % shorter in the step (0.49-0.55 ->
+//     0.55-0.59 of HBM; the cache-cold 4 M-item table 0.43 -> 0.51) because its 0.5 GB of one-touch rows no longer displace what
+//     the forward pass left for BPTT and what the Infinity Cache holds of the table;
+//   sparse update's parameter / optimiser-state rows (read, rewritten once per step): ON (step -0.5 %, the GEMM beside it -1.5 %);
+//   forward gather: OFF (its rows are the score kernel's target rows one step later: cached, they are hits there);
+//   BPTT's re-gather: neutral; the EWMA scans: OFF (the backward scan re-reads what the forward scan gathered: 1.36 -> 1.57 ms).
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4s(const float* p) {
+    const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+    v4f_nt t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_nt*>(p));
+}
+#ifndef SBR_NT_SCORE
+#define SBR_NT_SCORE 1
+#endif
+#ifndef SBR_NT_UPD
+#define SBR_NT_UPD 1
+#endif
+#ifndef SBR_NT_UPD_ST
+#define SBR_NT_UPD_ST 1
+#endif
+__device__ __forceinline__ float4 ld4_score(const float* p) { return SBR_NT_SCORE ? ld4s(p) : ld4(p); }
+__device__ __forceinline__ float4 ld4_upd(const float* p) { return SBR_NT_UPD ? ld4s(p) : ld4(p); }
+__device__ __forceinline__ void st4_upd(float* p, float4 v) { if (SBR_NT_UPD_ST) st4s(p, v); else st4(p, v); }
+
 // ------------------------------------------------------------------------------------------------
 // K1+K3+K4: gather + negative sampling + loss + dloss/dh  (the HBM-roofline kernel)
 // One d/4-lane group per packed row; 16 B per lane per gathered embedding row.
@@ -106,6 +136,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
     const int lg = lane % L;
     const int grp = lane / L;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
+    auto ldrow = [](const float* p) { return SPEC ? ld4(p) : ld4_score(p); };  // (a one-workgroup step re-reads its rows: cached)
     static_assert(SBR_WARP_MAX_TRIES <= 8, "one candidate per lane of an 8-lane group");
     const bool spread = L >= 8 && max_tries > 1;
     double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
@@ -124,7 +155,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
             const int rr0 = r0 < mb.R ? r0 : last_row;
             pi_n[u] = mb.out_idx[rr0];
             ctr_n[u] = mb.ctr[rr0];
-            h_n[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+            h_n[u] = ldrow(blk.H + (size_t)rr0 * D + 4 * lg);
         }
     }
     for (; base < mb.R; base += nwaves * RPW) {
@@ -143,16 +174,16 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
                 const int rr0 = r0 < mb.R ? r0 : last_row;
                 pi[u] = mb.out_idx[rr0];
                 ctr[u] = mb.ctr[rr0];
-                h[u] = ld4(blk.H + (size_t)rr0 * D + 4 * lg);
+                h[u] = ldrow(blk.H + (size_t)rr0 * D + 4 * lg);
             }
-            ep[u] = ld4(m.E + (size_t)pi[u] * D + 4 * lg);
+            ep[u] = ldrow(m.E + (size_t)pi[u] * D + 4 * lg);
             bp[u] = m.b[pi[u]];
             // WARP: lane lg of the group draws candidate lg & 7 — the five draws of the row cost one evaluation of the
             // 64-bit hash instead of one per try (every lane would compute the same value); try k reads lane k's
             draws[u] = sbr_neg_draw(epoch_key, ctr[u], spread ? (uint32_t)(lg & 7) : 0u, m.num_items);
             // first candidate is always scored: issue its gather together with the positive's
             cand[u] = spread ? (uint32_t)__shfl((int)draws[u], grp * L, 64) : draws[u];
-            ec[u] = ld4(m.E + (size_t)cand[u] * D + 4 * lg);
+            ec[u] = ldrow(m.E + (size_t)cand[u] * D + 4 * lg);
             bc[u] = m.b[cand[u]];
         }
         if constexpr (PF) {
@@ -162,7 +193,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
                 const int rrn = rn < mb.R ? rn : last_row;
                 pi_n[u] = mb.out_idx[rrn];
                 ctr_n[u] = mb.ctr[rrn];
-                h_n[u] = ld4(blk.H + (size_t)rrn * D + 4 * lg);
+                h_n[u] = ldrow(blk.H + (size_t)rrn * D + 4 * lg);
             }
         }
 #pragma unroll
@@ -185,7 +216,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
 #pragma unroll
                 for (int k = 1; k < SBR_WARP_MAX_TRIES; ++k) {
                     cds[u][k] = spread ? (uint32_t)__shfl((int)draws[u], grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr[u], (uint32_t)k, m.num_items);
-                    ecs[u][k] = ld4(m.E + (size_t)cds[u][k] * D + 4 * lg);
+                    ecs[u][k] = ldrow(m.E + (size_t)cds[u][k] * D + 4 * lg);
                     bcs[u][k] = m.b[cds[u][k]];
                 }
             }
@@ -215,7 +246,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
                 for (int u = 0; u < U; ++u) {
                     cand[u] = spread ? (uint32_t)__shfl((int)draws[u], grp * L + k, 64) : sbr_neg_draw(epoch_key, ctr[u], (uint32_t)k, m.num_items);
                     if (!done[u]) {
-                        ec[u] = ld4(m.E + (size_t)cand[u] * D + 4 * lg);
+                        ec[u] = ldrow(m.E + (size_t)cand[u] * D + 4 * lg);
                         bc[u] = m.b[cand[u]];
                     }
                 }
@@ -255,192 +286,6 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
     *tries_out = tries_part;
 }
 
-// The REFILL form of the WARP search (round 5): a lane group's row slot takes its next row the moment the row it holds ends its
-// search, instead of waiting for the longest search among the wave's rows and for a round of ids in front of every pass.  The
-// lockstep form above runs 1 + max-over-the-wave's-rows rounds of dependent gathers per pass (~4 at the headline shape, of which
-// only the second has every slot requesting rows) and is the LATENCY of those rounds (28 % VALU-busy, 0.55 of HBM); here every
-// resident slot has a candidate row outstanding in EVERY round (and, for a fresh row, its h and target rows): ~1.75 rounds per row
-// and slot.  What makes that pay is the instruction count of a round (a first refill form that re-did the lockstep form's per-row
-// index work every round was VALU-bound and 12 % slower): a slot's index work is done once per RUN of L/8 consecutive rows — the
-// lanes of the group hold (row of the run, try) pairs: ids, counters and the 64-bit hash of the draws are one evaluation per run,
-// a row's target id and candidates come out of those registers by ds_bpermute — and every address is a 32-bit byte offset on a
-// scalar base (tables below 4 GiB; larger ones keep the lockstep form).  A wave owns a contiguous share of the rows (static: the
-// walk is a function of the data alone, so the order-free f64 loss partial is reproducible); its slots draw runs from that share
-// in slot order, the next run's ids travelling underneath the rounds of the current one.  Same arithmetic per row, same tests in
-// the same order: NEGATIVES / TRIES / coefficients are the lockstep form's bits.
-#ifdef SBR_SCORE_PROF
-// development only (tools/score_ubench.hip): [0] waves, [1] rounds, [2] cycles in a round's index work + requests, [3] cycles from the
-// last request to the end of the round, [4] wave lifetimes (cycles), [5] longest wave (cycles), [6] first start, [7] last end (100 MHz)
-__device__ unsigned long long g_score_prof[8];
-#define SBR_SP(x) x
-#else
-#define SBR_SP(x)
-#endif
-__device__ __forceinline__ float4 ld4_at(const float* base, uint32_t byte_off) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ T ld_at(const T* base, uint32_t byte_off) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ void st_at(T* base, uint32_t byte_off, T v) {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
-}
-template <int D, int U>
-__device__ __forceinline__ void score_warp_refill(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
-                                                  uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
-    constexpr int L = D / 4;
-    static_assert(L >= 8, "a run's (row, try) pairs need eight lanes per row");
-    constexpr int QR = L / 8;               // rows per run
-    constexpr int LOGD4 = D == 32 ? 7 : D == 64 ? 8 : D == 128 ? 9 : 10;  // log2 of a row's bytes
-    const int lane = threadIdx.x & 63;
-    const int lg = lane % L;
-    const int grp = lane / L;
-    const int sub = lg >> 3;                // the row of the run this lane's id registers describe
-    const uint32_t lgoff = 16u * (uint32_t)lg;
-    const uint32_t gl4 = 4u * (uint32_t)(grp * L);  // ds_bpermute address of the group's first lane
-    double loss_part = 0.0;
-    unsigned int tries_part = 0;
-    // the wave's runs: run k of the wave is run (wave + k nwaves) of the launch — at any time the chip walks a moving window of
-    // the rows (h rows, ids, results: streams), not nwaves far-apart places
-    const int R = mb.R;
-    int pool = wave * QR;
-    const int pool_step = nwaves * QR;
-    int row[U], qrow[U], nqrow[U];
-    uint32_t j[U], qpi[U], qdraw[U], nqpi[U], nqctr[U], nqin[U], tries[U];
-    float pos[U];
-    float4 h[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        row[u] = -1; qrow[u] = -1; nqrow[u] = -1;
-        j[u] = 0; qpi[u] = 0; qdraw[u] = 0; nqpi[u] = 0; nqctr[u] = 0; nqin[u] = 0; tries[u] = 0;
-        pos[u] = 0.0f;
-        h[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    SBR_SP(unsigned long long pr_rounds = 0; unsigned long long pr_issue = 0; unsigned long long pr_rest = 0;
-           const unsigned long long pr_t_begin = __builtin_readcyclecounter(); const unsigned long long pr_w_begin = wall_clock64();)
-    for (;;) {
-        SBR_SP(const unsigned long long pr_t0 = __builtin_readcyclecounter();)
-        // a slot whose row ended: the next row of its run, or the run whose ids arrived underneath the last rounds
-        bool live = false, want = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (row[u] < 0) {
-                if (qrow[u] >= 0 && (int)j[u] + 1 < QR && qrow[u] + (int)j[u] + 1 < R) {
-                    ++j[u];
-                    row[u] = qrow[u] + (int)j[u];
-                } else if (nqrow[u] >= 0) {
-                    qrow[u] = nqrow[u];
-                    j[u] = 0;
-                    row[u] = qrow[u];
-                    qpi[u] = nqpi[u];
-                    qdraw[u] = sbr_neg_draw(epoch_key, nqctr[u], (uint32_t)(lg & 7), m.num_items);
-                    if ((lg & 7) == 0 && qrow[u] + sub < R) {  // the block's copy of the run's ids
-                        st_at(blk.in_idx, 4u * (uint32_t)(qrow[u] + sub), nqin[u]);
-                        st_at(blk.out_idx, 4u * (uint32_t)(qrow[u] + sub), nqpi[u]);
-                    }
-                    nqrow[u] = -1;
-                } else {
-                    qrow[u] = -1;
-                }
-                tries[u] = 0;
-            }
-            live = live || row[u] >= 0;
-            want = want || nqrow[u] < 0;
-        }
-        // (the exit test comes BEFORE this round's requests: every path from a request to the loop's back edge then runs through
-        // the round's wait, and the compiler's wait-count bookkeeping sees no request pending at the loop header)
-        {
-            bool more = live || pool < R;
-#pragma unroll
-            for (int u = 0; u < U; ++u) more = more || nqrow[u] >= 0;
-            if (!__any(more)) break;
-        }
-        // every slot without a next run draws one from the wave's share (slot order) and requests its ids
-        if (__any(want) && pool < R) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool need = nqrow[u] < 0;
-                const unsigned long long mk = __ballot(need && lg == 0);
-                const int rank = __popcll(mk & ((1ull << (grp * L)) - 1ull));
-                const long long idx64 = (long long)pool + (long long)rank * pool_step;
-                const long long adv = (long long)pool + (long long)__popcll(mk) * pool_step;
-                pool = adv < (long long)R ? (int)adv : R;
-                if (need && idx64 < (long long)R) {
-                    const int idx = (int)idx64;
-                    nqrow[u] = idx;
-                    const int r = idx + sub < R ? idx + sub : R - 1;
-                    nqpi[u] = ld_at(mb.out_idx, 4u * (uint32_t)r);
-                    nqctr[u] = ld_at(mb.ctr, 4u * (uint32_t)r);
-                    nqin[u] = ld_at(mb.in_idx, 4u * (uint32_t)r);
-                }
-            }
-        }
-        // this round's requests: the candidate row of every live slot; h and the target row of a fresh one
-        float4 ep[U], ec[U];
-        float bp[U], bc[U];
-        uint32_t cand[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cand[u] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gl4 + 32u * j[u] + 4u * tries[u]), (int)qdraw[u]);
-            if (row[u] >= 0) {
-                ec[u] = ld4_at(m.E, (cand[u] << LOGD4) | lgoff);
-                bc[u] = ld_at(m.b, cand[u] << 2);
-                if (tries[u] == 0) {
-                    const uint32_t pi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gl4 + 32u * j[u]), (int)qpi[u]);
-                    h[u] = ld4_at(blk.H, ((uint32_t)row[u] << LOGD4) | lgoff);
-                    ep[u] = ld4_at(m.E, (pi << LOGD4) | lgoff);
-                    bp[u] = ld_at(m.b, pi << 2);
-                }
-            }
-        }
-        SBR_SP(const unsigned long long pr_t1 = __builtin_readcyclecounter();)
-        // (no store between the rounds' loads and the tests on them: vmcnt counts stores too, and a store in a branch makes the
-        // count unknown — the next wait would then be for the stores' acknowledgements, a round trip of its own per round.  The
-        // ended rows' results are stored after the last test, back to back with the next round's requests.)
-        bool fin[U];
-        float sc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float ps = bp[u] + group_allreduce<L>(dot4(h[u], ep[u]));
-            sc[u] = bc[u] + group_allreduce<L>(dot4(h[u], ec[u]));
-            fin[u] = false;
-            if (row[u] >= 0) {
-                if (tries[u] == 0) pos[u] = ps;
-                ++tries[u];
-                fin[u] = sbr_warp_violates(pos[u], sc[u]) || tries[u] >= (uint32_t)SBR_WARP_MAX_TRIES;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (fin[u]) {
-                float g;
-                const float l = sbr_loss_hinge(pos[u], sc[u], &g);
-                if (lg == 0) {
-                    const uint32_t ro = 4u * (uint32_t)row[u];
-                    st_at(blk.neg, ro, cand[u]);
-                    st_at(blk.coef, ro, g);
-                    st_at(w.loss, ro, l);
-                    st_at(w.tries, ro, tries[u]);
-                    loss_part += (double)l;
-                    tries_part += tries[u];
-                }
-                row[u] = -1;
-            }
-        }
-        SBR_SP(const unsigned long long pr_t2 = __builtin_readcyclecounter(); ++pr_rounds; pr_issue += pr_t1 - pr_t0; pr_rest += pr_t2 - pr_t1;)
-    }
-    SBR_SP(if (lane == 0) {
-        const unsigned long long life = __builtin_readcyclecounter() - pr_t_begin;
-        atomicAdd(&g_score_prof[0], 1ull); atomicAdd(&g_score_prof[1], pr_rounds); atomicAdd(&g_score_prof[2], pr_issue);
-        atomicAdd(&g_score_prof[3], pr_rest); atomicAdd(&g_score_prof[4], life); atomicMax(&g_score_prof[5], life);
-        atomicMin(&g_score_prof[6], pr_w_begin); atomicMax(&g_score_prof[7], wall_clock64());
-    })
-    *loss_out = loss_part;
-    *tries_out = tries_part;
-}
-
 // the workgroup's share of the reported loss / tries (order-free sums) -> part_loss / part_tries [block]; thread 0 returns the sums
 template <bool ALL>  // ALL: every thread gets the sums (the small tail follows); otherwise thread 0 only, as the store needs them
 __device__ __forceinline__ void score_partials(const WorkView& w, int block, double loss_part, unsigned int tries_part, double* lsum,
@@ -476,143 +321,6 @@ __global__ __launch_bounds__(256, PF ? 1 : (D >= 128 ? 7 : 6)) void score_kernel
     unsigned int tries_part, tsum = 0;
     score_warp_rows<D, U, PF>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
                               &loss_part, &tries_part);
-    score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
-}
-// The lockstep form with a pass's IDS A PASS AHEAD in run registers (round 5): lane (slot) of the wave holds the target id, the
-// counter and the input id of row base + slot of the NEXT pass — one coalesced request per array and pass, three registers, where
-// the PF form above spends two registers per row and four more on the h row.  A pass is then its gathers and retries alone (the h
-// row needs no id: it is requested with the target and the first candidate), one dependent round trip fewer out of ~4; the block's
-// copies of the ids are two coalesced stores per pass.  32-bit byte offsets on scalar bases (tables below 4 GiB).  Same
-// arithmetic per row, same tests in the same order.
-template <int D, int U>
-__device__ __forceinline__ void score_warp_ahead(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
-                                                 uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
-    constexpr int L = D / 4;
-    constexpr int GPW = 64 / L;
-    constexpr int RPW = GPW * U;  // rows per wave and pass
-    constexpr int LOGD4 = D == 16 ? 6 : D == 32 ? 7 : D == 64 ? 8 : D == 128 ? 9 : 10;
-    constexpr bool spread = L >= 8;
-    const int lane = threadIdx.x & 63;
-    const int lg = lane % L;
-    const int grp = lane / L;
-    const uint32_t lgoff = 16u * (uint32_t)lg;
-    const uint32_t gl4 = 4u * (uint32_t)(grp * L);
-    const int sub = lane % RPW;
-    const int R = mb.R;
-    double loss_part = 0.0;
-    unsigned int tries_part = 0;
-    int base = wave * RPW;
-    const int step = nwaves * RPW;
-    uint32_t qpi = 0, qctr = 0, qin = 0;
-    {
-        const uint32_t o = 4u * (uint32_t)(base + sub < R ? base + sub : R - 1);
-        qpi = ld_at(mb.out_idx, o);
-        qctr = ld_at(mb.ctr, o);
-        qin = ld_at(mb.in_idx, o);
-    }
-    for (; base < R; base += step) {
-        float4 h[U], ep[U], ec[U];
-        uint32_t draws[U], cand[U], nj[U], tries[U];
-        float bp[U], bc[U], pos[U], neg[U];
-        bool done[U];
-        if (lane < RPW && base + lane < R) {  // the block's copy of the pass's ids
-            st_at(blk.in_idx, 4u * (uint32_t)(base + lane), qin);
-            st_at(blk.out_idx, 4u * (uint32_t)(base + lane), qpi);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = u * GPW + grp;
-            const uint32_t pi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * slot, (int)qpi);
-            const uint32_t ctr = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * slot, (int)qctr);
-            const int r0 = base + slot;
-            const uint32_t rr = (uint32_t)(r0 < R ? r0 : R - 1);
-            h[u] = ld4_at(blk.H, (rr << LOGD4) | lgoff);
-            ep[u] = ld4_at(m.E, (pi << LOGD4) | lgoff);
-            bp[u] = ld_at(m.b, pi << 2);
-            draws[u] = sbr_neg_draw(epoch_key, ctr, spread ? (uint32_t)(lg & 7) : 0u, m.num_items);
-            cand[u] = spread ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)gl4, (int)draws[u]) : draws[u];
-            ec[u] = ld4_at(m.E, (cand[u] << LOGD4) | lgoff);
-            bc[u] = ld_at(m.b, cand[u] << 2);
-            if (!spread) draws[u] = ctr;  // the later tries hash the counter again
-        }
-        {   // the next pass's ids
-            const int nb = base + step + sub;
-            const uint32_t o = 4u * (uint32_t)(nb < R ? nb : R - 1);
-            qpi = ld_at(mb.out_idx, o);
-            qctr = ld_at(mb.ctr, o);
-            qin = ld_at(mb.in_idx, o);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            pos[u] = bp[u] + group_allreduce<L>(dot4(h[u], ep[u]));
-            done[u] = false;
-            nj[u] = 0;
-            tries[u] = 0;
-            neg[u] = 0.0f;
-        }
-        for (int k = 0; k < SBR_WARP_MAX_TRIES; ++k) {
-            if (k > 0) {
-                bool all_done = true;
-#pragma unroll
-                for (int u = 0; u < U; ++u) all_done = all_done && done[u];
-                if (__all(all_done)) break;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    cand[u] = spread ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gl4 + 4u * (uint32_t)k), (int)draws[u])
-                                     : sbr_neg_draw(epoch_key, draws[u], (uint32_t)k, m.num_items);
-                    if (!done[u]) {
-                        ec[u] = ld4_at(m.E, (cand[u] << LOGD4) | lgoff);
-                        bc[u] = ld_at(m.b, cand[u] << 2);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float sc = bc[u] + group_allreduce<L>(dot4(h[u], ec[u]));
-                if (!done[u]) {
-                    nj[u] = cand[u];
-                    neg[u] = sc;
-                    ++tries[u];
-                    if (sbr_warp_violates(pos[u], sc)) done[u] = true;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = base + u * GPW + grp;
-            float g;
-            const float l = sbr_loss_hinge(pos[u], neg[u], &g);
-            if (r < R && lg == 0) {
-                const uint32_t ro = 4u * (uint32_t)r;
-                st_at(blk.neg, ro, nj[u]);
-                st_at(blk.coef, ro, g);
-                st_at(w.loss, ro, l);
-                st_at(w.tries, ro, tries[u]);
-                loss_part += (double)l;
-                tries_part += tries[u];
-            }
-        }
-    }
-    *loss_out = loss_part;
-    *tries_out = tries_part;
-}
-template <int D, int U>
-__global__ __launch_bounds__(256, D >= 128 ? 7 : 6) void score_ahead_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
-    double loss_part, lsum = 0.0;
-    unsigned int tries_part, tsum = 0;
-    score_warp_ahead<D, U>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
-                           &loss_part, &tries_part);
-    score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
-}
-#ifndef SBR_SCORE_REFILL_WPE
-#define SBR_SCORE_REFILL_WPE 5 /* waves per SIMD the refill form's registers are budgeted for */
-#endif
-template <int D, int U>
-__global__ __launch_bounds__(256, SBR_SCORE_REFILL_WPE) void score_refill_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
-    double loss_part, lsum = 0.0;
-    unsigned int tries_part, tsum = 0;
-    score_warp_refill<D, U>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
-                            &loss_part, &tries_part);
     score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
 }
 template <int D, int U>
@@ -713,10 +421,10 @@ __device__ __forceinline__ void score_single_rows(const ModelView& m, const MbVi
         for (int u = 0; u < U; ++u) {
             const int r = base + u * GPW + grp;
             const int rr = r < R ? r : last;
-            h[u] = ld4(Hh + (size_t)rr * D + 4 * lg);
-            ep[u] = ld4(E + (size_t)pi[u] * D + 4 * lg);
+            h[u] = ld4_score(Hh + (size_t)rr * D + 4 * lg);
+            ep[u] = ld4_score(E + (size_t)pi[u] * D + 4 * lg);
             bp[u] = bias[pi[u]];
-            ec[u] = ld4(E + (size_t)cand[u] * D + 4 * lg);
+            ec[u] = ld4_score(E + (size_t)cand[u] * D + 4 * lg);
             bc[u] = bias[cand[u]];
         }
 #pragma unroll
@@ -2445,8 +2153,8 @@ struct EmitApply {  // single device: one optimiser update per touched row
     template <int D>
     __device__ __forceinline__ RowPrefetch pre(uint32_t r, int lg) const {
         RowPrefetch q;
-        q.w = ld4(m.E + (size_t)r * D + 4 * lg);
-        q.a = ld4(m.Eacc + (size_t)r * D + 4 * lg);
+        q.w = ld4_upd(m.E + (size_t)r * D + 4 * lg);
+        q.a = ld4_upd(m.Eacc + (size_t)r * D + 4 * lg);
         q.mo = m.optimizer == SBR_OPT_ADAM ? ld4(m.Em + (size_t)r * D + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
         return q;
     }
@@ -2457,8 +2165,8 @@ struct EmitApply {  // single device: one optimiser update per touched row
         opt_update(m, &q.w.y, &q.a.y, &q.mo.y, g.y);
         opt_update(m, &q.w.z, &q.a.z, &q.mo.z, g.z);
         opt_update(m, &q.w.w, &q.a.w, &q.mo.w, g.w);
-        st4(m.E + (size_t)r * D + 4 * lg, q.w);
-        st4(m.Eacc + (size_t)r * D + 4 * lg, q.a);
+        st4_upd(m.E + (size_t)r * D + 4 * lg, q.w);
+        st4_upd(m.Eacc + (size_t)r * D + 4 * lg, q.a);
         if (adam) st4(m.Em + (size_t)r * D + 4 * lg, q.mo);
         if (has_b) bias_update(m, r, lg, gb);
     }
@@ -3394,27 +3102,7 @@ static int score_warp_u(int rows) {
     if (e && (e[0] == '1' || e[0] == '2')) return e[0] - '0';
     return rows < SBR_SCORE_U2_MAX_ROWS ? 2 : 1;
 }
-/* WARP: the refill form (score_refill_kernel) unless SBR_SCORE_FORM=lockstep (test hook: both forms ship, same bits) */
-#ifndef SBR_SCORE_REFILL_U
-#define SBR_SCORE_REFILL_U 2
-#endif
-static bool score_refill_on(int d, uint32_t num_items, int rows) {
-    const char* e = std::getenv("SBR_SCORE_FORM"); /* read per call */
-    if (e && (e[0] == 'l' || e[0] == 'a')) return false;
-    /* (row, try) pairs need eight lanes per row; 32-bit byte offsets into the table and the h rows */
-    return d >= 32 && (unsigned long long)num_items * d * 4 < (1ull << 32) && (unsigned long long)rows * d * 4 < (1ull << 32);
-}
-static int score_grid(int d, uint32_t num_items, int rows, bool single_negative) {
-    if (!single_negative && score_refill_on(d, num_items, rows)) { /* resident grid; a wave's share is at least two runs per slot */
-        const long long per_wg = 4ll * (64 / (d / 4)) * SBR_SCORE_REFILL_U * 2 * (d / 32);
-        long long g = (rows + per_wg - 1) / per_wg;
-        if (g < 1) g = 1;
-        const char* gm = std::getenv("SBR_SCORE_GRID_MULT"); /* experiment */
-        const long long mult = gm ? std::atoi(gm) : 1;
-        if (g > 256 * SBR_SCORE_REFILL_WPE * mult) g = 256 * SBR_SCORE_REFILL_WPE * mult;
-        if (g > 8192) g = 8192;
-        return (int)g;
-    }
+static int score_grid(int d, int rows, bool single_negative) {
     const int gpb = 4 * (64 / (d / 4)) * (single_negative ? SBR_SCORE_SINGLE_U : score_warp_u(rows));  // rows per workgroup and pass
     return grid_for_groups(rows, gpb);
 }
@@ -3435,26 +3123,13 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                 }
             }
             if (m.loss == SBR_LOSS_WARP) {
-                bool refill = false;
-                if constexpr (DD >= 32) {
-                    if (score_refill_on(DD, m.num_items, rows_host)) {
-                        refill = true;
-                        hipLaunchKernelGGL((score_refill_kernel<DD, SBR_SCORE_REFILL_U>), dim3(score_grid(DD, m.num_items, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-                    }
-                }
-                const char* form = std::getenv("SBR_SCORE_FORM");
-                if (refill) {}
-                else if (form && form[0] == 'a' && score_warp_u(rows_host) == 2)
-                    hipLaunchKernelGGL((score_ahead_kernel<DD, 2>), dim3(score_grid(DD, m.num_items, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-                else if (form && form[0] == 'a')
-                    hipLaunchKernelGGL((score_ahead_kernel<DD, 1>), dim3(score_grid(DD, m.num_items, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-                else if (score_warp_u(rows_host) == 2)
-                    hipLaunchKernelGGL((score_kernel<DD, 2, false>), dim3(score_grid(DD, m.num_items, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                if (score_warp_u(rows_host) == 2)
+                    hipLaunchKernelGGL((score_kernel<DD, 2, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
                 else
-                    hipLaunchKernelGGL((score_kernel<DD, 1, true>), dim3(score_grid(DD, m.num_items, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                    hipLaunchKernelGGL((score_kernel<DD, 1, true>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
             }
             else
-                hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, m.num_items, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
+                hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
                                    epoch_key);
         });
     }
@@ -3473,7 +3148,7 @@ void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const Block
                 return;
             }
         }
-        const int grid = score_grid(DD, m.num_items, rows_host, true);
+        const int grid = score_grid(DD, rows_host, true);
         if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
         else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
     });
@@ -3489,7 +3164,7 @@ void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_ho
 void launch_block_header(const ModelView& m, const BlockView& blk, const WorkView& w, const MbView& mb, int rows_host, double* loss_acc,
                          unsigned long long* ex_acc, float* lag_state, hipStream_t s) {
     launch_block_header_parts(blk.header, rows_host, w.part_loss, w.part_tries,
-                              rows_host > 0 ? score_grid(m.d, m.num_items, rows_host, m.loss != SBR_LOSS_WARP) : 0, loss_acc, ex_acc, mb, w.loss, lag_state, s);
+                              rows_host > 0 ? score_grid(m.d, rows_host, m.loss != SBR_LOSS_WARP) : 0, loss_acc, ex_acc, mb, w.loss, lag_state, s);
 }
 
 void launch_recurrent_backward(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,

@@ -14,5 +14,5 @@ PY
 }
 for spec in "$@"; do
   label=${spec%%:*}; envs=${spec#*:}
-  run $label $envs
+  run $label ${envs//,/ }
 done

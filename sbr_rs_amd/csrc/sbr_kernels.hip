@@ -110,6 +110,37 @@ __device__ __forceinline__ void st4s(float* p, float4 v) {
 #ifndef SBR_NT_UPD_ST
 #define SBR_NT_UPD_ST 1
 #endif
+/* cache-policy word of the raw buffer accesses of the recurrent kernels' per-row activations (2 = nt; build-time A/B hooks).
+ * The forward pass writes 12 d floats per packed row — gates, cell states, the copy of the gathered input rows, h (1.5 GB at the
+ * headline batch) — of which only h (131 MB) is read again soon: by the score kernel, next on the stream.  Gates, cell states and
+ * the input copy streamed past the caches leave h in the 256 MB Infinity Cache: the score launch reads it there instead of from
+ * HBM, 110 -> 92 us (0.56 -> 0.67 of the HBM roofline on its algorithmic bytes; cache-cold 4 M-item table 0.51 -> 0.62); the forward
+ * pass pays ~1.5 % (0.675 -> 0.69 ms), the step is unchanged within noise.  BPTT's dz (0.5 GB, read once by the dense-gradient GEMM)
+ * streamed: BPTT -1.4 %.  Streaming dx, BPTT's own reads or the GEMM's reads: nothing.  profiles/r05_streaming_gathers.md. */
+#ifndef SBR_AUX_FWD_ST
+#define SBR_AUX_FWD_ST 2 /* forward: gates, cell states, copy of the gathered input rows */
+#endif
+#ifndef SBR_AUX_FWD_G
+#define SBR_AUX_FWD_G SBR_AUX_FWD_ST
+#endif
+#ifndef SBR_AUX_FWD_C
+#define SBR_AUX_FWD_C SBR_AUX_FWD_ST
+#endif
+#ifndef SBR_AUX_FWD_X
+#define SBR_AUX_FWD_X SBR_AUX_FWD_ST
+#endif
+#ifndef SBR_AUX_BWD_LD
+#define SBR_AUX_BWD_LD 0 /* BPTT: its reads of the gates and cell states */
+#endif
+#ifndef SBR_AUX_BWD_ST
+#define SBR_AUX_BWD_ST 0 /* BPTT: dx */
+#endif
+#ifndef SBR_AUX_BWD_Z
+#define SBR_AUX_BWD_Z 2 /* BPTT: dz */
+#endif
+#ifndef SBR_AUX_DW_LD
+#define SBR_AUX_DW_LD 0 /* dense-gradient GEMM: x / dz rows */
+#endif
 __device__ __forceinline__ float4 ld4_score(const float* p) { return SBR_NT_SCORE ? ld4s(p) : ld4(p); }
 __device__ __forceinline__ float4 ld4_upd(const float* p) { return SBR_NT_UPD ? ld4s(p) : ld4(p); }
 __device__ __forceinline__ void st4_upd(float* p, float4 v) { if (SBR_NT_UPD_ST) st4s(p, v); else st4(p, v); }
@@ -1080,7 +1111,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 dst[0] = make_float2(xn[it].x, xn[it].y);
                 dst[1] = make_float2(xn[it].z, xn[it].w);
                 // row i, columns c4 .. c4+3 of the tile's rows = byte idx * 16
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, SBR_AUX_FWD_X);
             }
         }
     };
@@ -1233,11 +1264,11 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                             cst[rt][p][reg] = cc;
                             // row i = rt*16 + kq*4 + reg: (rt, reg, p) go into the scalar offset, the gate into the immediate
                             const int sG = ((rt * 16 + reg) * 4 * D + p * 16) * 4, sC = ((rt * 16 + reg) * D + p * 16) * 4;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, SBR_AUX_FWD_G);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, SBR_AUX_FWD_G);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, SBR_AUX_FWD_G);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, SBR_AUX_FWD_G);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, SBR_AUX_FWD_C);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hh), rsH, vC, sC, 0);
                             As[i * LDA + D + u] = hh;
                         }
@@ -1548,7 +1579,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
         const __amdgpu_buffer_rsrc_t rsC = row_rsrc(w.C, D * 4, rb + b0, nr_live);
 #pragma unroll
         for (int k = 0; k < CITER; ++k)  // row i, units u..u+3 of a D-wide row = byte idx * 16
-            dst[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, tid * 16, k * NT * 16, 0));
+            dst[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, tid * 16, k * NT * 16, SBR_AUX_BWD_LD));
     };
     auto request_gates = [&](int t) {  // gate values of step t
         const int tid = thread_id();
@@ -1561,7 +1592,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
             const int so = k * (NT / Q) * (4 * D * 4);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                pg[k][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vg + g * D * 4, so, 0));
+                pg[k][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vg + g * D * 4, so, SBR_AUX_BWD_LD));
         }
     };
 
@@ -1634,7 +1665,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
                 for (int g = 0; g < NG; ++g) {
                     const int src = NG == 4 ? g : g + 1;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, make_float4(dz[src][0], dz[src][1], dz[src][2], dz[src][3])), rsZ,
-                                                           vz + g * D * 4, k * (NT / Q) * (NGD * 4), 0);
+                                                           vz + g * D * 4, k * (NT / Q) * (NGD * 4), SBR_AUX_BWD_Z);
                     float2* dst = reinterpret_cast<float2*>(&Zs[i * LDZ + g * D + u]);
                     dst[0] = make_float2(dz[src][0], dz[src][1]);
                     dst[1] = make_float2(dz[src][2], dz[src][3]);
@@ -1732,7 +1763,7 @@ __global__ __launch_bounds__((D / 16) * 64, RT >= 4 ? 2 : 4) void lstm_bwd_seq_k
                 for (int reg = 0; reg < 4; ++reg) {
                     const int i = rt * 16 + kq * 4 + reg;
                     const float dx = acc[0][rt][reg];  // (a bit_cast applied directly to the vector element reads element 0)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dx), rsX, vx, (rt * 16 + reg) * D * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dx), rsX, vx, (rt * 16 + reg) * D * 4, SBR_AUX_BWD_ST);
                     Zs[i * LDZ + wv * 16 + c16] = acc[1][rt][reg];
                 }
         }
@@ -1929,12 +1960,12 @@ __global__ __launch_bounds__(256, SBR_DW_WPE) void lstm_dw_full_kernel(ModelView
             for (int i = 0; i < NI; ++i) {
                 const int lr = slab * SLAB + srow + 8 * i;
                 if (tk * 128 < D) {  // x columns (uniform per workgroup); rows past R are out of range and read as zeros: they meet zeros in dZ
-                    xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsXc, (srow * D + kcol) * 4, (slab * SLAB + 8 * i) * D * 4, 0));
+                    xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsXc, (srow * D + kcol) * 4, (slab * SLAB + 8 * i) * D * 4, SBR_AUX_DW_LD));
                 } else {
                     const int pr = s_prev[lr];
                     xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsH, pr >= 0 ? (int)((uint32_t)pr * (uint32_t)(D * 4) + (uint32_t)((kcol - D) * 4)) : -16, 0, 0));
                 }
-                zr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (srow * NGD + jcol) * 4, (slab * SLAB + 8 * i) * NGD * 4, 0));
+                zr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (srow * NGD + jcol) * 4, (slab * SLAB + 8 * i) * NGD * 4, SBR_AUX_DW_LD));
             }
             return;
         }

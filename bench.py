@@ -920,7 +920,11 @@ def main():
                         "traffic_source": traffic_source, "traffic_over_algorithmic": [traffic_lower / bytes_per_launch, traffic / bytes_per_launch] if traffic else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
-                        "avg_launch_ms": score["ms_per_launch"]}
+                        "avg_launch_ms": score["ms_per_launch"],
+                        "cache_policy": ("achieved = algorithmic bytes / time against the HBM peak; `traffic` counts what the L2s fetch (FETCH_SIZE), i.e. HBM plus "
+                                         "Infinity Cache.  Since round 5 the forward pass streams everything but h past the caches, so the h rows' share of the "
+                                         "algorithmic bytes (4d of (2+k)4d per row) is read from the Infinity Cache; table rows and h rows are read nt "
+                                         "(DESIGN.md section 6, profiles/r05_streaming_gathers.md)") if loss_kind == 2 and model_kind != 2 else None}
             ceil = measured_ceiling(4 * d, cached_table=args.items * d * 4 < (1 << 30))
             if ceil and traffic:
                 roofline["measured_gather_ceiling"] = {"GBps": ceil, "source": "tools/hbm_ceiling.hip, profiles/r02_hbm_ceiling.jsonl",

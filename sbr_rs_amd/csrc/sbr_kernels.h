@@ -68,6 +68,8 @@ struct WorkView { /* per-plan scratch, sized for Rmax rows / Bmax sequences */
     float* zeros;           /* 256 zeros (h_{-1} of the dense-gradient GEMM, 64-bit address path) */
     int fold_max_tiles;     /* the recurrent kernels fold their length-sorted tile list up to this many tiles */
     int wide_addresses;     /* 1: the dense-gradient GEMM takes its 64-bit per-lane address path even where the buffer path would do (tests) */
+    int stream_activations; /* set per launch by launch_recurrent_forward: 1 = gates / cell states / input copy are stored nt (the step's h rows fit
+                             * the Infinity Cache and the score kernel, next on the stream, finds them there: SBR_STREAM_MAX_H_BYTES) */
 };
 
 /* one chunk pointer per device: slices of one gathered buffer (collective transport), or the peers' own

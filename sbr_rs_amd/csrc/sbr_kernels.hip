@@ -157,7 +157,7 @@ __device__ __forceinline__ void st4_upd(float* p, float4 v) { if (SBR_NT_UPD_ST)
 // SPEC (the one-workgroup launch of a one-sequence step): all of a row's candidates are gathered together and then tested in
 // order — the launch is a handful of dependent memory round trips and nothing else, and WARP's retries were up to four of them
 // (~6 us of a 19 us launch); the extra rows are a few KB.  Same tests in the same order on the same values.
-template <int D, int U, bool PF, bool SPEC = false>
+template <int D, int U, bool PF, bool SPEC = false, bool NT = false>
 __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                                 uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
     constexpr int L = D / 4;
@@ -167,7 +167,7 @@ __device__ __forceinline__ void score_warp_rows(const ModelView& m, const MbView
     const int lg = lane % L;
     const int grp = lane / L;
     const int max_tries = m.loss == SBR_LOSS_WARP ? SBR_WARP_MAX_TRIES : 1;
-    auto ldrow = [](const float* p) { return SPEC ? ld4(p) : ld4_score(p); };  // (a one-workgroup step re-reads its rows: cached)
+    auto ldrow = [](const float* p) { return NT ? ld4_score(p) : ld4(p); };  // nt: the launch's cache policy (launch_score)
     static_assert(SBR_WARP_MAX_TRIES <= 8, "one candidate per lane of an 8-lane group");
     const bool spread = L >= 8 && max_tries > 1;
     double loss_part = 0.0;   // reporting only: order-free f64 partial sums per workgroup
@@ -346,15 +346,15 @@ __device__ __forceinline__ void score_partials(const WorkView& w, int block, dou
 
 // (seven waves per SIMD = 72 registers is what the d = 128 rows need in flight; below that a row is 64-256 B, the two-row form
 // wants 73-80 registers, and a scratch reload inside the pass loop would wait for every gather outstanding: six waves there)
-template <int D, int U, bool PF>
+template <int D, int U, bool PF, bool NT>
 __global__ __launch_bounds__(256, PF ? 1 : (D >= 128 ? 7 : 6)) void score_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
     double loss_part, lsum = 0.0;
     unsigned int tries_part, tsum = 0;
-    score_warp_rows<D, U, PF>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
+    score_warp_rows<D, U, PF, false, NT>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
                               &loss_part, &tries_part);
     score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
 }
-template <int D, int U>
+template <int D, int U, bool NT = false>
 __device__ __forceinline__ void score_single_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                                   uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out);
 #define SBR_SCORE_SINGLE_U 4 /* rows per lane group and pass of score_single_kernel */
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT) void score_tail_kernel(ModelView m, MbView mb, 
 // order, so they have long arrived when the next pass starts).  Without the retry loop the pass is pure memory-level
 // parallelism: 1.25 -> 1.1 ms at d = 256 against a 10 M-row table.  (With WARP's retry rounds in lockstep the same
 // idea loses — more rounds per row than a two-row group needs — so WARP keeps score_kernel.)
-template <int D, int U>
+template <int D, int U, bool NT>
 __device__ __forceinline__ void score_single_rows(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w,
                                                   uint64_t epoch_key, int wave, int nwaves, double* loss_out, unsigned int* tries_out) {
     constexpr int L = D / 4;
@@ -452,10 +452,10 @@ __device__ __forceinline__ void score_single_rows(const ModelView& m, const MbVi
         for (int u = 0; u < U; ++u) {
             const int r = base + u * GPW + grp;
             const int rr = r < R ? r : last;
-            h[u] = ld4_score(Hh + (size_t)rr * D + 4 * lg);
-            ep[u] = ld4_score(E + (size_t)pi[u] * D + 4 * lg);
+            h[u] = (NT ? ld4s : ld4)(Hh + (size_t)rr * D + 4 * lg);
+            ep[u] = (NT ? ld4s : ld4)(E + (size_t)pi[u] * D + 4 * lg);
             bp[u] = bias[pi[u]];
-            ec[u] = ld4_score(E + (size_t)cand[u] * D + 4 * lg);
+            ec[u] = (NT ? ld4s : ld4)(E + (size_t)cand[u] * D + 4 * lg);
             bc[u] = bias[cand[u]];
         }
 #pragma unroll
@@ -481,12 +481,12 @@ __device__ __forceinline__ void score_single_rows(const ModelView& m, const MbVi
     *loss_out = loss_part;
     *tries_out = tries_part;
 }
-template <int D, int U>
+template <int D, int U, bool NT>
 __global__ __launch_bounds__(256) void score_single_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key) {
     double loss_part, lsum = 0.0;
     unsigned int tries_part, tsum = 0;
-    score_single_rows<D, U>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
-                            &loss_part, &tries_part);
+    score_single_rows<D, U, NT>(m, mb, blk, w, epoch_key, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (int)((gridDim.x * blockDim.x) >> 6),
+                                &loss_part, &tries_part);
     score_partials<false>(w, blockIdx.x, loss_part, tries_part, &lsum, &tsum);
 }
 
@@ -989,6 +989,7 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
     __shared__ int s_off[SBR_MAX_T + 2];
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const bool stream_act = w.stream_activations != 0;  // kernel argument: a scalar
     // Per-lane values derived from the thread id are re-derived where they are used (the id passes through an
     // empty asm), so that the compiler does not keep dozens of loop-invariant address pieces alive across the
     // time loop and spill them
@@ -1111,7 +1112,8 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                 dst[0] = make_float2(xn[it].x, xn[it].y);
                 dst[1] = make_float2(xn[it].z, xn[it].w);
                 // row i, columns c4 .. c4+3 of the tile's rows = byte idx * 16
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, SBR_AUX_FWD_X);
+                if (stream_act) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, SBR_AUX_FWD_X);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, xn[it]), rsX, tid * 16, it * NT * 16, 0);
             }
         }
     };
@@ -1264,11 +1266,19 @@ __global__ __launch_bounds__((D / 16 / UPW) * 64, UPW == 1 ? (RT >= 4 ? 2 : 4) :
                             cst[rt][p][reg] = cc;
                             // row i = rt*16 + kq*4 + reg: (rt, reg, p) go into the scalar offset, the gate into the immediate
                             const int sG = ((rt * 16 + reg) * 4 * D + p * 16) * 4, sC = ((rt * 16 + reg) * D + p * 16) * 4;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, SBR_AUX_FWD_G);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, SBR_AUX_FWD_G);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, SBR_AUX_FWD_G);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, SBR_AUX_FWD_G);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, SBR_AUX_FWD_C);
+                            if (stream_act) {  // (wave-uniform: the launch's cache policy, sbr_kernels.h WorkView::stream_activations)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, SBR_AUX_FWD_G);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, SBR_AUX_FWD_G);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, SBR_AUX_FWD_G);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, SBR_AUX_FWD_G);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, SBR_AUX_FWD_C);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gi), rsG, vG, sG, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gf), rsG, vG + D * 4, sG, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gg), rsG, vG + 2 * D * 4, sG, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, go), rsG, vG + 3 * D * 4, sG, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cc), rsC, vC, sC, 0);
+                            }
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hh), rsH, vC, sC, 0);
                             As[i * LDA + D + u] = hh;
                         }
@@ -3061,9 +3071,18 @@ static inline int grid_for_groups(long long groups, int groups_per_block) {
     return (int)g;
 }
 
-void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w, int tm_host,
+/* The step's cache policy by size (profiles/r05_streaming_gathers.md): while the step's h rows fit the Infinity Cache beside the rows
+ * the forward pass gathers (131 + 131 MB of 256 at the headline batch) the forward pass streams its other stores past the caches and
+ * the score kernels read their rows nt; at 50 000 sequences per step (838 MB of h rows) both lose (forward +5 %, score +6 %). */
+#ifndef SBR_STREAM_MAX_H_BYTES
+#define SBR_STREAM_MAX_H_BYTES (192ull << 20)
+#endif
+static bool stream_policy(int rows, int d) { return (unsigned long long)rows * (unsigned long long)d * 4ull <= SBR_STREAM_MAX_H_BYTES; }
+void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w_plan, int tm_host,
                               const int* off_host, hipStream_t s) {
     if (mb.R == 0) return;
+    WorkView w = w_plan;
+    w.stream_activations = stream_policy(mb.R, m.d) ? 1 : 0;
     if (m.ng == 0) {
         DISPATCH_D(m.d, {
             const int gpb = 4 * (64 / (DD / 4));
@@ -3154,14 +3173,22 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
                 }
             }
             if (m.loss == SBR_LOSS_WARP) {
-                if (score_warp_u(rows_host) == 2)
-                    hipLaunchKernelGGL((score_kernel<DD, 2, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
-                else
-                    hipLaunchKernelGGL((score_kernel<DD, 1, true>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                const bool nt = stream_policy(rows_host, DD);
+                if (score_warp_u(rows_host) == 2) {
+                    if (nt) hipLaunchKernelGGL((score_kernel<DD, 2, false, true>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                    else hipLaunchKernelGGL((score_kernel<DD, 2, false, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                } else {
+                    if (nt) hipLaunchKernelGGL((score_kernel<DD, 1, true, true>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                    else hipLaunchKernelGGL((score_kernel<DD, 1, true, false>), dim3(score_grid(DD, rows_host, false)), dim3(256), 0, s, m, mb, blk, w, epoch_key);
+                }
             }
             else
-                hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
-                                   epoch_key);
+                if (stream_policy(rows_host, DD))
+                    hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U, true>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
+                                       epoch_key);
+                else
+                    hipLaunchKernelGGL((score_single_kernel<DD, SBR_SCORE_SINGLE_U, false>), dim3(score_grid(DD, rows_host, true)), dim3(256), 0, s, m, mb, blk, w,
+                                       epoch_key);
         });
     }
 }

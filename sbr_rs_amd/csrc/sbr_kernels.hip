@@ -3077,7 +3077,11 @@ static inline int grid_for_groups(long long groups, int groups_per_block) {
 #ifndef SBR_STREAM_MAX_H_BYTES
 #define SBR_STREAM_MAX_H_BYTES (192ull << 20)
 #endif
-static bool stream_policy(int rows, int d) { return (unsigned long long)rows * (unsigned long long)d * 4ull <= SBR_STREAM_MAX_H_BYTES; }
+static bool stream_policy(int rows, int d) {
+    const char* e = std::getenv("SBR_STREAM"); /* test hook, read per call: "0" / "1" force either form (same bits: a cache hint) */
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return (unsigned long long)rows * (unsigned long long)d * 4ull <= SBR_STREAM_MAX_H_BYTES;
+}
 void launch_recurrent_forward(const ModelView& m, const MbView& mb, float* H, const WorkView& w_plan, int tm_host,
                               const int* off_host, hipStream_t s) {
     if (mb.R == 0) return;

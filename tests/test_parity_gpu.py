@@ -129,11 +129,14 @@ def test_d256_bptt_both_forms(monkeypatch, kind, loss, min_tiles):
     assert_params_equal(g, o, kind, "after the step")
 
 
+@pytest.mark.parametrize("stream", ["0", "1"])
 @pytest.mark.parametrize("rows_per_group", ["1", "2", None])
-def test_warp_retry_loop_all_trip_counts(monkeypatch, rows_per_group):
+def test_warp_retry_loop_all_trip_counts(monkeypatch, rows_per_group, stream):
     """sample_warp_negative (sequence_model.rs:47-68): every trip count 1..5 occurs, including
     rows where no candidate violates and the 5th draw is used anyway.  Both forms of the score kernel: one row per lane
-    group in flight (bandwidth-bound launches) and two, their retry rounds in lockstep (latency-bound launches)."""
+    group in flight (bandwidth-bound launches) and two, their retry rounds in lockstep (latency-bound launches); each with its
+    rows gathered streaming (nt) and cached (SBR_STREAM: the step's cache policy by size, forced either way)."""
+    monkeypatch.setenv("SBR_STREAM", stream)
     if rows_per_group:
         monkeypatch.setenv("SBR_SCORE_U", rows_per_group)
     items, d, T = 400, 64, 24
@@ -814,12 +817,14 @@ def test_dense_gradient_wide_address_path(monkeypatch):
     (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, "4"),
     (ModelKind.EWMA, LOSS_WARP, 256, None),
 ])
-def test_many_tiles_per_minibatch(monkeypatch, kind, loss, d, rt):
+@pytest.mark.parametrize("stream", ["0", "1"])
+def test_many_tiles_per_minibatch(monkeypatch, kind, loss, d, rt, stream):
     """A minibatch of 9 000 sequences = 282 tiles of 32 sequences: more than the 256 slots over which the
     sequence-resident kernels fold their length-sorted tile list (second fold group reversed), 40+ chunks of
     1 024 packed rows in the dense-gradient GEMM, and a sparse update with ~10^5 keys — the regime the
     benchmark runs in, at a size the oracle still finishes in seconds.  Whole-fit parity, bit for bit, in both
     forms of the sequence-resident kernels (SBR_SEQ_RT: 16- / 32- / 64-sequence tiles)."""
+    monkeypatch.setenv("SBR_STREAM", stream)  # the forward pass's stores and the score kernels' gathers streaming / cached: same bits
     if rt is not None:
         monkeypatch.setenv("SBR_SEQ_RT", rt)
     users, items, T, B = 9500, 4001, 7, 9000

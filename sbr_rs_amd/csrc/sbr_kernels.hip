@@ -86,7 +86,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Streaming (non-temporal, `nt`) forms of the 16-byte row accesses, per kernel family by measurement
 // (profiles/r05_streaming_gathers.md; the SBR_NT_* macros are build-time A/B hooks, tools/build_variant.sh):
-//   score kernels (table rows gathered once, h rows read once): ON — the launch is 10-12 % shorter in the step (0.49-0.55 ->
+//   score kernels (table rows gathered once, h rows read once): ON while the step's h rows fit the Infinity Cache (stream_policy,
+//     launch_score) — the launch is 10-12 % shorter in the step (0.49-0.55 ->
 //     0.55-0.59 of HBM; the cache-cold 4 M-item table 0.43 -> 0.51) because its 0.5 GB of one-touch rows no longer displace what
 //     the forward pass left for BPTT and what the Infinity Cache holds of the table;
 //   sparse update's parameter / optimiser-state rows (read, rewritten once per step): ON (step -0.5 %, the GEMM beside it -1.5 %);

@@ -597,43 +597,61 @@ __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView 
 // moments ago by this very group, newest first in the order the backward scan wants them.
 // Same arithmetic, same bits as ewma_forward_kernel + score_single_kernel (+ ewma_backward_kernel).
 // ------------------------------------------------------------------------------------------------
+// Packing invariant both scans rest on (sbr_engine.hip pack_sequences / the epoch packer: in_idx = item[t], out_idx = item[t + 1] of
+// ONE item slice): the target of step t is the input of step t + 1, out_idx[row(t, b)] == in_idx[row(t + 1, b)].  A step's target
+// row therefore IS the next step's input row: it is gathered once and handed on in registers (two table rows per step forward —
+// target and negative — instead of three; input, negative and the h row backward instead of four).
+// The ids of the NEXT batch of EWMA_U steps travel underneath the rows of the current one (forward, the offsets of the steps are
+// scalar loads: every live lane of the wave is at the same time step), so a batch is ONE dependent round trip — its rows — where
+// the loop used to pay three (offsets, ids, rows).
 template <int D>
 __device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, int b, int n,
                                                   int lg, const float (&a)[4], const float (&oma)[4]) {
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
     float da[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = n - 1; t0 >= 0; t0 -= EWMA_U) {  // EWMA_U steps' rows requested together, as in the forward scan
-        int r[EWMA_U], rp[EWMA_U];
-        uint32_t ii[EWMA_U], ni[EWMA_U], oi[EWMA_U];
-        float g[EWMA_U];
-        float4 x[EWMA_U], sp[EWMA_U], en[EWMA_U], ep[EWMA_U];
+    auto step_off = [&](int t) { return mb.off[t < 0 ? 0 : t]; };  // (per lane: the groups of a wave start at their own n - 1)
+    // ids of a batch: steps t0, t0 - 1, ... (q ascending = t descending); rows of steps below 0 are row b (step 0: valid memory)
+    int r[EWMA_U], rp[EWMA_U];
+    uint32_t ii[EWMA_U], ni[EWMA_U];
+    float g[EWMA_U];
+    auto request_ids = [&](int t0, int (&r_)[EWMA_U], int (&rp_)[EWMA_U], uint32_t (&ii_)[EWMA_U], uint32_t (&ni_)[EWMA_U], float (&g_)[EWMA_U]) {
 #pragma unroll
         for (int q = 0; q < EWMA_U; ++q) {
-            const int t = t0 - q >= 0 ? t0 - q : 0;
-            r[q] = mb.off[t] + b;
-            rp[q] = mb.off[t > 0 ? t - 1 : 0] + b;
+            const int t = t0 - q;
+            const int o = step_off(t), op = step_off(t - 1);
+            r_[q] = t >= 0 ? o + b : b;
+            rp_[q] = t > 0 ? op + b : b;
         }
 #pragma unroll
         for (int q = 0; q < EWMA_U; ++q) {
-            ii[q] = mb.in_idx[r[q]];
-            ni[q] = blk.neg[r[q]];
-            oi[q] = blk.out_idx[r[q]];
-            g[q] = blk.coef[r[q]];
+            ii_[q] = mb.in_idx[r_[q]];
+            ni_[q] = blk.neg[r_[q]];
+            g_[q] = blk.coef[r_[q]];
         }
+    };
+    request_ids(n - 1, r, rp, ii, ni, g);
+    // the target row of the LAST step is no step's input: gathered on its own
+    float4 xnext = ld4(m.E + (size_t)blk.out_idx[step_off(n - 1) + b] * D + 4 * lg);
+    for (int t0 = n - 1; t0 >= 0; t0 -= EWMA_U) {
+        float4 x[EWMA_U], sp[EWMA_U], en[EWMA_U];
 #pragma unroll
         for (int q = 0; q < EWMA_U; ++q) {
             x[q] = ld4(m.E + (size_t)ii[q] * D + 4 * lg);
             sp[q] = ld4(blk.H + (size_t)rp[q] * D + 4 * lg);
             en[q] = ld4(m.E + (size_t)ni[q] * D + 4 * lg);
-            ep[q] = ld4(m.E + (size_t)oi[q] * D + 4 * lg);
         }
+        int rn[EWMA_U], rpn[EWMA_U];
+        uint32_t iin[EWMA_U], nin[EWMA_U];
+        float gn[EWMA_U];
+        request_ids(t0 - EWMA_U, rn, rpn, iin, nin, gn);
 #pragma unroll
         for (int q = 0; q < EWMA_U; ++q) {
             const int t = t0 - q;
             if (t < 0) continue;
+            const float4 ep = q == 0 ? xnext : x[q - 1];  // target of step t = input of step t + 1
             // dloss/dh: g*E[neg] - g*E[pos], two rounded products and one subtraction (dh_loss4)
-            float ds[4] = {g[q] * en[q].x - g[q] * ep[q].x, g[q] * en[q].y - g[q] * ep[q].y, g[q] * en[q].z - g[q] * ep[q].z,
-                           g[q] * en[q].w - g[q] * ep[q].w};
+            float ds[4] = {g[q] * en[q].x - g[q] * ep.x, g[q] * en[q].y - g[q] * ep.y, g[q] * en[q].z - g[q] * ep.z,
+                           g[q] * en[q].w - g[q] * ep.w};
             if (t != n - 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ds[j] = ds[j] + carry[j];
@@ -658,6 +676,9 @@ __device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbVi
             }
             st4(blk.dX + (size_t)r[q] * D + 4 * lg, dx);
         }
+        xnext = x[EWMA_U - 1];
+#pragma unroll
+        for (int q = 0; q < EWMA_U; ++q) { r[q] = rn[q]; rp[q] = rpn[q]; ii[q] = iin[q]; ni[q] = nin[q]; g[q] = gn[q]; }
     }
     st4(w.dab + (size_t)b * D + 4 * lg, make_float4(da[0], da[1], da[2], da[3]));
 }
@@ -680,37 +701,61 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
     for (int b = wave * GPW + grp; b < mb.B; b += nwaves * GPW) {
         const int n = mb.steps[b];
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t0 = 0; t0 < n; t0 += EWMA_U) {
-            int r[EWMA_U];
-            uint32_t it[EWMA_U], pi[EWMA_U], cand[EWMA_U];
-            float4 x[EWMA_U], ep[EWMA_U], ec[EWMA_U];
-            float bp[EWMA_U], bc[EWMA_U];
-#pragma unroll
-            for (int q = 0; q < EWMA_U; ++q) r[q] = mb.off[t0 + q < n ? t0 + q : n - 1] + b;
+        auto step_off = [&](int t) {  // off[t], a scalar load (t is the same in every live lane); clamped to the array
+            const int ts = __builtin_amdgcn_readfirstlane(t);
+            return mb.off[ts > mb.Tm ? mb.Tm : ts];
+        };
+        // ids of a batch of EWMA_U steps (rows of steps past the sequence's end: row b, step 0's — valid memory, never used)
+        // (the negative of a step is a 64-bit hash of its counter: lane q of the group evaluates step q's — one evaluation per batch
+        // instead of EWMA_U, each the same value in every lane — and the others read it from there)
+        static_assert(EWMA_U <= L, "one lane of the group per step of a batch");
+        int r[EWMA_U];
+        uint32_t pi[EWMA_U], ctr;
+        auto request_ids = [&](int t0, int (&r_)[EWMA_U], uint32_t (&pi_)[EWMA_U], uint32_t* ctr_) {
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
-                it[q] = mb.in_idx[r[q]];
-                pi[q] = mb.out_idx[r[q]];
-                cand[q] = sbr_neg_draw(epoch_key, mb.ctr[r[q]], 0u, m.num_items);
+                const int o = step_off(t0 + q);
+                r_[q] = t0 + q < n ? o + b : b;
             }
+            int rmine = r_[0];
+#pragma unroll
+            for (int q = 1; q < EWMA_U; ++q) rmine = (lg & (EWMA_U - 1)) == q ? r_[q] : rmine;
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) pi_[q] = mb.out_idx[r_[q]];
+            *ctr_ = mb.ctr[rmine];
+        };
+        static_assert((EWMA_U & (EWMA_U - 1)) == 0, "lg & (EWMA_U - 1) picks the lane's step");
+        request_ids(0, r, pi, &ctr);
+        // the input of step 0 is no step's target: gathered on its own (see the packing invariant above ewma_backward_seq)
+        uint32_t pprev = mb.in_idx[b];
+        float4 xprev = ld4(m.E + (size_t)pprev * D + 4 * lg);
+        for (int t0 = 0; t0 < n; t0 += EWMA_U) {
+            uint32_t cand[EWMA_U];
+            float4 ep[EWMA_U], ec[EWMA_U];
+            float bp[EWMA_U], bc[EWMA_U];
+            const uint32_t cmine = sbr_neg_draw(epoch_key, ctr, 0u, m.num_items);
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
-                x[q] = ld4(m.E + (size_t)it[q] * D + 4 * lg);
+                cand[q] = (uint32_t)__shfl((int)cmine, grp * L + q, 64);
                 ep[q] = ld4(m.E + (size_t)pi[q] * D + 4 * lg);
                 bp[q] = m.b[pi[q]];
                 ec[q] = ld4(m.E + (size_t)cand[q] * D + 4 * lg);
                 bc[q] = m.b[cand[q]];
             }
+            int rn[EWMA_U];
+            uint32_t pin[EWMA_U], ctrn;
+            request_ids(t0 + EWMA_U, rn, pin, &ctrn);  // the next batch's ids, underneath this batch's rows
 #pragma unroll
             for (int q = 0; q < EWMA_U; ++q) {
                 if (t0 + q < n) {
+                    const float4 x = q == 0 ? xprev : ep[q - 1];  // input of step t = target of step t - 1
                     if (t0 + q == 0) {
-                        s = x[q];
+                        s = x;
                     } else {
-                        s.x = sbr_fma(a[0], s.x, oma[0] * x[q].x);
-                        s.y = sbr_fma(a[1], s.y, oma[1] * x[q].y);
-                        s.z = sbr_fma(a[2], s.z, oma[2] * x[q].z);
-                        s.w = sbr_fma(a[3], s.w, oma[3] * x[q].w);
+                        s.x = sbr_fma(a[0], s.x, oma[0] * x.x);
+                        s.y = sbr_fma(a[1], s.y, oma[1] * x.y);
+                        s.z = sbr_fma(a[2], s.z, oma[2] * x.z);
+                        s.w = sbr_fma(a[3], s.w, oma[3] * x.w);
                     }
                     st4(blk.H + (size_t)r[q] * D + 4 * lg, s);
                     const float pos = bp[q] + group_allreduce<L>(dot4(s, ep[q]));
@@ -721,7 +766,7 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
                     if (lg == 0) {
                         blk.neg[r[q]] = cand[q];
                         blk.coef[r[q]] = g;
-                        blk.in_idx[r[q]] = it[q];
+                        blk.in_idx[r[q]] = q == 0 ? pprev : pi[q - 1];
                         blk.out_idx[r[q]] = pi[q];
                         w.loss[r[q]] = l;
                         w.tries[r[q]] = 1u;
@@ -730,6 +775,11 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
                     }
                 }
             }
+            xprev = ep[EWMA_U - 1];
+            pprev = pi[EWMA_U - 1];
+#pragma unroll
+            for (int q = 0; q < EWMA_U; ++q) { r[q] = rn[q]; pi[q] = pin[q]; }
+            ctr = ctrn;
         }
         if constexpr (WHOLE) {
             /* lane 0's stores to blk.neg / coef / out_idx are read back by the whole group below */

@@ -18,7 +18,8 @@ struct MbView {
     const int* steps;        /* device [B]   steps of sequence b                              */
     const int* prev_row;     /* device [R]   packed row of (t-1, b) or -1                      */
     const uint32_t* in_idx;  /* device [R]                                                    */
-    const uint32_t* out_idx; /* device [R]                                                    */
+    const uint32_t* out_idx; /* device [R]   = in_idx of the same sequence's next step (both packers write item[t] / item[t + 1] of one
+                              *               slice): the EWMA scans hand a step's target row on as the next step's input               */
     const uint32_t* ctr;     /* device [R]   p * max_sequence_length + t                       */
 };
 

@@ -338,6 +338,8 @@ def workload_label(args, world):
     if shape == ("lstm", "warp", 128, 1_000_000, 125_000, 128) and world > 1 and not args.partition_table:
         return ("BASELINE.json configs[3]" if world == 8 else
                 f"BASELINE.json configs[3]'s per-GPU shape at {world} GPUs (the config itself is 1M users over 8)")
+    if shape == ("lstm", "warp", 128, 1_000_000, 125_000, 128) and world == 1 and not args.partition_table:
+        return "BASELINE.json configs[3]'s per-GPU shape on ONE GPU (the same-shape denominator of the weak-scaling runs)"
     if (args.model, args.loss, args.dim, args.items) == ("ewma", "hinge", 256, 10_000_000) and args.partition_table:
         return ("BASELINE.json configs[4]" if world == 8 and args.users == 125_000 else
                 "BASELINE.json configs[4]'s shape (EWMA + hinge, d 256, 1e7 items, partitioned item table)")
@@ -345,74 +347,106 @@ def workload_label(args, world):
 
 
 def simulate_world(args, model_kind, loss_kind):
-    """Rank 0's share of an N-GPU synchronous step on ONE GPU: local compute, then the real exchange kernels —
-    scatter into N per-owner chunks, owner reduce over N inputs, table update from N reduced chunks, dense
-    update from N dense blocks — with device-to-device copies standing in for the all-to-all / all-gather
-    (every "peer" contributes a copy of rank 0's own chunk, so the touched-row density is one device's).  What it
-    measures is the kernel-side term of the exchange; the link term is priced from the bytes."""
+    """Rank 0's share of an N-GPU synchronous step on ONE GPU with ALL N ranks' real entries: N replicas (num_devices = N, rank q on
+    its own partition) step together through the C-ABI halves, device-to-device copies standing in for the all-to-all / all-gather;
+    the phases of RANK 0 are timed one by one (the other ranks' work is what fills rank 0's receive buffers with real touched-row
+    densities — with N ranks nearly every table row is touched every step).  --exchange owner (default): scatter -> owner update of
+    rank 0's slice (in place) -> parameter slices of the other owners copied into rank 0's table; --exchange gradient: rounds 1-5's
+    owner reduce -> gathered gradient chunks -> whole-table update.  What it measures is the kernel-side term of the exchange; the
+    link term is priced from the bytes.  (Round 5 fed rank 0's own chunk N times: one device's density.)"""
     import torch
 
     from sbr_rs_amd import engine
-    from sbr_rs_amd.distributed import HipBackend
+    from sbr_rs_amd._abi import Param
+    from sbr_rs_amd.distributed import HipBackend, device_bytes_as_tensor
 
     n = args.simulate_world
+    owner = args.exchange != "gradient"
     engine.set_device(0)
     ptr, items = synthetic_csr(args.users * n, args.items, args.max_len, zipf=args.item_distribution == "zipf")
-    model = engine.Model(make_hp(args, n, 0, model_kind, loss_kind, args.items))
-    be = HipBackend(model, (ptr, items), n)
-    recv, table, dense_all = be.buffers(n)
-    chunk, db = be.chunk, be.dense_bytes
-    nmb = be.epoch_prepare()
-    phases = {k: 0.0 for k in ("local_compute", "scatter", "all_to_all_stand_in_copies", "owner_reduce", "all_gather_stand_in_copies",
-                               "apply_rows", "dense_join_and_apply")}
+    models = [engine.Model(make_hp(args, n, q, model_kind, loss_kind, args.items)) for q in range(n)]
+    bes = [HipBackend(m, (ptr, items), n) for m in models]
+    chunk, db = bes[0].chunk, bes[0].dense_bytes
+    recv = [torch.zeros(n * chunk, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    dense_all = torch.zeros(n * db, dtype=torch.uint8, device="cuda")
+    table = None if owner else torch.zeros(n * chunk, dtype=torch.uint8, device="cuda")
+    blocks = {}
+    for q in range(n):
+        for which in (Param.ITEM_EMBEDDING, Param.ITEM_BIAS):
+            p_, sb = models[q].table_slice(which)
+            blocks[q, which] = (device_bytes_as_tensor(torch, p_, sb * n), sb)
+    nmb = {be.epoch_prepare() for be in bes}
+    assert len(nmb) == 1
+    nmb = nmb.pop()
+    names = ("local_compute", "scatter", "all_to_all_stand_in_copies", "owner_update" if owner else "owner_reduce", "all_gather_stand_in_copies") + \
+            (() if owner else ("apply_rows",)) + ("dense_join_and_apply",)
+    phases = {k: 0.0 for k in names}
 
-    def timed(name, fn):
-        model.synchronize(); torch.cuda.synchronize()
+    def timed(name, fn, on=True):
+        if not on:
+            fn()
+            return
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
-        model.synchronize(); torch.cuda.synchronize()
+        torch.cuda.synchronize()
         phases[name] += 1e3 * (time.perf_counter() - t0)
 
-    rows = 0
-    steps = 0
+    rows = steps = 0
     for i in range(args.warmup + args.steps):
         mb = i % nmb
         if i == args.warmup:
             for k in phases:
                 phases[k] = 0.0
             rows = steps = 0
-        timed("local_compute", lambda: be.compute_local(mb))
-        timed("scatter", lambda: be.scatter(mb))
+        for q in range(n - 1, -1, -1):  # rank 0 last, its phases timed
+            timed("local_compute", lambda: bes[q].compute_local(mb), q == 0)
+            timed("scatter", lambda: bes[q].scatter(mb), q == 0)
+        for p_ in range(n - 1, -1, -1):
+            def a2a():  # chunk p of every device arrives at device p
+                for src in range(n):
+                    recv[p_][src * chunk:(src + 1) * chunk].copy_(bes[src].send[p_ * chunk:(p_ + 1) * chunk])
+            timed("all_to_all_stand_in_copies", a2a, p_ == 0)
+            if owner:
+                timed("owner_update", lambda: bes[p_].plan.step_owner_update(recv[p_].data_ptr()), p_ == 0)
+            else:
+                timed("owner_reduce", lambda: bes[p_].owner_reduce(recv[p_]), p_ == 0)
+        dn = [be.dense() for be in bes]
+        for q in range(n - 1, -1, -1):
+            def ag():
+                if owner:  # the other owners' updated parameter slices, straight into this replica's table
+                    for which in (Param.ITEM_EMBEDDING, Param.ITEM_BIAS):
+                        dst, sb = blocks[q, which]
+                        for p2 in range(n):
+                            if p2 != q:
+                                dst[p2 * sb:(p2 + 1) * sb].copy_(blocks[p2, which][0][p2 * sb:(p2 + 1) * sb])
+                else:
+                    for p2 in range(n):
+                        table[p2 * chunk:(p2 + 1) * chunk].copy_(bes[p2].own)
+            timed("all_gather_stand_in_copies", ag, q == 0)
+            if not owner:
+                timed("apply_rows", lambda: bes[q].apply_rows(table), q == 0)
 
-        def a2a():  # chunk 0 of every device arrives at device 0: N copies of the own contribution
-            for src in range(n):
-                recv[src * chunk:(src + 1) * chunk].copy_(be.send[:chunk])
-        timed("all_to_all_stand_in_copies", a2a)
-        timed("owner_reduce", lambda: be.owner_reduce(recv))
-
-        def ag():  # the owners' reduced chunks: own slice from the owner reduce, the others from the send buffer (same layout)
-            table[:chunk].copy_(be.own)
-            table[chunk:].copy_(be.send[chunk:])
-        timed("all_gather_stand_in_copies", ag)
-        timed("apply_rows", lambda: be.apply_rows(table))
-
-        def dn():
-            d = be.dense()
-            for q in range(n):
-                dense_all[q * db:(q + 1) * db].copy_(d)
-            be.apply_dense(dense_all)
-        timed("dense_join_and_apply", dn)
-        rows += be.plan.minibatch_rows(mb)
+            def dense_apply():
+                for p2 in range(n):
+                    dense_all[p2 * db:(p2 + 1) * db].copy_(dn[p2])
+                bes[q].apply_dense(dense_all)
+            timed("dense_join_and_apply", dense_apply, q == 0)
+        rows += bes[0].plan.minibatch_rows(mb)
         steps += 1
-    be.close()
+    for be in bes:
+        be.close()
     per = {k: v / steps for k, v in phases.items()}
     link_gbs = 153.0  # one xGMI link, per direction (the prompt's figure; 7 links per GPU, full mesh)
+    kern = per["scatter"] + (per["owner_update"] if owner else per["owner_reduce"] + per["apply_rows"])
     return {
-        "mode": f"simulate-world {n} on one GPU (kernel-side cost of the exchange; NOT a multi-GPU measurement)",
+        "mode": f"simulate-world {n} on one GPU, all {n} ranks' real entries (kernel-side cost of the exchange; NOT a multi-GPU measurement)",
+        "exchange": "owner-applied update, parameter slices gathered in place" if owner else "gradient all-gather, whole-table update on every replica (rounds 1-5)",
         "workload": f"{workload_label(args, n)}: rank 0 of {n}, {args.users} users/GPU x {args.items} items, seq_len<={args.max_len}, "
                     f"dim {args.dim}, {args.model}+{args.loss}, batch_sequences {args.batch_sequences}",
         "steps": steps, "interactions_per_step": rows / steps, "ms_per_phase": per,
-        "exchange_kernels_ms": per["scatter"] + per["owner_reduce"] + per["apply_rows"],
+        "exchange_kernels_ms": kern,
+        "rank0_step_ms_without_links": per["local_compute"] + kern + per["dense_join_and_apply"],
         "single_device_update_ms_for_comparison": "see the N = 1 line's kernels.SPARSE_UPDATE",
         "chunk_bytes": chunk, "bytes_per_link_per_phase": chunk,
         "bytes_per_gpu_per_step": 2 * (n - 1) * chunk + (n - 1) * db,
@@ -441,8 +475,10 @@ def group_driver(args, model_kind, loss_kind):
     models = engine.group_create(hp, n, partition_item_table=args.partition_table)
     modes = {}
 
-    def run(threads):
+    def run(threads, gradient=args.exchange == "gradient"):
         gp = engine.GroupPlan(models, ptr, items, host_threads=threads)
+        if gradient and n > 1 and not args.partition_table and args.parallelism != "async":
+            gp.set_exchange(True)
         st = {"nmb": gp.epoch_prepare(prefetch_next=True), "mb": 0}
 
         def one():
@@ -466,8 +502,8 @@ def group_driver(args, model_kind, loss_kind):
         gp.synchronize()
         t1 = time.perf_counter()
         q1, s1, _ = gp.stats()
-        gp.close()
-        return {"host_threads": nth, "ms_per_step": 1e3 * (t1 - t0) / args.steps, "host_enqueue_ms_per_step": (q1 - q0) / max(s1 - s0, 1),
+        gp.close()  # (gathers the owners' optimiser-state slices back onto every replica)
+        return {"host_threads": nth, "exchange": "gradient all-gather" if gradient else "owner-applied", "ms_per_step": 1e3 * (t1 - t0) / args.steps, "host_enqueue_ms_per_step": (q1 - q0) / max(s1 - s0, 1),
                 "host_loop_ms_per_step": 1e3 * (t_queued - t0) / args.steps, "interactions_per_s": rows / (t1 - t0), "interactions_timed": rows}
 
     default = run(None)
@@ -475,6 +511,8 @@ def group_driver(args, model_kind, loss_kind):
     if n > 1:
         modes["one_host_thread"] = run(False)
         modes["host_thread_per_device"] = run(True)
+        if not args.partition_table and args.parallelism != "async":  # the other form of the Synchronous step, same box, same models (A/B)
+            modes["library_default_other_exchange"] = run(None, gradient=args.exchange != "gradient")
     names = ["ITEM_EMBEDDING", "ITEM_EMBEDDING_ACC", "ITEM_BIAS", "ITEM_BIAS_ACC"] + (["LSTM_W", "LSTM_W_ACC", "LSTM_B"] if model_kind != 2 else ["EWMA_ALPHA"])
     crcs = []
     if args.param_crc:
@@ -591,6 +629,13 @@ def main():
     ap.add_argument("--driver", choices=["ranks", "group"], default="ranks",
                     help="ranks: one process per GPU over torch.distributed (the launcher contract); group: --gpus N replicas driven "
                          "from ONE process through sbr_group_fit's step sequence (what INTEGRATION.md's Rust binding calls)")
+    ap.add_argument("--exchange", choices=["owner", "gradient"], default="owner",
+                    help="Synchronous multi-GPU step over a replicated table: owner = the owner of a slice reduces AND updates it in place, "
+                         "the updated parameter slices are all-gathered into every replica's table (round 6); gradient = rounds 1-5: the "
+                         "reduced gradient chunks are all-gathered and every replica updates the whole table.  Same bits")
+    ap.add_argument("--scale-shape", action="store_true",
+                    help="N = 1 on the shape the N > 1 runs use per GPU (BASELINE configs[3]: 125 000 users, seq_len <= 128): the denominator of a "
+                         "weak-scaling efficiency (every N > 1 line also carries it as `single_gpu_same_shape`)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-GPU exchange collectives even at world size 1 (smoke test of the RCCL path)")
     args = ap.parse_args()
@@ -606,7 +651,7 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus and args.driver != "group":
         args.gpus = world
-    multi = world > 1 or args.simulate_world > 1 or (args.driver == "group" and args.gpus > 1)
+    multi = world > 1 or args.simulate_world > 1 or (args.driver == "group" and args.gpus > 1) or args.scale_shape
     if args.users is None:
         args.users = 125_000 if multi else 100_000   # BASELINE.json configs[3] (1M users over 8 GPUs) / configs[2]
     if args.max_len is None:
@@ -690,9 +735,11 @@ def main():
         if args.force_exchange and world == 1:  # one rank owns the whole table: a single chunk
             backend.send = backend.send[:backend.chunk]
         # the production step sequencing (sbr_rs_amd/distributed.py); --force-exchange runs the collectives at world 1
-        loop = StepLoop(backend, world if not args.force_exchange else max(world, 2), asynchronous=args.parallelism == "async")
+        loop = StepLoop(backend, world if not args.force_exchange else max(world, 2), asynchronous=args.parallelism == "async",
+                        exchange=args.exchange)
         if args.force_exchange and world == 1:
             loop.world = 2  # take the exchange branch; the process group itself has a single rank
+            backend.world = 1  # (one owner slice: the whole table)
             c, db = backend.chunk, backend.dense_bytes
             loop.bufs = tuple(torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (c, c, db))
 
@@ -859,6 +906,23 @@ def main():
             except Exception as e:
                 small["error"] = repr(e)
 
+    if hasattr(loop, "finish"):
+        loop.finish()  # owner-applied steps: the owners' optimiser-state slices back on every replica (outside every timed region)
+    single_same_shape = None
+    if world > 1 and not args.partition_table:
+        # the denominator of the weak-scaling efficiency, measured in THIS job: rank 0 alone on the same per-GPU shape and batch (the
+        # N = 1 default of this script is configs[2]'s shorter sequences, a different workload); the other ranks wait at the barrier
+        if rank == 0:
+            try:
+                sptr, sitems = synthetic_csr(args.users, args.items, args.max_len, zipf=args.item_distribution == "zipf")
+                v1, _, rpl1, _, ms1 = short_run(make_hp(args, 1, 0, model_kind, loss_kind, args.items), sptr, sitems, args.steps, args.warmup, timers=False)
+                single_same_shape = {"value": v1, "unit": "interactions/s", "ms_per_step": ms1, "interactions_per_step": rpl1, "steps": args.steps,
+                                     "warmup": args.warmup, "what": "rank 0's GPU alone, one process, no exchange: the same users per GPU, sequence "
+                                                                  "lengths, model and batch_sequences as every rank of this run"}
+                del sptr, sitems
+            except Exception as e:
+                single_same_shape = {"error": repr(e)}
+        dist.barrier()
     crc_ranks = None
     if args.param_crc:  # every rank's replica (a partitioned table is read whole through the rank's mapping)
         import zlib
@@ -994,6 +1058,15 @@ def main():
                                f"SCORE: HIP events inside the timed region; the other families: a second pass of {args.steps} steps of the same schedule "
                                "with every family bracketed (events cost the step 1.5-2 %, so the timed region brackets the roofline kernel only)"),
         }
+        if world > 1:
+            out["config"]["exchange"] = ("owner-applied update, parameter slices all-gathered in place" if getattr(loop, "owner_applied", False) else
+                                         "gradient all-gather, whole-table update on every replica") if not args.partition_table else "partitioned table: owner-computes over gradient lists"
+        if single_same_shape is not None:
+            out["single_gpu_same_shape"] = single_same_shape
+            if "value" in single_same_shape:
+                out["weak_scaling_efficiency"] = (rows_total / elapsed) / (world * single_same_shape["value"])
+                out["weak_scaling_efficiency_note"] = ("value / (n_gpus x single_gpu_same_shape.value), both measured in this job on the same per-GPU "
+                                                       "shape; the N = 1 default line of this script is configs[2] (shorter sequences) and is NOT its denominator")
         if sweep is not None:
             sweep.append({"batch_sequences": args.batch_sequences, "interactions_per_s": rows_total / elapsed,
                           "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "interactions_per_step": rows_per_launch, "note": "the timed run"})

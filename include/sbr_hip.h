@@ -221,6 +221,32 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
 sbr_status sbr_fit_step_apply_rows(sbr_fit_plan* p, const void* device_table);
 sbr_status sbr_fit_step_apply_dense(sbr_fit_plan* p, const void* device_dense_all);
 
+/* OWNER-APPLIED update — the Synchronous step of a replicated table since round 6 (≙ the ONE shared parameter and optimiser state
+ * behind every worker, lstm.rs:259-260 / ewma.rs:267-269, under the synchronised step of sequence_model.rs:163-169).  Per step, after
+ * sbr_fit_step_local:
+ *   scatter (as above)                                                   -> host: all-to-all of the chunks
+ *   owner_update : the devices' contributions to the owned slice added in device order AND the one optimiser update of every touched
+ *                  row of that slice, in place in this replica (opens the optimiser step)
+ *                                                                        -> host: all-gather, IN PLACE, of the updated PARAMETER slices:
+ *                                                                           sbr_model_table_slice(ITEM_EMBEDDING) and (ITEM_BIAS)
+ *   dense + all-gather of the dense blocks + apply_dense (as above)
+ * Same sums in the same order and the same update arithmetic as owner_reduce + apply_rows — bit-identical results — and the same
+ * bytes on the links, but no replica walks the whole table (sbr_fit_step_apply_rows visits every row's flag on every device) and a
+ * row's optimiser state is maintained by its owner alone.  Consequence: while such a fit runs, a replica's copy of the item table's
+ * optimiser state (SBR_PARAM_ITEM_*_ACC / _M) is current for its OWN rows only; sbr_model_get_param on those blocks and the
+ * gradient-all-gather halves (apply_table / apply_rows) return SBR_ERR_INVALID_ARGUMENT until the host has all-gathered those blocks
+ * too (same in-place slices) and called sbr_model_optimizer_state_gathered — the library's own drivers (sbr_group_fit_end,
+ * sbr_model_fit_comm) and sbr_rs_amd/distributed.py do that when a fit ends.  The staleness-one pipeline (Asynchronous) keeps the
+ * gradient all-gather: its update lands one step late on every replica.
+ *   sbr_model_table_slice: device pointer of an item-table block of THIS replica (allocated for num_devices slices of
+ *   ceil(num_items / num_devices) rows each, so that slices are equally long) and the bytes of one slice: rank r's slice is
+ *   [base + r * slice_bytes, + slice_bytes).  which: SBR_PARAM_ITEM_EMBEDDING / _ACC / _M, SBR_PARAM_ITEM_BIAS / _ACC / _M; base = NULL
+ *   for a block the model does not have (Adam moments under Adagrad). */
+sbr_status sbr_fit_step_owner_update(sbr_fit_plan* p, const void* device_recv);
+sbr_status sbr_model_table_slice(sbr_model* m, int32_t which, void** out_base, uint64_t* out_slice_bytes);
+sbr_status sbr_model_optimizer_state_gathered(sbr_model* m);
+sbr_status sbr_model_optimizer_state_is_partial(const sbr_model* m, int32_t* out);
+
 /* The same multi-device fit driven from ONE process (≙ fit with num_threads(n) on one host,
  * sequence_model.rs:90-102): models[r] was created with num_devices = n, device_rank = r, the same
  * seed, on the device that was current at its creation (sbr_set_device).  The exchange runs as
@@ -253,6 +279,13 @@ sbr_status sbr_group_member_plan(sbr_group_plan* g, uint32_t replica, sbr_fit_pl
 sbr_status sbr_group_synchronize(sbr_group_plan* g);
 sbr_status sbr_group_plan_set_host_threads(sbr_group_plan* g, int32_t enable);
 sbr_status sbr_group_plan_stats(const sbr_group_plan* g, double* out_host_enqueue_ms, uint64_t* out_steps, int32_t* out_host_threads);
+/* The Synchronous step of a replicated group is the owner-applied update (sbr_fit_step_owner_update: parameter slices travel, in
+ * place); gradient_all_gather != 0 selects the gradient all-gather + whole-table update of rounds 1-5 instead (A/B measurements and
+ * the parity tests of those halves; the pipeline always runs it).  Same bits.  sbr_group_gather_optimizer_state: every replica's
+ * copy of the item table's optimiser state made complete from the owners' slices — sbr_group_fit_end does it; a host that reads
+ * SBR_PARAM_ITEM_*_ACC between steps calls it first. */
+sbr_status sbr_group_plan_set_exchange(sbr_group_plan* g, int32_t gradient_all_gather);
+sbr_status sbr_group_gather_optimizer_state(sbr_group_plan* g);
 sbr_status sbr_group_fit_end(sbr_group_plan* g, float* out_loss);
 void sbr_group_plan_destroy(sbr_group_plan* g);
 
@@ -314,8 +347,9 @@ sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds,
  *   sbr_comm_unique_id    rank 0 makes the 128-byte id; the host hands it to the other ranks (a file, a socket, an environment
  *                         variable: any channel)
  *   sbr_comm_create       every rank, on its own device (sbr_set_device first), with the same id
- *   sbr_fit_step_exchange after sbr_fit_step_local: scatter -> all-to-all -> owner reduce -> all-gather -> table update, dense
- *                         block -> all-gather -> dense update, all queued on the model's stream; same bits as every other transport
+ *   sbr_fit_step_exchange after sbr_fit_step_local: scatter -> all-to-all -> owner update (in place) -> all-gather of the updated
+ *                         parameter slices into every replica's table, dense block -> all-gather -> dense update, all queued on
+ *                         the model's stream; same bits as every other transport
  *   sbr_model_fit_comm    the whole fit of this rank (sbr_model_fit for num_devices = world across processes); the loss is the
  *                         all-rank figure, sbr_model_last_fit_lagged_loss holds THIS rank's term of the reference's figure
  * Replicated table, Parallelism::Synchronous order of work.  SBR_ERR_UNSUPPORTED: no librccl on this host. */
@@ -324,6 +358,9 @@ sbr_status sbr_comm_unique_id(uint8_t out_id[128]);
 sbr_status sbr_comm_create(const uint8_t id[128], uint32_t world, uint32_t rank, sbr_comm** out);
 void sbr_comm_destroy(sbr_comm* c);
 sbr_status sbr_fit_step_exchange(sbr_fit_plan* p, uint64_t minibatch, sbr_comm* c);
+/* after the last sbr_fit_step_exchange of a fit driven step by step: the owners' optimiser-state slices all-gathered in place
+ * (sbr_model_fit_comm does it itself) */
+sbr_status sbr_comm_gather_optimizer_state(sbr_model* m, sbr_comm* c);
 sbr_status sbr_model_fit_comm(sbr_model* m, sbr_comm* c, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users,
                               float* out_loss);
 

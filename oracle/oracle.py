@@ -66,6 +66,11 @@ def lib():
         L.orc_fit_scatter.argtypes = [vp, C.c_int, vp]
         L.orc_fit_owner_reduce.argtypes = [vp, vp, vp]
         L.orc_fit_apply_table.argtypes = [vp, vp, vp]
+        L.orc_fit_owner_update.argtypes = [vp, C.c_int, vp]
+        L.orc_fit_apply_dense_blocks.argtypes = [vp, vp]
+        L.orc_model_table_slice_bytes.argtypes = [vp, C.c_int, u64p]
+        L.orc_model_get_table_slice.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.orc_model_set_table_slice.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_fit_step.argtypes = [vp, C.c_uint64]
         L.orc_fit_epoch_async.argtypes = [vp, C.c_uint64]
         L.orc_fit_end.argtypes = [vp, fp, u64p]
@@ -224,6 +229,15 @@ class OraclePlan:
         dense_all = np.ascontiguousarray(dense_all, dtype=np.uint8)
         _check(lib().orc_fit_apply_table(self._h, _ptr(all_chunks), _ptr(dense_all)))
 
+    # ---- the owner-applied form (sbr_fit_step_owner_update): the owner updates its rows, parameter slices travel ----
+    def owner_update(self, rank: int, recv: np.ndarray):
+        recv = np.ascontiguousarray(recv, dtype=np.uint8)
+        _check(lib().orc_fit_owner_update(self._h, rank, _ptr(recv)))
+
+    def apply_dense_blocks(self, dense_all: np.ndarray):
+        dense_all = np.ascontiguousarray(dense_all, dtype=np.uint8)
+        _check(lib().orc_fit_apply_dense_blocks(self._h, _ptr(dense_all)))
+
     def end(self):
         loss, ex = C.c_float(), C.c_uint64()
         _check(lib().orc_fit_end(self._h, C.byref(loss), C.byref(ex)))
@@ -317,6 +331,18 @@ class OracleModel:
     def set_param(self, which: int, values: np.ndarray):
         values = np.ascontiguousarray(values, dtype=np.float32).ravel()
         _check(lib().orc_model_set_param(self._h, int(which), _ptr(values), values.size))
+
+    def table_slice(self, which: int, rank: int) -> np.ndarray:
+        """Owner slice `rank` of an item-table block in stored layout (zero-padded to ceil(I / num_devices) rows), as bytes."""
+        n = C.c_uint64()
+        _check(lib().orc_model_table_slice_bytes(self._h, int(which), C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().orc_model_get_table_slice(self._h, int(which), rank, _ptr(out)))
+        return out
+
+    def set_table_slice(self, which: int, rank: int, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        _check(lib().orc_model_set_table_slice(self._h, int(which), rank, _ptr(data)))
 
     def global_epoch(self) -> int:
         return lib().orc_model_get_epoch(self._h)

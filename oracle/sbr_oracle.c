@@ -1188,6 +1188,98 @@ int orc_fit_apply_table(orc_plan* p, const void* all_chunks, const void* dense_a
     return SBR_OK;
 }
 
+/* The owner-APPLIED form of the same step (include/sbr_hip.h: sbr_fit_step_owner_update; the engine's Synchronous step since
+ * round 6).  Rank `rank` adds the devices' contributions to ITS slice in device order and applies the one optimiser update of
+ * every touched row of the slice to its own replica; the updated parameter slices (and, when a fit ends, the optimiser-state
+ * slices) then travel instead of the gradient sums.  orc_fit_apply_table above does the same arithmetic for every slice on every
+ * replica: same bits — which is what tests/test_distributed_cpu.py checks by running BOTH forms against the one-process emulation.
+ * Checker-side halves of a multi-process run only (one orc_model per rank). */
+int orc_fit_owner_update(orc_plan* p, int rank, const void* recv) {
+    orc_model* m = p->m;
+    int d = m->d;
+    uint64_t S = orc_slice_rows(p), cw = S * ((uint64_t)d + 2), I = m->hp.num_items;
+    uint64_t row0 = (uint64_t)rank * S;
+    if (rank < 0 || rank >= p->ndev) return SBR_ERR_INVALID_ARGUMENT;
+    orc_begin_optimizer_step(m);
+    float* g = (float*)malloc(sizeof(float) * d);
+    for (uint64_t i = 0; i < S && row0 + i < I; ++i) {
+        uint32_t fl = 0;
+        float gb = 0.0f;
+        for (int q = 0; q < p->ndev; ++q) { /* device order; the first toucher initialises (orc_fit_owner_reduce) */
+            const float* c = (const float*)recv + (size_t)q * cw;
+            uint32_t f = ((const uint32_t*)(c + S * d + S))[i];
+            if (f & 1u) {
+                const float* s = c + i * d;
+                if (fl & 1u) for (int k = 0; k < d; ++k) g[k] = g[k] + s[k];
+                else for (int k = 0; k < d; ++k) g[k] = s[k];
+            }
+            if (f & 2u) gb = (fl & 2u) ? gb + c[S * d + i] : c[S * d + i];
+            fl |= f;
+        }
+        orc_row_update(m, row0 + i, g, (fl & 1u) != 0, (fl & 2u) != 0, gb);
+    }
+    free(g);
+    return SBR_OK;
+}
+
+/* the dense half of orc_fit_apply_table alone (the optimiser step was opened by orc_fit_owner_update) */
+int orc_fit_apply_dense_blocks(orc_plan* p, const void* dense_all) {
+    orc_model* m = p->m;
+    int ndev = p->ndev;
+    uint64_t nd = orc_ndense(m);
+    float* dg = (float*)malloc(nd * 4);
+    for (int q = 0; q < ndev; ++q) {
+        const uint32_t* w = (const uint32_t*)dense_all + (size_t)q * (8 + nd);
+        const float* dense = (const float*)(w + 8);
+        if (q == 0) memcpy(dg, dense, nd * 4); else for (uint64_t i = 0; i < nd; ++i) dg[i] = dg[i] + dense[i];
+        double ls; uint64_t ex;
+        memcpy(&ls, w + 4, 8); memcpy(&ex, w + 6, 8);
+        p->loss_sum += ls; p->examples += ex;
+        p->loss_dev[q] += ls; p->examples_dev[q] += ex;
+    }
+    orc_dense_update(m, dg);
+    free(dg);
+    return SBR_OK;
+}
+
+/* slice `rank` (rows [rank * S, (rank + 1) * S), zero-padded past num_items) of an item-table block in stored layout: what a
+ * rank contributes to / receives from the all-gather of the parameter (or optimiser-state) slices */
+int orc_model_table_slice_bytes(orc_model* m, int which, uint64_t* out) {
+    uint64_t n = m->hp.num_devices, S = ((uint64_t)m->hp.num_items + n - 1) / n;
+    int row = which == SBR_PARAM_ITEM_EMBEDDING || which == SBR_PARAM_ITEM_EMBEDDING_ACC || which == SBR_PARAM_ITEM_EMBEDDING_M;
+    *out = S * (row ? (uint64_t)m->d : 1) * 4;
+    return SBR_OK;
+}
+static float* orc_table_block(orc_model* m, int which, uint64_t* width) {
+    *width = 1;
+    switch (which) {
+        case SBR_PARAM_ITEM_EMBEDDING: *width = (uint64_t)m->d; return m->E;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: *width = (uint64_t)m->d; return m->Eacc;
+        case SBR_PARAM_ITEM_EMBEDDING_M: *width = (uint64_t)m->d; return m->Em;
+        case SBR_PARAM_ITEM_BIAS: return m->b;
+        case SBR_PARAM_ITEM_BIAS_ACC: return m->bacc;
+        case SBR_PARAM_ITEM_BIAS_M: return m->bm;
+    }
+    return NULL;
+}
+int orc_model_get_table_slice(orc_model* m, int which, int rank, float* out) {
+    uint64_t w, n = m->hp.num_devices, I = m->hp.num_items, S = (I + n - 1) / n;
+    float* p = orc_table_block(m, which, &w);
+    if (!p || rank < 0 || (uint64_t)rank >= n) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t r0 = (uint64_t)rank * S, r1 = r0 + S < I ? r0 + S : I;
+    memset(out, 0, S * w * 4);
+    if (r1 > r0) memcpy(out, p + r0 * w, (r1 - r0) * w * 4);
+    return SBR_OK;
+}
+int orc_model_set_table_slice(orc_model* m, int which, int rank, const float* in) {
+    uint64_t w, n = m->hp.num_devices, I = m->hp.num_items, S = (I + n - 1) / n;
+    float* p = orc_table_block(m, which, &w);
+    if (!p || rank < 0 || (uint64_t)rank >= n) return SBR_ERR_INVALID_ARGUMENT;
+    uint64_t r0 = (uint64_t)rank * S, r1 = r0 + S < I ? r0 + S : I;
+    if (r1 > r0) memcpy(p + r0 * w, in, (r1 - r0) * w * 4);
+    return SBR_OK;
+}
+
 /* One full optimiser step, all devices emulated in this process. */
 int orc_fit_step(orc_plan* p, uint64_t mb) {
     if (p->ndev == 1) {

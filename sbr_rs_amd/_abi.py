@@ -66,7 +66,7 @@ class KernelFamily(enum.IntEnum):
 
 
 NUM_KERNEL_FAMILIES = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SbrHparams(C.Structure):

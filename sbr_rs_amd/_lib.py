@@ -63,6 +63,13 @@ def load():
         "sbr_fit_step_apply_table": [vp, vp, vp],
         "sbr_fit_step_apply_rows": [vp, vp],
         "sbr_fit_step_apply_dense": [vp, vp],
+        "sbr_fit_step_owner_update": [vp, vp],
+        "sbr_model_table_slice": [vp, C.c_int32, C.POINTER(vp), u64p],
+        "sbr_model_optimizer_state_gathered": [vp],
+        "sbr_model_optimizer_state_is_partial": [vp, C.POINTER(C.c_int32)],
+        "sbr_group_plan_set_exchange": [vp, C.c_int32],
+        "sbr_group_gather_optimizer_state": [vp],
+        "sbr_comm_gather_optimizer_state": [vp, vp],
         "sbr_model_set_stream": [vp, vp],
         "sbr_model_synchronize": [vp],
         "sbr_fit_debug_fetch": [vp, C.c_int32, vp, C.c_uint64],
@@ -154,4 +161,6 @@ DECLARED_SYMBOLS = [
     "sbr_selftest_dot_tree", "sbr_selftest_mfma", "sbr_selftest_sort", "sbr_release_cached_memory",
     "sbr_group_fit_begin", "sbr_group_epoch_prepare", "sbr_group_step", "sbr_group_step_local", "sbr_group_member_plan",
     "sbr_fit_steps", "sbr_comm_unique_id", "sbr_comm_create", "sbr_comm_destroy", "sbr_fit_step_exchange", "sbr_model_fit_comm", "sbr_model_set_reference_order", "sbr_fit_block_bytes", "sbr_fit_step_apply_blocks_in_order", "sbr_model_set_step_fusion", "sbr_fit_debug_phase_clocks", "sbr_group_synchronize", "sbr_group_plan_set_host_threads", "sbr_group_plan_stats", "sbr_group_fit_end", "sbr_group_plan_destroy",
+    "sbr_fit_step_owner_update", "sbr_model_table_slice", "sbr_model_optimizer_state_gathered", "sbr_model_optimizer_state_is_partial",
+    "sbr_group_plan_set_exchange", "sbr_group_gather_optimizer_state", "sbr_comm_gather_optimizer_state",
 ]

@@ -152,6 +152,12 @@ inline void hfree(void* p) { scratch_cache().put(p, true); }
 
 int dim_ok(uint32_t d) { return d == 16 || d == 32 || d == 64 || d == 128 || d == 256; }
 
+/* rows a replica's item-table arrays are allocated for: num_devices x S, S = ceil(num_items / num_devices) (one device: num_items) */
+uint64_t table_rows_allocated(const sbr_hparams* hp) {
+    const uint64_t n = hp->num_devices ? hp->num_devices : 1, I = hp->num_items;
+    return n > 1 ? n * ((I + n - 1) / n) : I;
+}
+
 /* Storage width of an embedding_dim: the kernels exist for 16 / 32 / 64 / 128 / 256 columns; any other
  * embedding_dim <= 256 (the reference's builder takes any usize, lstm.rs:86-89) is stored in the next width up
  * with the extra columns — of the embeddings, of every weight row and column, of alpha — ZERO.  That is a fixed
@@ -420,6 +426,9 @@ struct sbr_model {
     uint64_t global_epoch = 0;
     uint64_t opt_steps = 0; /* optimiser steps taken (Adam bias correction) */
     float last_lagged_loss = 0.0f; /* what the reference's fit would have returned for the last sbr_model_fit / sbr_group_fit */
+    bool opt_state_partial = false; /* owner-applied steps (sbr_fit_step_owner_update) have run since the item table's optimiser state was last
+                                     * complete on this replica: only the rows this rank owns are current (sbr_model_table_slice /
+                                     * sbr_model_optimizer_state_gathered; the library's own drivers gather when a fit ends) */
     bool reference_order = false; /* sbr_model_set_reference_order: negatives from the worker's sequential stream (one sequence per step) */
     int step_fusion = 2; /* one-sequence steps at d <= 32 (sbr_model_set_step_fusion): 0 separate launches, 1 fused launches
                           * (SmallTail + small_back: four per step), 2 runs of steps in one launch where the shape allows */
@@ -724,7 +733,7 @@ sbr_status ensure_device(const sbr_model* m) {
 
 extern "C" {
 
-uint32_t sbr_abi_version(void) { return 9; }
+uint32_t sbr_abi_version(void) { return 10; }
 
 void sbr_release_cached_memory(void) { scratch_cache().trim(); }
 
@@ -803,6 +812,9 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
     v.optimizer = hp->optimizer; v.c1 = 1.0f; v.c2 = 1.0f;
     const bool adam = hp->optimizer == SBR_OPT_ADAM;
     const uint64_t I = hp->num_items, d = (uint64_t)m->d;
+    /* a replica of a multi-device model stores num_devices x ceil(I / num_devices) rows: the owners' slices are then equally long, so
+     * the all-gather of the updated parameter slices (sbr_fit_step_owner_update) can write every replica's table IN PLACE */
+    const uint64_t Ia = table_rows_allocated(hp);
     sbr_status st = SBR_OK;
     auto fail = [&](sbr_status s) { sbr_model_destroy(m); return s; };
     m->shared = shared;
@@ -810,13 +822,23 @@ static sbr_status model_create_impl(const sbr_hparams* hp, std::shared_ptr<Share
         v.E = shared->E; v.Eacc = shared->Eacc; v.b = shared->b; v.bacc = shared->bacc;
         v.Em = shared->Em; v.bm = shared->bm;
     } else {
-        if ((st = dmalloc(&v.E, I * d)) != SBR_OK) return fail(st);
-        if ((st = dmalloc(&v.Eacc, I * d)) != SBR_OK) return fail(st);
-        if ((st = dmalloc(&v.b, I)) != SBR_OK) return fail(st);
-        if ((st = dmalloc(&v.bacc, I)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.E, Ia * d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.Eacc, Ia * d)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.b, Ia)) != SBR_OK) return fail(st);
+        if ((st = dmalloc(&v.bacc, Ia)) != SBR_OK) return fail(st);
         if (adam) {
-            if ((st = dmalloc(&v.Em, I * d)) != SBR_OK) return fail(st);
-            if ((st = dmalloc(&v.bm, I)) != SBR_OK) return fail(st);
+            if ((st = dmalloc(&v.Em, Ia * d)) != SBR_OK) return fail(st);
+            if ((st = dmalloc(&v.bm, Ia)) != SBR_OK) return fail(st);
+        }
+        if (Ia > I) { /* the padding rows: never addressed by a row id, but they travel with the last owner's slice */
+            hipMemsetAsync(v.E + I * d, 0, (Ia - I) * d * 4, m->stream);
+            hipMemsetAsync(v.Eacc + I * d, 0, (Ia - I) * d * 4, m->stream);
+            hipMemsetAsync(v.b + I, 0, (Ia - I) * 4, m->stream);
+            hipMemsetAsync(v.bacc + I, 0, (Ia - I) * 4, m->stream);
+            if (adam) {
+                hipMemsetAsync(v.Em + I * d, 0, (Ia - I) * d * 4, m->stream);
+                hipMemsetAsync(v.bm + I, 0, (Ia - I) * 4, m->stream);
+            }
         }
     }
     /* ≙ build_params (lstm.rs:174-194): embeddings first, then the recurrent weights, same RNG */
@@ -971,6 +993,10 @@ static float* param_ptr(sbr_model* m, int32_t which, uint64_t* count, uint64_t* 
     return p;
 }
 
+static bool is_table_optimizer_state(int32_t which) {
+    return which == SBR_PARAM_ITEM_EMBEDDING_ACC || which == SBR_PARAM_ITEM_BIAS_ACC || which == SBR_PARAM_ITEM_EMBEDDING_M || which == SBR_PARAM_ITEM_BIAS_M;
+}
+
 /* copy between the caller's logical array and the stored (padded) array, host side; to_stored fills the padding with 0 */
 static void param_repack(const sbr_model* m, int shape, const float* src, float* dst, bool to_stored) {
     const uint64_t I = m->hp.num_items, d = (uint64_t)m->d, dl = (uint64_t)m->dl, ng = (uint64_t)m->ng;
@@ -1009,6 +1035,7 @@ sbr_status sbr_model_get_param(sbr_model* m, int32_t which, float* host_out, uin
     int shape = SHAPE_FLAT;
     float* p = param_ptr(m, which, &n, &stored, &shape);
     if (!p || n != count) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->opt_state_partial && is_table_optimizer_state(which)) return SBR_ERR_INVALID_ARGUMENT; /* gather the owners' slices first */
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (stored == n) {
@@ -1030,6 +1057,7 @@ sbr_status sbr_model_get_param_rows(sbr_model* m, int32_t which, const uint32_t*
     const uint64_t I = m->hp.num_items;
     const bool table = shape == SHAPE_ROWS, bias = shape == SHAPE_FLAT && stored == I && (which == SBR_PARAM_ITEM_BIAS || which == SBR_PARAM_ITEM_BIAS_ACC || which == SBR_PARAM_ITEM_BIAS_M);
     if (!p || !count || (!table && !bias)) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->opt_state_partial && is_table_optimizer_state(which)) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     const uint64_t w = table ? (uint64_t)m->dl : 1, ws = table ? (uint64_t)m->d : 1;
@@ -1879,6 +1907,10 @@ sbr_status sbr_fit_dense_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
 sbr_status sbr_fit_step_scatter(sbr_fit_plan* p, uint64_t minibatch, void* device_send) {
     if (!p || !device_send || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
+    /* reference order with several workers is n optimiser applications per step in worker order plus an exchange of the workers'
+     * generator states per epoch: only the single-process group driver sequences that (sbr_fit_step_apply_blocks_in_order).  The
+     * summed-gradient exchange would silently give neither order. */
+    if (m->reference_order && p->ndev > 1) return SBR_ERR_UNSUPPORTED;
     SBRCHK(ensure_device(m));
     const sbr::BlockView bv = block_view(m, p->block, p->rmax);
     const uint32_t R = p->ep[p->cur].rows_of_dev[minibatch * p->ndev + p->rank];
@@ -1963,6 +1995,7 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
     if (!p || !device_table || !device_dense_all) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     if (m->shared) return SBR_ERR_INVALID_ARGUMENT; /* a partitioned table is updated by its owners (sbr_group_fit) */
+    if (m->opt_state_partial) return SBR_ERR_INVALID_ARGUMENT; /* this replica holds its own rows' optimiser state only: gather it first */
     SBRCHK(ensure_device(m));
     SBRCHK(apply_dense_blocks(p, device_dense_all));
     {
@@ -1978,7 +2011,7 @@ sbr_status sbr_fit_step_apply_table(sbr_fit_plan* p, const void* device_table, c
 sbr_status sbr_fit_step_apply_rows(sbr_fit_plan* p, const void* device_table) {
     if (!p || !device_table) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
-    if (m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->shared || m->opt_state_partial) return SBR_ERR_INVALID_ARGUMENT;
     SBRCHK(ensure_device(m));
     begin_optimizer_step(m);
     {
@@ -1996,6 +2029,66 @@ sbr_status sbr_fit_step_apply_dense(sbr_fit_plan* p, const void* device_dense_al
     SBRCHK(ensure_device(m));
     SBRCHK(apply_dense_blocks(p, device_dense_all, /*begins_step=*/false));
     HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* ---- owner-APPLIED update of the replicated exchange (Parallelism::Synchronous) ------------------------------------------
+ * ≙ the one shared parameter + optimiser state of lstm.rs:259-260 / ewma.rs:267-269 under the synchronised step of
+ * sequence_model.rs:163-169.  After the all-to-all the owner of a slice adds the devices' contributions in device order AND applies
+ * the one optimiser update of every touched row of its slice, in place in its own replica; what the devices then all-gather is the
+ * updated PARAMETER slices (E rows and biases), written straight into every replica's table (sbr_model_table_slice: the arrays are
+ * allocated for num_devices equal slices).  Same sums in the same order, same update arithmetic, same bytes on the links as the
+ * gradient all-gather of sbr_fit_step_owner_reduce + sbr_fit_step_apply_rows — same bits — but no replica walks the whole table
+ * any more and the optimiser state of a row is maintained by its owner alone. */
+sbr_status sbr_fit_step_owner_update(sbr_fit_plan* p, const void* device_recv) {
+    if (!p || !device_recv) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    if (m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    begin_optimizer_step(m);
+    const uint64_t S = slice_rows(p), I = m->hp.num_items;
+    const uint64_t row0 = std::min<uint64_t>(I, (uint64_t)p->rank * S), nrows = std::min<uint64_t>(I, row0 + S) - row0;
+    {
+        ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
+        sbr::launch_owner_update(m->mv, contiguous_chunks(p, device_recv), p->ndev, S, row0, nrows, m->stream);
+    }
+    if (p->ndev > 1) m->opt_state_partial = true;
+    HIPCHK(hipGetLastError());
+    return SBR_OK;
+}
+
+/* the owner update reading chunk `rank` of every peer's send buffer in place (peer transport) is sbr_fit_step_owner_reduce_peers'
+ * sibling; not built: the peers' parameter slices would have to be exportable allocations as well */
+
+sbr_status sbr_model_table_slice(sbr_model* m, int32_t which, void** out_base, uint64_t* out_slice_bytes) {
+    if (!m || !out_base || !out_slice_bytes || m->shared) return SBR_ERR_INVALID_ARGUMENT;
+    const uint64_t n = m->hp.num_devices, S = ((uint64_t)m->hp.num_items + n - 1) / n, d = (uint64_t)m->d;
+    const sbr::ModelView& v = m->mv;
+    float* base = nullptr;
+    uint64_t row_bytes = 0;
+    switch (which) {
+        case SBR_PARAM_ITEM_EMBEDDING: base = v.E; row_bytes = d * 4; break;
+        case SBR_PARAM_ITEM_EMBEDDING_ACC: base = v.Eacc; row_bytes = d * 4; break;
+        case SBR_PARAM_ITEM_EMBEDDING_M: base = v.Em; row_bytes = d * 4; break;
+        case SBR_PARAM_ITEM_BIAS: base = v.b; row_bytes = 4; break;
+        case SBR_PARAM_ITEM_BIAS_ACC: base = v.bacc; row_bytes = 4; break;
+        case SBR_PARAM_ITEM_BIAS_M: base = v.bm; row_bytes = 4; break;
+        default: return SBR_ERR_INVALID_ARGUMENT;
+    }
+    *out_base = base; /* null: the block does not exist (Adam moments under Adagrad) */
+    *out_slice_bytes = base ? S * row_bytes : 0;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_optimizer_state_gathered(sbr_model* m) {
+    if (!m) return SBR_ERR_INVALID_ARGUMENT;
+    m->opt_state_partial = false;
+    return SBR_OK;
+}
+
+sbr_status sbr_model_optimizer_state_is_partial(const sbr_model* m, int32_t* out) {
+    if (!m || !out) return SBR_ERR_INVALID_ARGUMENT;
+    *out = m->opt_state_partial ? 1 : 0;
     return SBR_OK;
 }
 
@@ -2204,7 +2297,7 @@ struct sbr_comm {
     void* comm = nullptr;
     uint32_t world = 0, rank = 0;
     int device = 0;
-    uint8_t *send = nullptr, *recv = nullptr, *own = nullptr, *table = nullptr, *dense = nullptr, *dense_all = nullptr;
+    uint8_t *send = nullptr, *recv = nullptr, *dense = nullptr, *dense_all = nullptr;
     uint64_t chunk = 0, db = 0; /* sizes the buffers were made for */
 };
 
@@ -2236,52 +2329,95 @@ void sbr_comm_destroy(sbr_comm* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     if (c->comm) rccl_api()->CommDestroy(c->comm);
-    dfree(c->send); dfree(c->recv); dfree(c->own); dfree(c->table); dfree(c->dense); dfree(c->dense_all);
+    dfree(c->send); dfree(c->recv); dfree(c->dense); dfree(c->dense_all);
     delete c;
 }
 
-/* the exchange and the update of one optimiser step (after sbr_fit_step_local): scatter -> all-to-all -> owner reduce -> all-gather
- * of the reduced chunks -> item-table update; the dense block joins the dense-gradient GEMM late -> all-gather -> dense update.
- * Everything is queued on the model's stream; the call does not block the host. */
+/* the exchange and the update of one optimiser step (after sbr_fit_step_local): scatter -> all-to-all -> owner update (device-order
+ * sum + the one optimiser update of the owner's rows, in place) -> all-gather of the updated parameter slices straight into this
+ * replica's table; the dense block joins the dense-gradient GEMM late -> all-gather -> dense update.  Everything is queued on the
+ * model's stream; the call does not block the host. */
+static sbr_status comm_buffers(sbr_fit_plan* p, sbr_comm* c, uint64_t chunk, uint64_t db) {
+    if (c->chunk == chunk && c->db == db && c->send) return SBR_OK;
+    sbr_model* m = p->m;
+    const uint32_t n = c->world;
+    HIPCHK(hipStreamSynchronize(m->stream));
+    dfree(c->send); dfree(c->recv); dfree(c->dense); dfree(c->dense_all);
+    c->send = c->recv = c->dense = c->dense_all = nullptr;
+    c->chunk = c->db = 0;
+    /* all or nothing, BEFORE any collective of the step is queued: a rank that failed half-way through would leave its peers
+     * waiting inside theirs */
+    sbr_status st = dmalloc(&c->send, n * chunk);
+    if (st == SBR_OK) st = dmalloc(&c->recv, n * chunk);
+    if (st == SBR_OK) st = dmalloc(&c->dense, db);
+    if (st == SBR_OK) st = dmalloc(&c->dense_all, n * db);
+    if (st != SBR_OK) {
+        dfree(c->send); dfree(c->recv); dfree(c->dense); dfree(c->dense_all);
+        c->send = c->recv = c->dense = c->dense_all = nullptr;
+        return st;
+    }
+    c->chunk = chunk; c->db = db;
+    return SBR_OK;
+}
+
+/* in-place all-gather of one item-table block's owner slices (slice r of every replica <- rank r) */
+static sbr_status comm_gather_block(sbr_model* m, sbr_comm* c, int32_t which) {
+    RcclApi& a = *rccl_api();
+    void* base = nullptr;
+    uint64_t sb = 0;
+    SBRCHK(sbr_model_table_slice(m, which, &base, &sb));
+    if (!base) return SBR_OK;
+    if (a.AllGather(reinterpret_cast<uint8_t*>(base) + (size_t)c->rank * sb, base, sb, kNcclUint8, c->comm, m->stream) != 0) return SBR_ERR_HIP;
+    return SBR_OK;
+}
+
 sbr_status sbr_fit_step_exchange(sbr_fit_plan* p, uint64_t minibatch, sbr_comm* c) {
     if (!p || !c || (int)c->world != p->ndev || (int)c->rank != p->rank || minibatch >= p->ep[p->cur].num_mb || p->m->shared)
         return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
+    if (c->device != m->device) return SBR_ERR_INVALID_ARGUMENT; /* the communicator belongs to the device that was current at sbr_comm_create */
     SBRCHK(ensure_device(m));
     RcclApi& a = *rccl_api();
     uint64_t chunk = 0, db = 0;
     SBRCHK(sbr_fit_chunk_bytes(p, &chunk));
     SBRCHK(sbr_fit_dense_bytes(p, &db));
     const uint32_t n = c->world;
-    if (c->chunk != chunk || c->db != db) {
-        HIPCHK(hipStreamSynchronize(m->stream));
-        dfree(c->send); dfree(c->recv); dfree(c->own); dfree(c->table); dfree(c->dense); dfree(c->dense_all);
-        c->send = c->recv = c->own = c->table = c->dense = c->dense_all = nullptr;
-        SBRCHK(dmalloc(&c->send, n * chunk)); SBRCHK(dmalloc(&c->recv, n * chunk));
-        SBRCHK(dmalloc(&c->own, chunk)); SBRCHK(dmalloc(&c->table, n * chunk));
-        SBRCHK(dmalloc(&c->dense, db)); SBRCHK(dmalloc(&c->dense_all, n * db));
-        c->chunk = chunk; c->db = db;
-    }
+    SBRCHK(comm_buffers(p, c, chunk, db));
     hipStream_t st = m->stream;
     SBRCHK(sbr_fit_step_scatter(p, minibatch, c->send));
     if (a.GroupStart() != 0) return SBR_ERR_HIP; /* all-to-all: chunk q of this rank -> rank q */
+    int bad = 0; /* the group is closed whatever happens inside it: an open group would swallow every later collective of this thread */
     for (uint32_t q = 0; q < n; ++q) {
-        if (a.Send(c->send + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st) != 0) return SBR_ERR_HIP;
-        if (a.Recv(c->recv + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st) != 0) return SBR_ERR_HIP;
+        bad |= a.Send(c->send + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st);
+        bad |= a.Recv(c->recv + (size_t)q * chunk, chunk, kNcclUint8, (int)q, c->comm, st);
     }
-    if (a.GroupEnd() != 0) return SBR_ERR_HIP;
-    SBRCHK(sbr_fit_step_owner_reduce(p, c->recv, c->own));
-    if (a.AllGather(c->own, c->table, chunk, kNcclUint8, c->comm, st) != 0) return SBR_ERR_HIP;
-    SBRCHK(sbr_fit_step_apply_rows(p, c->table));
+    bad |= a.GroupEnd();
+    if (bad) return SBR_ERR_HIP;
+    SBRCHK(sbr_fit_step_owner_update(p, c->recv));
+    SBRCHK(comm_gather_block(m, c, SBR_PARAM_ITEM_EMBEDDING));
+    SBRCHK(comm_gather_block(m, c, SBR_PARAM_ITEM_BIAS));
     SBRCHK(sbr_fit_step_dense(p, c->dense));
     if (a.AllGather(c->dense, c->dense_all, db, kNcclUint8, c->comm, st) != 0) return SBR_ERR_HIP;
     SBRCHK(sbr_fit_step_apply_dense(p, c->dense_all));
     return SBR_OK;
 }
 
+/* every replica's copy of the item table's optimiser state made complete again from the owners' slices (a fit through
+ * sbr_fit_step_exchange leaves a row's state on its owner only) */
+sbr_status sbr_comm_gather_optimizer_state(sbr_model* m, sbr_comm* c) {
+    if (!m || !c || m->hp.num_devices != c->world || m->hp.device_rank != c->rank || c->device != m->device) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(ensure_device(m));
+    for (int32_t which : {SBR_PARAM_ITEM_EMBEDDING_ACC, SBR_PARAM_ITEM_BIAS_ACC, SBR_PARAM_ITEM_EMBEDDING_M, SBR_PARAM_ITEM_BIAS_M})
+        SBRCHK(comm_gather_block(m, c, which));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->opt_state_partial = false;
+    return SBR_OK;
+}
+
 /* the whole fit of THIS rank through the library's own transport: ≙ fit with num_threads(world) across processes */
 sbr_status sbr_model_fit_comm(sbr_model* m, sbr_comm* c, const uint64_t* user_ptr, const uint32_t* item_ids, uint64_t num_users, float* out_loss) {
     if (!m || !c || m->hp.num_devices != c->world || m->hp.device_rank != c->rank) return SBR_ERR_INVALID_ARGUMENT;
+    if (m->reference_order && c->world > 1) return SBR_ERR_UNSUPPORTED; /* several workers in reference order: sbr_group_fit only */
     sbr_fit_plan* p = nullptr;
     SBRCHK(sbr_fit_begin(m, user_ptr, item_ids, num_users, &p));
     sbr_status st = SBR_OK;
@@ -2294,6 +2430,7 @@ sbr_status sbr_model_fit_comm(sbr_model* m, sbr_comm* c, const uint64_t* user_pt
             if (st == SBR_OK) st = sbr_fit_step_exchange(p, mb, c);
         }
     }
+    if (st == SBR_OK) st = sbr_comm_gather_optimizer_state(m, c);
     if (st == SBR_OK) st = sbr_fit_end(p, out_loss, nullptr);
     if (st == SBR_OK) st = sbr_fit_end_lagged(p, &m->last_lagged_loss); /* this rank's term; hosts add the ranks' terms in rank order */
     sbr_fit_plan_destroy(p);
@@ -2462,6 +2599,16 @@ sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds,
  * it, and phases are separated by a host barrier, so hipStreamWaitEvent never sees an event that has not been recorded yet. */
 namespace {
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 /* n - 1 helper threads (the caller is worker 0).  run(f) = f(r) on every worker, then a barrier.  The helpers spin for the next
  * phase for a short while (a step's phases follow each other within microseconds) and then sleep on a condition variable. */
 struct PhaseWorkers {
@@ -2491,7 +2638,7 @@ struct PhaseWorkers {
         for (;;) {
             int spins = 0;
             while (generation.load(std::memory_order_acquire) == seen) {
-                if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+                if (++spins < 20000) { cpu_relax(); continue; }
                 std::unique_lock<std::mutex> g(mu);
                 cv.wait(g, [&] { return generation.load(std::memory_order_acquire) != seen; });
             }
@@ -2511,7 +2658,7 @@ struct PhaseWorkers {
         }
         cv.notify_all();
         status[0] = f(0);
-        while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+        while (pending.load(std::memory_order_acquire) != 0) cpu_relax();
         for (uint32_t r = 0; r < n; ++r)
             if (status[r] != SBR_OK) return status[r];
         return SBR_OK;
@@ -2532,6 +2679,7 @@ struct sbr_group_plan {
     uint32_t n = 0;
     uint64_t chunk = 0, db = 0, block_bytes = 0;
     bool partitioned = false, async = false, reforder = false;
+    bool owner_applied = true;       /* Synchronous, replicated: the owners apply the update and the parameter slices travel (sbr_group_plan_set_exchange) */
     bool first = true;               /* no step has been applied yet: nothing to wait for */
     uint64_t nmb = 0;                /* minibatches of the prepared epoch */
     uint32_t epochs_prepared = 0;
@@ -2556,7 +2704,8 @@ struct sbr_group_plan {
     /* local half of minibatch mb on device r (a partitioned table must not still be written by the previous step's owners) */
     sbr_status local(uint32_t r, uint64_t mb) {
         SBRCHK(ensure_device(models[r]));
-        if (partitioned) SBRCHK(wait_applied(r, models[r]->stream));
+        /* (reference order: the peers copy this plan's block on their own streams) */
+        if (partitioned || reforder) SBRCHK(wait_applied(r, models[r]->stream));
         return sbr_fit_step_local(dev[r].plan, mb);
     }
     /* reference order (sbr_model_set_reference_order on every replica): the devices' blocks are gathered and applied as n optimiser
@@ -2588,7 +2737,11 @@ struct sbr_group_plan {
         if (local_done == (int64_t)mb) return sbr_fit_step_apply(dev[0].plan, mb);
         return sbr_fit_step(dev[0].plan, mb);
     }
-    /* Parallelism::Synchronous: compute, exchange, apply — every device sees every update before its next minibatch */
+    /* Parallelism::Synchronous: compute, exchange, apply — every device sees every update before its next minibatch.
+     * owner_applied (default): the owner of a slice adds the devices' contributions AND updates its rows in place; the updated
+     * parameter slices are all-gathered straight into every replica's table (peer copies) — no replica walks the whole table, a row's
+     * optimiser state lives on its owner (gathered to all replicas when the fit ends).  Otherwise (sbr_group_plan_set_exchange 1;
+     * what the staleness-one pipeline runs as well): the gradient chunks are all-gathered and every replica applies every update. */
     sbr_status sync_step(uint64_t mb) {
         const bool have_local = local_done == (int64_t)mb;
         SBRCHK(phase([&](uint32_t r) -> sbr_status {
@@ -2605,23 +2758,70 @@ struct sbr_group_plan {
                 if (r != p) HIPCHK(hipStreamWaitEvent(models[p]->stream, dev[r].scattered, 0));
                 HIPCHK(hipMemcpyAsync(dev[p].recv + r * chunk, dev[r].send + p * chunk, chunk, hipMemcpyDefault, models[p]->stream));
             }
-            SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
+            if (owner_applied) SBRCHK(sbr_fit_step_owner_update(dev[p].plan, dev[p].recv));
+            else SBRCHK(sbr_fit_step_owner_reduce(dev[p].plan, dev[p].recv, dev[p].own));
             SBRCHK(sbr_fit_step_dense(dev[p].plan, dev[p].dense));
             HIPCHK(hipEventRecord(dev[p].reduced, models[p]->stream));
             return SBR_OK;
         }));
-        SBRCHK(phase([&](uint32_t q) -> sbr_status { /* all-gather of the owners' chunks and of the dense blocks */
+        SBRCHK(phase([&](uint32_t q) -> sbr_status { /* all-gather of the owners' slices / chunks and of the dense blocks */
             SBRCHK(ensure_device(models[q]));
             for (uint32_t p = 0; p < n; ++p) {
                 if (p != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[p].reduced, 0));
-                HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, models[q]->stream));
+                if (owner_applied) {
+                    if (p != q) {
+                        SBRCHK(copy_slice(q, p, SBR_PARAM_ITEM_EMBEDDING));
+                        SBRCHK(copy_slice(q, p, SBR_PARAM_ITEM_BIAS));
+                    }
+                } else {
+                    HIPCHK(hipMemcpyAsync(dev[q].table + p * chunk, dev[p].own, chunk, hipMemcpyDefault, models[q]->stream));
+                }
                 HIPCHK(hipMemcpyAsync(dev[q].dense_all + p * db, dev[p].dense, db, hipMemcpyDefault, models[q]->stream));
             }
-            SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
+            if (owner_applied) SBRCHK(sbr_fit_step_apply_dense(dev[q].plan, dev[q].dense_all));
+            else SBRCHK(sbr_fit_step_apply_table(dev[q].plan, dev[q].table, dev[q].dense_all));
             HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
             return SBR_OK;
         }));
         first = false;
+        return SBR_OK;
+    }
+    /* the owner's reduced chunk and the gathered chunks of the gradient all-gather (the pipeline; sbr_group_plan_set_exchange 1) */
+    sbr_status gradient_gather_buffers(uint32_t r) {
+        Dev& v = dev[r];
+        if (v.own) return SBR_OK;
+        SBRCHK(ensure_device(models[r]));
+        SBRCHK(dmalloc(&v.own, chunk));
+        SBRCHK(dmalloc(&v.table, n * chunk));
+        return SBR_OK;
+    }
+    /* replica q's copy of owner p's slice of one item-table block <- replica p's (queued on q's stream) */
+    sbr_status copy_slice(uint32_t q, uint32_t p, int32_t which) {
+        void *src = nullptr, *dst = nullptr;
+        uint64_t sb = 0, sb2 = 0;
+        SBRCHK(sbr_model_table_slice(models[p], which, &src, &sb));
+        SBRCHK(sbr_model_table_slice(models[q], which, &dst, &sb2));
+        if (!src || !dst || sb != sb2) return src || dst ? SBR_ERR_INVALID_ARGUMENT : SBR_OK;
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(dst) + (size_t)p * sb, reinterpret_cast<const uint8_t*>(src) + (size_t)p * sb, sb,
+                              hipMemcpyDefault, models[q]->stream));
+        return SBR_OK;
+    }
+    /* owner-applied steps leave a row's optimiser state on its owner only: every replica's copy made complete again (fit end) */
+    sbr_status gather_optimizer_state() {
+        bool any = false;
+        for (uint32_t r = 0; r < n; ++r) any = any || models[r]->opt_state_partial;
+        if (!any || partitioned) return SBR_OK;
+        drain(); /* every owner's last update has landed */
+        for (uint32_t q = 0; q < n; ++q) {
+            SBRCHK(ensure_device(models[q]));
+            for (uint32_t p = 0; p < n; ++p) {
+                if (p == q) continue;
+                for (int32_t which : {SBR_PARAM_ITEM_EMBEDDING_ACC, SBR_PARAM_ITEM_BIAS_ACC, SBR_PARAM_ITEM_EMBEDDING_M, SBR_PARAM_ITEM_BIAS_M})
+                    SBRCHK(copy_slice(q, p, which));
+            }
+        }
+        drain();
+        for (uint32_t r = 0; r < n; ++r) models[r]->opt_state_partial = false;
         return SBR_OK;
     }
     /* Partitioned item table: every row is stored once (on its owner) and read by everybody through the shared mapping.  A step:
@@ -2743,7 +2943,7 @@ struct sbr_group_plan {
             SBRCHK(dmalloc(&v.dense, db)); SBRCHK(dmalloc(&v.dense_all, n * db));
             if (!partitioned) { /* the replicated exchange moves table-sized chunks; the partitioned one needs none */
                 SBRCHK(dmalloc(&v.send, n * chunk)); SBRCHK(dmalloc(&v.recv, n * chunk));
-                SBRCHK(dmalloc(&v.own, chunk)); SBRCHK(dmalloc(&v.table, n * chunk));
+                if (async) SBRCHK(gradient_gather_buffers(r)); /* (Synchronous: the parameter slices are gathered in place) */
             }
             HIPCHK(hipEventCreateWithFlags(&v.scattered, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&v.reduced, hipEventDisableTiming));
@@ -2806,6 +3006,7 @@ struct sbr_group_plan {
     }
     ~sbr_group_plan() {
         workers.reset();
+        (void)gather_optimizer_state(); /* (an abandoned plan as well: the models outlive it) */
         drain();
         for (uint32_t r = 0; r < n; ++r) {
             Dev& v = dev[r];
@@ -2846,6 +3047,21 @@ sbr_status sbr_group_plan_set_host_threads(sbr_group_plan* g, int32_t enable) {
     if (enable && !g->workers && g->n > 1) g->workers.reset(new PhaseWorkers(g->n));
     if (!enable) g->workers.reset();
     return SBR_OK;
+}
+
+sbr_status sbr_group_plan_set_exchange(sbr_group_plan* g, int32_t gradient_all_gather) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    for (uint32_t r = 0; r < g->n; ++r)
+        if (g->models[r]->opt_state_partial && gradient_all_gather) return SBR_ERR_INVALID_ARGUMENT; /* owner-applied steps have run: finish the fit first */
+    if (gradient_all_gather && g->n > 1 && !g->partitioned && !g->reforder)
+        for (uint32_t r = 0; r < g->n; ++r) SBRCHK(g->gradient_gather_buffers(r));
+    g->owner_applied = !gradient_all_gather;
+    return SBR_OK;
+}
+
+sbr_status sbr_group_gather_optimizer_state(sbr_group_plan* g) {
+    if (!g) return SBR_ERR_INVALID_ARGUMENT;
+    return g->gather_optimizer_state();
 }
 
 sbr_status sbr_group_epoch_prepare(sbr_group_plan* g, uint64_t* out_num_minibatches, int32_t prefetch_next) {
@@ -2889,6 +3105,7 @@ sbr_status sbr_group_fit_end(sbr_group_plan* g, float* out_loss) {
     if (!g) return SBR_ERR_INVALID_ARGUMENT;
     auto finish = [&]() -> sbr_status {
         const uint32_t n = g->n;
+        SBRCHK(g->gather_optimizer_state());
         for (uint32_t r = 1; r < n; ++r) SBRCHK(sbr_fit_end(g->dev[r].plan, nullptr, nullptr));
         float lagged = 0.0f; /* the workers' terms added in worker order, f32 (sequence_model.rs:173-177) */
         for (uint32_t r = 0; r < n; ++r) {

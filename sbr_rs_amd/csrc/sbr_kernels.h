@@ -241,6 +241,9 @@ void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_hos
                      hipStream_t s);
 void launch_owner_reduce(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s);
 void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t slice_rows, hipStream_t s);
+/* owner-applied update: device-order sum of the devices' contributions to the owner's rows [row0, row0 + nrows) and ONE optimiser
+ * update of each touched row, in place (owner_reduce + table_apply for the owner's slice in one pass; the parameter slices travel) */
+void launch_owner_update(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, uint64_t row0, uint64_t nrows, hipStream_t s);
 /* partitioned item table: the owner merges the peers' lists (read through peer mappings) in device order
  * and updates its rows */
 void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,

@@ -18,6 +18,7 @@
 
 #include "sbr_kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -2755,6 +2756,43 @@ __global__ __launch_bounds__(256) void owner_reduce_kernel(ChunkPtrs recv, int n
     }
 }
 
+// owner-APPLIED update (Parallelism::Synchronous, replicated table; ≙ the one shared HogwildParameter of lstm.rs:259-260, whose
+// optimiser state exists once): the same device-order sum as owner_reduce_kernel, and right behind it the ONE optimiser update of
+// the row — in place, on the owner's own rows [row0, row0 + nrows) of its replica; the updated PARAMETER slice (not the gradient
+// sums) is what the devices then all-gather, straight into every replica's table.  Same sums, same update arithmetic as
+// owner_reduce_kernel + table_apply_kernel: same bits; no device walks the whole table any more, and a row's optimiser state
+// lives on its owner only.
+template <int D>
+__global__ __launch_bounds__(256) void owner_update_kernel(ModelView m, ChunkPtrs recv, int ndev, uint64_t S, uint64_t row0, uint64_t nrows) {
+    constexpr int L = D / 4;
+    constexpr int GPW = 64 / L;
+    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave * GPW + grp; i < nrows; i += nwaves * GPW) {
+        uint32_t f[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)  /* the devices' flags of this row first: one round trip, then only the touched contributions */
+            f[q] = q < ndev ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(recv.p[q]) + S * D + S)[i] : 0u;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gb = 0.0f;
+        uint32_t fl = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  /* (f[q] = 0 beyond ndev: nothing is read there) */
+            const float* c = reinterpret_cast<const float*>(recv.p[q]);
+            if (f[q] & 1u) {
+                const float4 v = ld4(c + i * D + 4 * lg);
+                if (fl & 1u) { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
+                else g = v;
+            }
+            if (f[q] & 2u) gb = (fl & 2u) ? gb + c[S * D + i] : c[S * D + i];
+            fl |= f[q];
+        }
+        if (fl & 1u) row_update<D>(m, row0 + i, lg, g, false, 0.0f);
+        if (fl & 2u) bias_update(m, row0 + i, lg, gb);
+    }
+}
+
 // every device: Adagrad on every touched row from the gathered global sums
 template <int D>
 __global__ __launch_bounds__(256) void table_apply_kernel(ModelView m, ChunkPtrs table, uint64_t S) {
@@ -3494,7 +3532,7 @@ void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& bl
             const int gpb = 4 * (64 / (DD / 4));
             const int seg_blocks = grid_for_groups((long long)total / 2 + 1, gpb);
             const size_t lds = m.ng ? ((size_t)rows_host * m.ng * DD + (size_t)(256 / (m.ng * DD) + 2) * rows_host) * 4 : 0;
-            static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
+            static std::atomic<size_t> granted[64]; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
             int dev = 0;
             (void)hipGetDevice(&dev);
             dev = dev >= 0 && dev < 64 ? dev : 0;
@@ -3540,6 +3578,14 @@ void launch_owner_reduce(const ModelView& m, const ChunkPtrs& recv, int ndev, ui
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
         hipLaunchKernelGGL((owner_reduce_kernel<DD>), dim3(grid_for_groups((long long)slice_rows, gpb)), dim3(256), 0, s, recv, ndev, slice_rows, own);
+    });
+}
+
+void launch_owner_update(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, uint64_t row0, uint64_t nrows, hipStream_t s) {
+    if (nrows == 0) return;
+    DISPATCH_D(m.d, {
+        const int gpb = 4 * (64 / (DD / 4));
+        hipLaunchKernelGGL((owner_update_kernel<DD>), dim3(grid_for_groups((long long)nrows, gpb)), dim3(256), 0, s, m, recv, ndev, slice_rows, row0, nrows);
     });
 }
 

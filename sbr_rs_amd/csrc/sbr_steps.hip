@@ -7,6 +7,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see sbr_rs_amd/build.py).
 #include "sbr_kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -1054,7 +1055,7 @@ void launch_epoch_steps(const ModelView& m, const EpochView& ev, const BlockView
     if (!lds || step_end <= step_begin) return;
 #define SBR_EWMA_STEPS(DD)                                                                                                          \
     {                                                                                                                               \
-        static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */                     \
+        static std::atomic<size_t> granted[64]; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */                     \
         int dev = 0;                                                                                                                \
         (void)hipGetDevice(&dev);                                                                                                   \
         dev = dev >= 0 && dev < 64 ? dev : 0;                                                                                       \
@@ -1080,7 +1081,7 @@ void launch_lstm_steps(const ModelView& m, const EpochView& ev, const BlockView&
     if (step_end <= step_begin || run_max_rows <= 0 || run_max_rows > SBR_LSTM_STEPS_MAX_ROWS) return;
     /* [loss nodes | dz | the largest step's arrays] */
     const size_t lds = (SBR_LSTM_STEPS_LDS_FLOATS(run_max_rows) - (size_t)((run_max_rows + 3) & ~3) + (size_t)((lag_rows + 3) & ~3)) * 4;
-    static size_t granted[64] = {0}; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
+    static std::atomic<size_t> granted[64]; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev >= 0 && dev < 64 ? dev : 0;

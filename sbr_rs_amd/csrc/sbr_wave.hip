@@ -27,6 +27,7 @@
  * return false otherwise and the caller launches the tile kernels).  The machine model behind the design — a lone wave
  * issues a dependent vector instruction every 8.8 cycles, so a step costs its instruction count — is measured by
  * tools/valu_chain_ubench.hip; numbers in profiles/r03_small_steps.md. */
+#include <atomic>
 #include <cstdlib>
 
 #include "sbr_kernels.h"
@@ -252,7 +253,7 @@ bool wave_shape_ok(int d, int ng, int B, size_t lds_bytes) {
 // step of a few microseconds does not pay for the call again
 // (per device: the attribute belongs to the function on the current device, and one process may drive several)
 template <class K>
-void allow_lds(K kernel, size_t bytes, size_t* granted) {
+void allow_lds(K kernel, size_t bytes, std::atomic<size_t>* granted) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev >= 0 && dev < 64 ? dev : 0;
@@ -270,7 +271,7 @@ bool launch_wave_forward(const ModelView& m, const MbView& mb, float* H, const W
     if (!wave_shape_ok(d, m.ng, mb.B, lds)) return false;
 #define SBR_WAVE_FWD(DD, NN)                                                                                   \
     {                                                                                                          \
-        static size_t granted[64] = {0};                                                                             \
+        static std::atomic<size_t> granted[64];                                                                             \
         allow_lds(lstm_fwd_wave_kernel<DD, NN>, lds, granted);                                                \
         hipLaunchKernelGGL((lstm_fwd_wave_kernel<DD, NN>), dim3(mb.B), dim3(256), lds, s, m, mb, H, w, seg);           \
     }
@@ -290,7 +291,7 @@ bool launch_wave_backward(const ModelView& m, const MbView& mb, const BlockView&
     if (!wave_shape_ok(d, m.ng, b_host, lds)) return false;
 #define SBR_WAVE_BWD(DD, NN)                                                                                   \
     {                                                                                                          \
-        static size_t granted[64] = {0};                                                                             \
+        static std::atomic<size_t> granted[64];                                                                             \
         allow_lds(lstm_bwd_wave_kernel<DD, NN>, lds, granted);                                                \
         hipLaunchKernelGGL((lstm_bwd_wave_kernel<DD, NN>), dim3(b_host), dim3(256), lds, s, m, mb, blk, w, seg);       \
     }
@@ -314,7 +315,7 @@ bool launch_wave_dense_gradient(const ModelView& m, const MbView& mb, const Bloc
 #define SBR_DW_BLOCK_LAUNCH(DD, NN)                                                                                          \
     {                                                                                                                        \
         using Cfg = DwBlockCfg<DD, NN>;                                                                                      \
-        static size_t granted[64] = {0};                                                                                           \
+        static std::atomic<size_t> granted[64];                                                                                           \
         allow_lds(lstm_dw_block_kernel<DD, NN>, Cfg::lds_bytes, granted);                                                    \
         hipLaunchKernelGGL((lstm_dw_block_kernel<DD, NN>), dim3(nch * Cfg::KB), dim3(Cfg::NT), Cfg::lds_bytes, s, m, mb, blk, w); \
     }

@@ -11,16 +11,23 @@ full parameter replica per GPU, and the rendezvous is the **owner-reduce** excha
     scatter         the device's own sparse entries reduced per table row into ``world`` dense
                     chunks, one per owner of a contiguous slice of ceil(I / world) rows
     all_to_all      chunk p of every device -> device p                      (RCCL, xGMI mesh)
-    owner_reduce    the owner adds the devices' contributions in device order
-    all_gather      of the owners' chunks (global gradient sums of the whole table) and of the
-                    small dense blocks (LSTM / alpha gradients + loss header)  (RCCL)
-    apply_table     every device applies the identical Adagrad update
+    owner_update    the owner adds the devices' contributions in device order AND applies the one
+                    optimiser update of every touched row of its slice, in place (round 6; ≙ the
+                    one shared parameter + optimiser state of lstm.rs:259-260)
+    all_gather      of the owners' updated PARAMETER slices, in place into every replica's table,
+                    and of the small dense blocks (LSTM / alpha gradients + loss header)  (RCCL)
+    apply_dense     every device applies the identical dense update (device-order sum)
+
+(Parallelism::Asynchronous, the staleness-one pipeline, keeps rounds 1-5's form of the last three:
+owner_reduce -> all-gather of the reduced GRADIENT chunks -> apply_table on every replica.)
 
 Per device and step the exchange moves 2 x (world-1)/world x table bytes, independent of the
 batch, and every pairwise link of the xGMI mesh carries table/world bytes per phase — instead of
 (world-1) x (2·4d + 16) bytes per interaction for an all-gather of the raw entries.  Every
 reduction has a fixed order, so replicas stay bit-identical without any parameter broadcast, and
-the result equals the single-process oracle run with ``num_devices = world`` bit for bit.
+the result equals the single-process oracle run with ``num_devices = world`` bit for bit.  During a
+fit a row's optimiser state is maintained by its owner alone; when the fit ends the owners' state
+slices are all-gathered the same way, so every replica is complete again (checkpoints, get_param).
 
 The driver below is backend-agnostic on purpose: ``tests/test_distributed_cpu.py`` runs it with
 world_size 2 on the gloo backend with CPU tensors (the oracle computing the device halves), which
@@ -29,6 +36,7 @@ halves for several simulated ranks on one GPU.
 """
 from __future__ import annotations
 
+import os
 from typing import Protocol
 
 
@@ -43,12 +51,60 @@ class StepBackend(Protocol):
     def owner_reduce(self, recv): ...                              # -> own chunk [chunk]
     def apply_table(self, table, dense_all) -> None: ...
     # optional: apply_rows(table) + apply_dense(dense_all) = apply_table in two halves (rows first)
+    # optional, the owner-applied form: owner_update(recv) -> [(whole block, this rank's slice of it), ...] to all-gather
+    #           (the HIP engine's pairs alias its table: the gather lands in place), slices_gathered(), apply_dense(dense_all);
+    #           optimizer_state_slices() -> the same pairs for the optimiser-state blocks, optimizer_state_gathered()
     def buffers(self, world: int): ...                             # -> (recv, table, dense_all)
     def end(self): ...                                             # -> (loss, examples)
 
 
+def _all_gather_pairs(dist, group, pairs, staged: bool) -> None:
+    import torch
+
+    for full, mine in pairs:
+        if staged:  # gloo with device tensors: through host memory
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(parts, mine.cpu(), group=group)
+            full.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(full, mine, group=group)
+
+
+def owner_exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=None) -> None:
+    """One Synchronous optimiser step after compute_local, owner-applied: all-to-all of the gradient chunks, the owner's
+    in-place update, all-gather of the updated parameter slices into every replica's table."""
+    import torch
+    import torch.distributed as dist
+
+    recv, _table, dense_all = bufs
+    send = backend.scatter(minibatch)
+    staged = send.is_cuda and dist.get_backend(group) == "gloo"
+    if staged:
+        h_recv = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(h_recv, send.cpu(), group=group)
+        recv.copy_(h_recv)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
+    _all_gather_pairs(dist, group, backend.owner_update(recv), staged)
+    backend.slices_gathered()
+    dense = backend.dense()  # joins the dense-gradient GEMM, which ran beside all of the above
+    _all_gather_pairs(dist, group, [(dense_all, dense)], staged)
+    backend.apply_dense(dense_all)
+
+
+def gather_optimizer_state(backend: StepBackend, group=None) -> None:
+    """After the last owner-applied step of a fit: every replica's copy of the item table's optimiser state made complete."""
+    import torch.distributed as dist
+
+    pairs = backend.optimizer_state_slices()
+    staged = bool(pairs) and pairs[0][0].is_cuda and dist.get_backend(group) == "gloo"
+    _all_gather_pairs(dist, group, pairs, staged)
+    backend.optimizer_state_gathered()
+
+
 def exchange_step(backend: StepBackend, minibatch: int, world: int, bufs, group=None) -> None:
-    """One optimiser step after compute_local: the owner-reduce exchange."""
+    """One optimiser step after compute_local with the GRADIENT all-gather (rounds 1-5; what the pipeline's ordering is built
+    on): owner reduce, all-gather of the reduced chunks, every replica applies every update."""
     import torch.distributed as dist
 
     recv, table, dense_all = bufs
@@ -101,12 +157,16 @@ class StepLoop:
     has streams) runs underneath that computation; update k is applied afterwards.  With one
     device both modes are the same step."""
 
-    def __init__(self, backend: StepBackend, world: int, asynchronous: bool = False, group=None):
+    def __init__(self, backend: StepBackend, world: int, asynchronous: bool = False, group=None, exchange: str = None):
         self.backend, self.world, self.group = backend, world, group
         self.asynchronous = bool(asynchronous) and world > 1
-        self.bufs = backend.buffers(world) if world > 1 else None
+        # Synchronous: the owner-applied update where the backend has it; exchange="gradient" forces rounds 1-5's form (A/B, parity)
+        want = exchange or os.environ.get("SBR_EXCHANGE", "owner")
+        self.owner_applied = (not self.asynchronous) and world > 1 and want != "gradient" and hasattr(backend, "owner_update")
+        self.bufs = (backend.buffers(world, gradient_gather=not self.owner_applied) if self.owner_applied else backend.buffers(world)) if world > 1 else None
         self.num_minibatches = 0
         self._computed = -1  # minibatch whose local results are in the backend's block
+        self._owner_steps = 0
 
     def begin_epoch(self, prefetch_next: bool = False) -> int:
         self.num_minibatches = self.backend.epoch_prepare(prefetch_next=prefetch_next)
@@ -119,6 +179,9 @@ class StepLoop:
             be.compute_local(minibatch)
         if self.world == 1:
             be.apply_single(minibatch)
+        elif self.owner_applied:
+            owner_exchange_step(be, minibatch, self.world, self.bufs, self.group)
+            self._owner_steps += 1
         elif not self.asynchronous:
             exchange_step(be, minibatch, self.world, self.bufs, self.group)
         else:
@@ -126,6 +189,12 @@ class StepLoop:
             pipelined_exchange_step(be, minibatch, nxt, self.bufs, self.group)
             if nxt is not None:
                 self._computed = nxt
+
+    def finish(self) -> None:
+        """End of a fit: the owners' optimiser-state slices back on every replica (no-op for the other step forms)."""
+        if self.owner_applied and self._owner_steps:
+            gather_optimizer_state(self.backend, self.group)
+            self._owner_steps = 0
 
 
 def pipelined_exchange_step(backend: StepBackend, minibatch: int, next_minibatch, bufs, group=None) -> None:
@@ -162,15 +231,28 @@ def pipelined_exchange_step(backend: StepBackend, minibatch: int, next_minibatch
     backend.apply_table(table, dense_all)
 
 
-def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None, asynchronous: bool = False):
+def run_fit(backend: StepBackend, num_epochs: int, world: int, group=None, asynchronous: bool = False, exchange: str = None):
     """The epoch/minibatch loop of fit_sequence_model (sequence_model.rs:108-171) with the
     per-step rendezvous expressed as collectives."""
-    loop = StepLoop(backend, world, asynchronous, group)
+    loop = StepLoop(backend, world, asynchronous, group, exchange=exchange)
     for e in range(num_epochs):
         nmb = loop.begin_epoch(prefetch_next=e + 1 < num_epochs)
         for mb in range(nmb):
             loop.step(mb)
+    loop.finish()
     return backend.end()
+
+
+class _DeviceBytes:
+    """Device memory owned by the engine, described through ``__cuda_array_interface__`` so that torch wraps it without a copy."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def device_bytes_as_tensor(torch, ptr: int, nbytes: int):
+    """A uint8 CUDA tensor ALIASING [ptr, ptr + nbytes) of the engine's memory (the model keeps it alive)."""
+    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device="cuda")
 
 
 class HipBackend:
@@ -192,6 +274,7 @@ class HipBackend:
         self._side = torch.cuda.Stream() if world > 1 else None
         model.set_stream(self._compute.cuda_stream)
         self.plan = model.fit_begin(up, it)
+        self._views = {}
         if world > 1:
             self.chunk = self.plan.chunk_bytes()
             self.dense_bytes = self.plan.dense_bytes()
@@ -243,10 +326,42 @@ class HipBackend:
     def apply_dense(self, dense_all) -> None:
         self.plan.step_apply_dense(dense_all.data_ptr())
 
-    def buffers(self, world: int):
+    # ---- owner-applied form: the engine's table blocks as torch tensors (no copy), this rank's slice a view of each ----
+    def _block_pairs(self, blocks):
+        rank = int(self.model.hp.device_rank)
+        pairs = []
+        for which in blocks:
+            if which not in self._views:
+                ptr, sb = self.model.table_slice(which)
+                self._views[which] = device_bytes_as_tensor(self.torch, ptr, sb * self.world) if ptr else None
+            full = self._views[which]
+            if full is not None:
+                sb = full.numel() // self.world
+                pairs.append((full, full[rank * sb:(rank + 1) * sb]))
+        return pairs
+
+    def owner_update(self, recv):
+        from ._abi import Param
+
+        self.plan.step_owner_update(recv.data_ptr())
+        return self._block_pairs((Param.ITEM_EMBEDDING, Param.ITEM_BIAS))
+
+    def slices_gathered(self) -> None:
+        pass  # the all-gather wrote the table in place
+
+    def optimizer_state_slices(self):
+        from ._abi import Param
+
+        return self._block_pairs((Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS_ACC, Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M))
+
+    def optimizer_state_gathered(self) -> None:
+        self.torch.cuda.current_stream().synchronize()
+        self.model.optimizer_state_gathered()
+
+    def buffers(self, world: int, gradient_gather: bool = True):
         t = self.torch
         return (t.zeros(world * self.chunk, dtype=t.uint8, device="cuda"),
-                t.zeros(world * self.chunk, dtype=t.uint8, device="cuda"),
+                t.zeros(world * self.chunk, dtype=t.uint8, device="cuda") if gradient_gather else None,
                 t.zeros(world * self.dense_bytes, dtype=t.uint8, device="cuda"))
 
     def end(self):

@@ -116,6 +116,15 @@ class GroupPlan:
     def synchronize(self):
         _check(self._L.sbr_group_synchronize(self._h))
 
+    def set_exchange(self, gradient_all_gather: bool):
+        """Synchronous, replicated: False (default) = owner-applied update, parameter slices gathered in place; True = rounds 1-5's
+        gradient all-gather + whole-table update on every replica (sbr_group_plan_set_exchange).  Same bits."""
+        _check(self._L.sbr_group_plan_set_exchange(self._h, 1 if gradient_all_gather else 0))
+
+    def gather_optimizer_state(self):
+        """Every replica's item-table optimiser state made complete from the owners' slices (fit end does it)."""
+        _check(self._L.sbr_group_gather_optimizer_state(self._h))
+
     def stats(self):
         """(host ms spent queueing steps, steps, host threads in use)."""
         ms, n, th = C.c_double(), C.c_uint64(), C.c_int32()
@@ -170,6 +179,9 @@ class Comm:
 
     def step_exchange(self, plan: "FitPlan", mb: int):
         _check(self._L.sbr_fit_step_exchange(plan._h, mb, self._h))
+
+    def gather_optimizer_state(self, model: "Model"):
+        _check(self._L.sbr_comm_gather_optimizer_state(model._h, self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -268,6 +280,11 @@ class FitPlan:
 
     def step_apply_dense(self, dense_all_ptr: int):
         _check(self._L.sbr_fit_step_apply_dense(self._h, C.c_void_p(dense_all_ptr)))
+
+    def step_owner_update(self, recv_ptr: int):
+        """Owner-applied update (sbr_fit_step_owner_update): device-order sum of the devices' contributions to this rank's slice and
+        the one optimiser update of its touched rows, in place; opens the optimiser step."""
+        _check(self._L.sbr_fit_step_owner_update(self._h, C.c_void_p(recv_ptr)))
 
     def end(self):
         loss, ex = C.c_float(), C.c_uint64()
@@ -409,6 +426,22 @@ class Model:
         if len(state) != 16:
             raise ValueError("RNG state is 16 bytes")
         _check(self._L.sbr_model_set_rng(self._h, (C.c_uint8 * 16)(*state)))
+
+    def table_slice(self, which: int):
+        """(device pointer of an item-table block of this replica, bytes per owner slice): rank r's slice is [ptr + r * bytes, + bytes)
+        (sbr_model_table_slice; the block is allocated for num_devices equal slices).  (0, 0): the model has no such block."""
+        base, nb = C.c_void_p(), C.c_uint64()
+        _check(self._L.sbr_model_table_slice(self._h, int(which), C.byref(base), C.byref(nb)))
+        return (base.value or 0), nb.value
+
+    def optimizer_state_gathered(self):
+        """The host has all-gathered the owners' optimiser-state slices into this replica (sbr_model_optimizer_state_gathered)."""
+        _check(self._L.sbr_model_optimizer_state_gathered(self._h))
+
+    def optimizer_state_is_partial(self) -> bool:
+        v = C.c_int32()
+        _check(self._L.sbr_model_optimizer_state_is_partial(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_stream(self, hip_stream_ptr: int):
         _check(self._L.sbr_model_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

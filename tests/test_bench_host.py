@@ -19,9 +19,10 @@ def test_workload_labels_follow_baseline_configs():
     assert bench.workload_label(_args(), 1) == "BASELINE.json configs[2]"
     assert bench.workload_label(_args(users=125_000, max_len=128), 8) == "BASELINE.json configs[3]"
     assert "configs[3]'s per-GPU shape at 4 GPUs" in bench.workload_label(_args(users=125_000, max_len=128), 4)
-    # configs[2]'s shape on several GPUs is not a BASELINE config, and neither is configs[3]'s shape on one
+    # configs[2]'s shape on several GPUs is not a BASELINE config; configs[3]'s per-GPU shape on one GPU is the denominator of the
+    # weak-scaling efficiency (--scale-shape) and says so
     assert bench.workload_label(_args(), 8) == "custom workload"
-    assert bench.workload_label(_args(users=125_000, max_len=128), 1) == "custom workload"
+    assert "same-shape denominator" in bench.workload_label(_args(users=125_000, max_len=128), 1)
     c4 = _args(model="ewma", loss="hinge", dim=256, items=10_000_000, users=125_000, max_len=128, partition_table=True)
     assert bench.workload_label(c4, 8) == "BASELINE.json configs[4]"
     assert "configs[4]'s shape" in bench.workload_label(c4, 2)

@@ -22,7 +22,7 @@ class OracleBackend:
     """The oracle's device halves behind the same StepBackend interface the HIP engine uses."""
 
     def __init__(self, model: OracleModel, rank: int, world: int, ptr, items):
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.model = rank, world, model
         self.plan = model.fit_begin(ptr, items)
 
     def epoch_prepare(self, prefetch_next=False):
@@ -46,9 +46,45 @@ class OracleBackend:
     def apply_table(self, table, dense_all):
         self.plan.apply_table(table.numpy(), dense_all.numpy())
 
-    def buffers(self, world):
+    # ---- the owner-applied form (sbr_fit_step_owner_update): the checker's replicas hold plain arrays, so the gathered
+    # slices are installed by slices_gathered() where the engine's all-gather lands in its table directly ----
+    def _pairs(self, blocks):
+        self._gathering = []
+        for which in blocks:
+            if self.model.param_count(which) == 0:
+                continue
+            mine = torch.from_numpy(self.model.table_slice(which, self.rank))
+            full = torch.zeros(self.world * mine.numel(), dtype=torch.uint8)
+            self._gathering.append((which, full))
+        return [(full, torch.from_numpy(self.model.table_slice(which, self.rank))) for which, full in self._gathering]
+
+    def _install(self):
+        for which, full in self._gathering:
+            sb = full.numel() // self.world
+            for r in range(self.world):
+                if r != self.rank:
+                    self.model.set_table_slice(which, r, full[r * sb:(r + 1) * sb].numpy())
+        self._gathering = []
+
+    def owner_update(self, recv):
+        self.plan.owner_update(self.rank, recv.numpy())
+        return self._pairs((Param.ITEM_EMBEDDING, Param.ITEM_BIAS))
+
+    def slices_gathered(self):
+        self._install()
+
+    def apply_dense(self, dense_all):
+        self.plan.apply_dense_blocks(dense_all.numpy())
+
+    def optimizer_state_slices(self):
+        return self._pairs((Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS_ACC, Param.ITEM_EMBEDDING_M, Param.ITEM_BIAS_M))
+
+    def optimizer_state_gathered(self):
+        self._install()
+
+    def buffers(self, world, gradient_gather=True):
         c, d = self.plan.chunk_bytes(), self.plan.dense_bytes()
-        return (torch.zeros(world * c, dtype=torch.uint8), torch.zeros(world * c, dtype=torch.uint8),
+        return (torch.zeros(world * c, dtype=torch.uint8), torch.zeros(world * c, dtype=torch.uint8) if gradient_gather else None,
                 torch.zeros(world * d, dtype=torch.uint8))
 
     def end(self):
@@ -59,7 +95,7 @@ PARAMS = {2: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, P
           0: [Param.ITEM_EMBEDDING, Param.ITEM_EMBEDDING_ACC, Param.ITEM_BIAS, Param.LSTM_W, Param.LSTM_W_ACC, Param.LSTM_B]}
 
 
-def _worker(rank, world, port, kind, loss, par, out_dir):
+def _worker(rank, world, port, kind, loss, par, out_dir, exchange="owner"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -67,7 +103,7 @@ def _worker(rank, world, port, kind, loss, par, out_dir):
         ptr, items = synthetic_interactions(40 if world < 8 else 120, 90, 14, seed=5, zipf=True)
         hp = hparams(90, 10, 16, kind, loss, epochs=2, B=4, ndev=world, rank=rank, par=par)
         m = OracleModel(hp)
-        loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world, asynchronous=par == PAR_ASYNC)
+        loss_v, ex = run_fit(OracleBackend(m, rank, world, ptr, items), 2, world, asynchronous=par == PAR_ASYNC, exchange=exchange)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=loss_v, ex=ex,
                  **{p.name: m.get_param(p) for p in PARAMS[kind]})
     finally:
@@ -80,14 +116,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind,loss,par,world", [(int(ModelKind.EWMA), LOSS_WARP, PAR_SYNC, 2), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC, 2),
-                                                 (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_ASYNC, 2),
-                                                 (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_SYNC, 8), (int(ModelKind.EWMA), LOSS_HINGE, PAR_ASYNC, 8)])
-def test_multi_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss, par, world):
+@pytest.mark.parametrize("kind,loss,par,world,exchange", [
+    (int(ModelKind.EWMA), LOSS_WARP, PAR_SYNC, 2, "owner"), (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC, 2, "owner"),
+    (int(ModelKind.LSTM_NORMAL), LOSS_HINGE, PAR_SYNC, 2, "gradient"),   # rounds 1-5's Synchronous step: gradient all-gather, every replica applies
+    (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_ASYNC, 2, "owner"),      # (the pipeline always runs the gradient all-gather)
+    (int(ModelKind.LSTM_NORMAL), LOSS_WARP, PAR_SYNC, 8, "owner"), (int(ModelKind.EWMA), LOSS_HINGE, PAR_SYNC, 3, "owner"),
+    (int(ModelKind.EWMA), LOSS_HINGE, PAR_ASYNC, 8, "owner")])
+def test_multi_process_gloo_matches_single_process(tmp_path, oracle_lib, kind, loss, par, world, exchange):
     """`world` gloo processes through the production driver (world 8 = the node BASELINE configs[3] / [4] name) against one
-    process that emulates all devices.  par = Asynchronous: the driver's pipelined step (compute k+1 before update k lands)
-    must equal the oracle's staleness-one emulation."""
-    mp.spawn(_worker, args=(world, _free_port(), kind, loss, par, str(tmp_path)), nprocs=world, join=True)
+    process that emulates all devices.  Synchronous = the owner-applied update (the owner of a slice reduces AND updates it; the
+    updated parameter slices are all-gathered, the optimiser-state slices when the fit ends; world 3 over 90 items: ragged last
+    slice) or, exchange = "gradient", the gradient all-gather of rounds 1-5 — both must equal the one-process emulation, whose
+    step is the latter.  par = Asynchronous: the driver's pipelined step (compute k+1 before update k lands) must equal the
+    oracle's staleness-one emulation."""
+    mp.spawn(_worker, args=(world, _free_port(), kind, loss, par, str(tmp_path), exchange), nprocs=world, join=True)
     ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     # single process, all devices emulated
     ptr, items = synthetic_interactions(40 if world < 8 else 120, 90, 14, seed=5, zipf=True)

@@ -210,20 +210,23 @@ def test_whole_fit_bit_exact(kind, loss, d, items, users, T, B):
     assert_same_bits(g.predict(ug, all_items), o.predict(uo, all_items), "predict")
 
 
-@pytest.mark.parametrize("kind,loss,d,world", [
-    (ModelKind.EWMA, LOSS_WARP, 32, 2),
-    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 64, 3),
-    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 4),
-    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 2),
-    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8),   # the node size of BASELINE configs[3]: eight chunks, eight owner inputs
-    (ModelKind.EWMA, LOSS_HINGE, 256, 8),
+@pytest.mark.parametrize("kind,loss,d,world,exchange", [
+    (ModelKind.EWMA, LOSS_WARP, 32, 2, "owner"),
+    (ModelKind.LSTM_NORMAL, LOSS_HINGE, 64, 3, "owner"),
+    (ModelKind.LSTM_COUPLED, LOSS_WARP, 16, 4, "owner"),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 2, "gradient"),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8, "owner"),   # the node size of BASELINE configs[3]: eight chunks, eight owner inputs
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 8, "gradient"),
+    (ModelKind.EWMA, LOSS_HINGE, 256, 8, "owner"),
+    (ModelKind.EWMA, LOSS_HINGE, 64, 3, "gradient"),
 ])
-def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
-    """The multi-GPU protocol (scatter / owner_reduce / apply_table through the C-ABI) with `world`
-    simulated ranks on ONE GPU: the collectives are replaced by explicit tensor copies, everything
-    else is the production path.  All replicas must end bit-identical to each other and to the
-    single-process oracle with num_devices = world."""
-    import torch
+def test_multi_device_halves_on_one_gpu(kind, loss, d, world, exchange):
+    """The multi-GPU protocol through the C-ABI halves with `world` simulated ranks on ONE GPU (tests/simulated_ranks.py: the
+    collectives are tensor copies, everything else is the production path), in both forms of the Synchronous step: the
+    owner-applied update (scatter / owner_update / in-place all-gather of the parameter slices; the optimiser-state slices when
+    the fit ends) and the gradient all-gather (scatter / owner_reduce / apply_table).  All replicas must end bit-identical to each
+    other and to the single-process oracle with num_devices = world — parameters AND optimiser state."""
+    from simulated_ranks import SimulatedRanks
 
     items, T, B = 203, 12, 6   # 203 % world != 0 for every world here: ragged last slice
     ptr, it = synthetic_interactions(90 if world < 8 else 240, items, T + 4, seed=17, zipf=True)
@@ -232,33 +235,17 @@ def test_multi_device_halves_on_one_gpu(kind, loss, d, world):
         m = Model(hparams(items, T, d, int(kind), loss, epochs=2, B=B, ndev=world, rank=q))
         models.append(m)
         plans.append(m.fit_begin(ptr, it))
-    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
-    u8 = dict(dtype=torch.uint8, device="cuda")
-    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
-    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
-    recv = torch.zeros(world * chunk, **u8)
-    own = [torch.zeros(chunk, **u8) for _ in range(world)]
+    ranks = SimulatedRanks(models, plans)
     for _ in range(2):
         nmb = {p.epoch_prepare() for p in plans}
         assert len(nmb) == 1
         for mb in range(nmb.pop()):
-            for q in range(world):
-                plans[q].step_local(mb)
-                plans[q].step_scatter(mb, send[q].data_ptr())
-                plans[q].step_dense(dense[q].data_ptr())
-                models[q].synchronize()
-            for q in range(world):  # all_to_all_single
-                for src in range(world):
-                    recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
-                torch.cuda.synchronize()
-                plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
-                models[q].synchronize()
-            table = torch.cat(own)          # all_gather_into_tensor
-            dense_all = torch.cat(dense)
-            torch.cuda.synchronize()
-            for q in range(world):
-                plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
-                models[q].synchronize()
+            ranks.step(mb, exchange)
+    if exchange == "owner":  # a row's optimiser state lives on its owner until the slices are gathered: reading it earlier fails loudly
+        assert all(m.optimizer_state_is_partial() for m in models)
+        with pytest.raises(EngineError):
+            models[0].get_param(Param.ITEM_EMBEDDING_ACC)
+    ranks.finish()
     o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=2, B=B, ndev=world, rank=0))
     lo = o.fit(ptr, it)
     for q in range(world):
@@ -411,39 +398,21 @@ def test_adam_whole_fit_bit_exact(kind, loss, d, B):
     assert np.array_equal(rg, ro) and mg == mo
 
 
-def test_adam_multi_device_halves(kind=ModelKind.LSTM_COUPLED):
-    import torch
+@pytest.mark.parametrize("exchange", ["owner", "gradient"])
+def test_adam_multi_device_halves(exchange, kind=ModelKind.LSTM_COUPLED):
+    from simulated_ranks import SimulatedRanks
 
     world, items, T, B, d = 2, 101, 10, 5, 32
     ptr, it = synthetic_interactions(60, items, T + 3, seed=19, zipf=True)
     mk = lambda q: hparams(items, T, d, int(kind), LOSS_BPR, lr=0.02, epochs=1, B=B, ndev=world, rank=q, opt=OPT_ADAM)
     models = [Model(mk(q)) for q in range(world)]
     plans = [m.fit_begin(ptr, it) for m in models]
-    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
-    u8 = dict(dtype=torch.uint8, device="cuda")
-    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
-    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
-    own = [torch.zeros(chunk, **u8) for _ in range(world)]
-    recv = torch.zeros(world * chunk, **u8)
+    ranks = SimulatedRanks(models, plans)
     nmb = plans[0].epoch_prepare()
     assert plans[1].epoch_prepare() == nmb
     for mb in range(nmb):
-        for q in range(world):
-            plans[q].step_local(mb)
-            plans[q].step_scatter(mb, send[q].data_ptr())
-            plans[q].step_dense(dense[q].data_ptr())
-            models[q].synchronize()
-        for q in range(world):
-            for src in range(world):
-                recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
-            torch.cuda.synchronize()
-            plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
-            models[q].synchronize()
-        table, dense_all = torch.cat(own), torch.cat(dense)
-        torch.cuda.synchronize()
-        for q in range(world):
-            plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
-            models[q].synchronize()
+        ranks.step(mb, exchange)
+    ranks.finish()  # owner form: both Adam moments of the item table live on the rows' owners until here
     o = OracleModel(mk(0))
     o.fit(ptr, it)
     for q in range(world):
@@ -1130,17 +1099,19 @@ def test_bench_regime_first_step_sampled_parity(name, kind, loss, d, users, item
     pg.close(); po.close()
 
 
-def test_bench_regime_multi_device_first_step_sampled_parity():
+@pytest.mark.parametrize("exchange", ["owner", "gradient"])
+def test_bench_regime_multi_device_first_step_sampled_parity(exchange):
     """BASELINE configs[3] at full size — 1e6 users over 8 devices, 1e6 items, sequences to 128, d = 128, LSTM + WARP, 8 192
-    sequences per device and step — through the multi-GPU protocol's C-ABI halves (scatter into 8 per-owner chunks of 125 000
-    rows, owner reduce over 8 inputs, table update from 8 reduced chunks, dense update from 8 blocks) with eight simulated ranks on
-    ONE GPU and tensor copies in place of the collectives.  The first optimiser step is compared with the oracle by sampling
+    sequences per device and step — through the multi-GPU protocol's C-ABI halves with eight simulated ranks on ONE GPU and
+    tensor copies in place of the collectives (tests/simulated_ranks.py), in both forms of the Synchronous step: owner-applied
+    (scatter into 8 per-owner chunks of 125 000 rows, every owner reduces 8 inputs and updates its 125 000 rows in place, the
+    parameter slices are all-gathered into the eight tables; the accumulator slices at the end) and the gradient all-gather
+    (owner reduce over 8 inputs, table update from 8 reduced chunks on every replica); dense update from 8 blocks.  The first optimiser step is compared with the oracle by sampling
     (tests/sampled_parity.py::check_first_step_multi): every device's half-step on a sample of its sequences, ~160 item rows'
     device-ordered gradient sums and updates on the first and the last replica, and the dense parameters."""
-    import torch
-
     import bench
     from sampled_parity import check_first_step_multi, count_subsequences
+    from simulated_ranks import SimulatedRanks
 
     world, users, items, T, d, B = 8, 125_000, 1_000_000, 128, 128, 8_192
     ptr, it = bench.synthetic_csr(users * world, items, T)
@@ -1150,8 +1121,7 @@ def test_bench_regime_multi_device_first_step_sampled_parity():
     o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=0))
     po = o.fit_begin(ptr, it)
     assert {p.epoch_prepare() for p in plans} == {po.epoch_prepare()}
-    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
-    u8 = dict(dtype=torch.uint8, device="cuda")
+    ranks = SimulatedRanks(models, plans)
 
     class Full:
         pass
@@ -1164,26 +1134,8 @@ def test_bench_regime_multi_device_first_step_sampled_parity():
     f.fetch = lambda q, which: plans[q].debug_fetch(which, f.rows(q))
 
     def apply_all():
-        send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
-        dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
-        recv = torch.zeros(world * chunk, **u8)
-        own = [torch.zeros(chunk, **u8) for _ in range(world)]
-        for q in range(world):
-            plans[q].step_scatter(0, send[q].data_ptr())
-            plans[q].step_dense(dense[q].data_ptr())
-            models[q].synchronize()
-        for q in range(world):  # all_to_all_single
-            for src in range(world):
-                recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
-            torch.cuda.synchronize()
-            plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
-            models[q].synchronize()
-        table = torch.cat(own)          # all_gather_into_tensor
-        dense_all = torch.cat(dense)
-        torch.cuda.synchronize()
-        for q in range(world):
-            plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
-            models[q].synchronize()
+        ranks.exchange(0, exchange)
+        ranks.finish()
 
     f.apply_all = apply_all
     nb = min(B, count_subsequences(ptr, T) // world)
@@ -1300,15 +1252,16 @@ def test_bench_regime_whole_steps_full_parity(name, kind, loss, d, items, users,
     pg.close(); po.close()
 
 
-def test_bench_regime_two_devices_whole_step_full_parity():
+@pytest.mark.parametrize("exchange", ["owner", "gradient"])
+def test_bench_regime_two_devices_whole_step_full_parity(exchange):
     """The multi-GPU step at configs[3]'s per-GPU size with no sampling: two devices x 125 000 users, sequences to 128, d = 128,
     LSTM + WARP, 8 192 sequences per device — one whole optimiser step through the protocol's C-ABI halves (two simulated ranks on
-    one GPU, tensor copies for the collectives: scatter into two 500 000-row owner chunks, owner reduce, table update, dense
-    update), then every parameter and accumulator of BOTH replicas against the oracle with num_devices = 2.  The eight-device
+    one GPU, tensor copies for the collectives: scatter into two 500 000-row owner chunks, then the owner-applied update + in-place
+    all-gather of the parameter and accumulator slices, or owner reduce + table update on both replicas; dense update), then
+    every parameter and accumulator of BOTH replicas against the oracle with num_devices = 2.  The eight-device
     step of the full configs[3] is compared by sampling above (its whole step is ~80 s of oracle time)."""
-    import torch
-
     import bench
+    from simulated_ranks import SimulatedRanks
 
     world, users, items, T, d, B = 2, 125_000, 1_000_000, 128, 128, 8_192
     kind, loss = ModelKind.LSTM_NORMAL, LOSS_WARP
@@ -1318,31 +1271,11 @@ def test_bench_regime_two_devices_whole_step_full_parity():
     o = OracleModel(hparams(items, T, d, int(kind), loss, epochs=1, B=B, ndev=world, rank=0))
     po = o.fit_begin(ptr, it)
     assert {p.epoch_prepare() for p in plans} == {po.epoch_prepare()}
-    chunk, dbytes = plans[0].chunk_bytes(), plans[0].dense_bytes()
-    u8 = dict(dtype=torch.uint8, device="cuda")
-    send = [torch.zeros(world * chunk, **u8) for _ in range(world)]
-    dense = [torch.zeros(dbytes, **u8) for _ in range(world)]
-    recv = torch.zeros(world * chunk, **u8)
-    own = [torch.zeros(chunk, **u8) for _ in range(world)]
-    rows = 0
-    for q in range(world):
-        rows += plans[q].minibatch_rows(0)
-        plans[q].step_local(0)
-        plans[q].step_scatter(0, send[q].data_ptr())
-        plans[q].step_dense(dense[q].data_ptr())
-        models[q].synchronize()
+    ranks = SimulatedRanks(models, plans)
+    rows = sum(plans[q].minibatch_rows(0) for q in range(world))
     assert rows > 900_000
-    for q in range(world):  # all_to_all_single
-        for src in range(world):
-            recv[src * chunk:(src + 1) * chunk] = send[src][q * chunk:(q + 1) * chunk]
-        torch.cuda.synchronize()
-        plans[q].step_owner_reduce(recv.data_ptr(), own[q].data_ptr())
-        models[q].synchronize()
-    table, dense_all = torch.cat(own), torch.cat(dense)  # all_gather_into_tensor
-    torch.cuda.synchronize()
-    for q in range(world):
-        plans[q].step_apply_table(table.data_ptr(), dense_all.data_ptr())
-        models[q].synchronize()
+    ranks.step(0, exchange)
+    ranks.finish()
     po.step(0)
     lo, eo = po.end()
     for q in range(world):

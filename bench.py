@@ -503,7 +503,8 @@ def group_driver(args, model_kind, loss_kind):
         t1 = time.perf_counter()
         q1, s1, _ = gp.stats()
         gp.close()  # (gathers the owners' optimiser-state slices back onto every replica)
-        return {"host_threads": nth, "exchange": "gradient all-gather" if gradient else "owner-applied", "ms_per_step": 1e3 * (t1 - t0) / args.steps, "host_enqueue_ms_per_step": (q1 - q0) / max(s1 - s0, 1),
+        return {"host_threads": nth, "exchange": ("partitioned table: owner-computes over gradient lists" if args.partition_table else "staleness-one pipeline (gradient all-gather)"
+                                                  if args.parallelism == "async" else "gradient all-gather" if gradient else "owner-applied"), "ms_per_step": 1e3 * (t1 - t0) / args.steps, "host_enqueue_ms_per_step": (q1 - q0) / max(s1 - s0, 1),
                 "host_loop_ms_per_step": 1e3 * (t_queued - t0) / args.steps, "interactions_per_s": rows / (t1 - t0), "interactions_timed": rows}
 
     default = run(None)

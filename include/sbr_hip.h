@@ -261,7 +261,8 @@ sbr_status sbr_device_count(int32_t* out_count);
  * sbr_group_fit IS this sequence over hp.num_epochs epochs.  (≙ the loop of sequence_model.rs:100-171 with num_threads(n).)
  *   sbr_group_epoch_prepare   every replica's sbr_fit_epoch_prepare (prefetch_next != 0: the next epoch is packed in the background)
  *   sbr_group_step            one optimiser step of the whole group (Synchronous / partitioned / the staleness-one pipeline);
- *                             returns when it is QUEUED on the devices' streams (a partitioned step includes its rendezvous)
+ *                             returns when it is QUEUED on the devices' streams (a partitioned step too since round 6: its owners
+ *                             wait for the devices' events on their streams and read the owner bounds on the device)
  *   sbr_group_step_local      parity access: only the local halves of `minibatch` (forward, scoring, BPTT on every replica); the
  *                             next sbr_group_step(minibatch) then runs the exchange and the update alone.  Not for Asynchronous.
  *   sbr_group_member_plan     replica r's plan, borrowed (sbr_fit_debug_fetch, sbr_fit_minibatch_rows, sbr_fit_counters)
@@ -315,7 +316,7 @@ sbr_status sbr_model_is_partitioned(const sbr_model* m, int32_t* out);
  *   sbr_fit_lists_export / _import   once per plan: the ranks' gradient lists become readable by their peers
  *   per step: sbr_fit_step_local -> sbr_fit_step_reduce_own (returns this rank's owner bounds; stream
  *   drained) -> all-gather of the bounds and of the dense blocks -> sbr_fit_step_owner_apply (stream
- *   drained) -> barrier.
+ *   drained) -> barrier;  or, nothing drained, the *_queued forms below.
  * Same bits as sbr_group_fit over a partitioned group and as the replicated Synchronous exchange. */
 /* Peer transport of the REPLICATED exchange (one process per GPU): every rank exports its send buffer and
  * its reduced own chunk once; the owner-reduce and table-update kernels then read the peers' buffers in
@@ -339,6 +340,14 @@ sbr_status sbr_fit_lists_export(sbr_fit_plan* p, int32_t out_fds[4], uint64_t ou
 sbr_status sbr_fit_lists_import(sbr_fit_plan* p, uint32_t peer_rank, const int32_t fds[4], const uint64_t bytes[4]);
 sbr_status sbr_fit_step_reduce_own(sbr_fit_plan* p, uint64_t minibatch, uint32_t* host_bounds, void* device_dense_out);
 sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds, const void* device_dense_all);
+/* The same two halves WITHOUT the host in the loop (round 6), for hosts whose collectives run on the device (RCCL): nothing is
+ * drained and nothing is read back.  reduce_own_queued leaves this rank's owner bounds (num_devices + 1 u32) on the device and
+ * returns their address; the host all-gathers the ranks' bounds and dense blocks with DEVICE collectives on the model's stream (a
+ * collective completes on a rank only after every rank's contribution: every rank has finished reading the table); the owner
+ * builds its merge plan from the gathered bounds on the device (rank r's bounds at r * (num_devices + 1) words) and updates its
+ * rows; a last small device collective keeps the next step's reads behind every owner's writes.  Same bits. */
+sbr_status sbr_fit_step_reduce_own_queued(sbr_fit_plan* p, uint64_t minibatch, void** out_device_bounds, void* device_dense_out);
+sbr_status sbr_fit_step_owner_apply_queued(sbr_fit_plan* p, const void* device_all_bounds, const void* device_dense_all);
 
 /* The rendezvous of a step through RCCL INSIDE the library — for hosts that run one process per GPU and have no collective library
  * of their own (≙ the synchronised optimiser step of sequence_model.rs:92, 163-166 across processes; xGMI within a node).  librccl

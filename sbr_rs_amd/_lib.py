@@ -117,6 +117,8 @@ def load():
         "sbr_fit_lists_import": [vp, C.c_uint32, C.POINTER(C.c_int32), u64p],
         "sbr_fit_step_reduce_own": [vp, C.c_uint64, u32p, vp],
         "sbr_fit_step_owner_apply": [vp, u32p, vp],
+        "sbr_fit_step_reduce_own_queued": [vp, C.c_uint64, C.POINTER(vp), vp],
+        "sbr_fit_step_owner_apply_queued": [vp, vp, vp],
         "sbr_selftest_math": [vp, C.c_uint64, vp, vp, vp],
         "sbr_selftest_dot_tree": [vp, vp, C.c_uint32, C.c_uint64, vp],
         "sbr_selftest_mfma": [vp, vp, vp, C.c_uint32, vp, vp, vp, vp],
@@ -163,4 +165,5 @@ DECLARED_SYMBOLS = [
     "sbr_fit_steps", "sbr_comm_unique_id", "sbr_comm_create", "sbr_comm_destroy", "sbr_fit_step_exchange", "sbr_model_fit_comm", "sbr_model_set_reference_order", "sbr_fit_block_bytes", "sbr_fit_step_apply_blocks_in_order", "sbr_model_set_step_fusion", "sbr_fit_debug_phase_clocks", "sbr_group_synchronize", "sbr_group_plan_set_host_threads", "sbr_group_plan_stats", "sbr_group_fit_end", "sbr_group_plan_destroy",
     "sbr_fit_step_owner_update", "sbr_model_table_slice", "sbr_model_optimizer_state_gathered", "sbr_model_optimizer_state_is_partial",
     "sbr_group_plan_set_exchange", "sbr_group_gather_optimizer_state", "sbr_comm_gather_optimizer_state",
+    "sbr_fit_step_reduce_own_queued", "sbr_fit_step_owner_apply_queued",
 ]

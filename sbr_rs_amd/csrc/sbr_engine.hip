@@ -688,6 +688,8 @@ struct sbr_fit_plan {
     void* msort_temp = nullptr;
     size_t msort_temp_bytes = 0;
     uint64_t mcap = 0;
+    sbr::MergePlan* mplan = nullptr;  /* where this owner's row range lies in every device's sorted keys: on the DEVICE (merge_plan_kernel) */
+    uint32_t* all_bounds_dev = nullptr; /* one process per GPU: the ranks' owner bounds, gathered on the device by the host's collective */
     /* last step (debug) */
     int last_R = 0;
     const void* last_block = nullptr;
@@ -1315,7 +1317,7 @@ void sbr_fit_plan_destroy(sbr_fit_plan* p) {
     dfree(p->seg.P); dfree(p->seg.Pb); dfree(p->seg.Pf);
     dfree(p->seg.head_pos); dfree(p->seg.nheads);
     dfree(p->glist); dfree(p->gblist); dfree(p->gfl); dfree(p->bounds_dev);
-    dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp);
+    dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp); dfree(p->mplan); dfree(p->all_bounds_dev);
     delete p;
 }
 
@@ -2114,19 +2116,21 @@ static sbr_status partition_buffers(sbr_fit_plan* p) {
     return SBR_OK;
 }
 
-static sbr_status merge_capacity(sbr_fit_plan* p, uint64_t total) {
-    if (total <= p->mcap) return SBR_OK;
-    sbr_model* m = p->m;
-    HIPCHK(hipStreamSynchronize(m->stream));
-    dfree(p->mkeys); dfree(p->mkeys_sorted); dfree(p->msort_temp);
-    p->mkeys = p->mkeys_sorted = nullptr; p->msort_temp = nullptr; p->mcap = 0;
-    const uint64_t cap = total + total / 4 + 1024;
+/* The owner's merge buffers.  Since round 6 the number of merge keys of a step — the key positions of all devices inside this
+ * owner's row range — is known on the device only (the host no longer reads the owner bounds back: that read drained every queue
+ * every step), so the buffers hold the worst case, every entry of every device: ndev x 3 x rmax keys (2 x 8 B each + the radix
+ * counters: 0.2 GB per owner at configs[4]'s 8 x 8 192 sequences of <= 63 steps).  Allocated at the first partitioned step. */
+static sbr_status merge_capacity(sbr_fit_plan* p) {
+    if (p->mcap) return SBR_OK;
+    const uint64_t cap = (uint64_t)p->ndev * 3ull * p->rmax;
+    if (cap >= (1ull << 32)) return SBR_ERR_UNSUPPORTED;
     SBRCHK(dmalloc(&p->mkeys, cap));
     SBRCHK(dmalloc(&p->mkeys_sorted, cap));
     p->msort_temp_bytes = sbr::sparse_sort_temp_bytes(cap, 64);
     uint8_t* tmp = nullptr;
     SBRCHK(dmalloc(&tmp, p->msort_temp_bytes));
     p->msort_temp = tmp;
+    SBRCHK(dmalloc(&p->mplan, 1));
     p->mcap = cap;
     return SBR_OK;
 }
@@ -2148,15 +2152,16 @@ static sbr_status partition_reduce_own(sbr_fit_plan* p, uint64_t minibatch) {
     return SBR_OK;
 }
 
-/* owner side: merge the peers' lists over this device's row range (device order) and update its rows */
-static sbr_status partition_owner_apply(sbr_fit_plan* p, const sbr::PeerLists& pl, uint32_t total) {
+/* owner side: merge the peers' lists over this device's row range (device order) and update its rows; the range's position in the
+ * peers' lists comes from their owner bounds ON THE DEVICE (pb: peer-readable arrays, or one gathered array) */
+static sbr_status partition_owner_apply(sbr_fit_plan* p, const sbr::PeerLists& pl, const sbr::PeerBounds& pb) {
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
-    SBRCHK(merge_capacity(p, total));
+    SBRCHK(merge_capacity(p));
     {
         ScopedTimer t(m, SBR_K_SPARSE_UPDATE, 1);
-        sbr::launch_owner_list_apply(m->mv, pl, p->ndev, total, p->mkeys, p->mkeys_sorted, p->msort_temp, p->msort_temp_bytes,
-                                     m->stream);
+        sbr::launch_owner_list_apply(m->mv, pl, pb, p->ndev, p->rank, p->mplan, (uint32_t)p->mcap, p->mkeys, p->mkeys_sorted, p->msort_temp,
+                                     p->msort_temp_bytes, m->stream);
     }
     HIPCHK(hipGetLastError());
     return SBR_OK;
@@ -2557,31 +2562,56 @@ sbr_status sbr_fit_step_reduce_own(sbr_fit_plan* p, uint64_t minibatch, uint32_t
     return SBR_OK;
 }
 
+/* the same half WITHOUT the host in the loop: nothing is drained, the owner bounds stay on the device (*out_device_bounds:
+ * num_devices + 1 u32 of this rank, for the host's DEVICE all-gather) */
+sbr_status sbr_fit_step_reduce_own_queued(sbr_fit_plan* p, uint64_t minibatch, void** out_device_bounds, void* device_dense_out) {
+    if (!p || !out_device_bounds || !device_dense_out || !p->m->shared || minibatch >= p->ep[p->cur].num_mb) return SBR_ERR_INVALID_ARGUMENT;
+    SBRCHK(partition_reduce_own(p, minibatch));
+    SBRCHK(sbr_fit_step_dense(p, device_dense_out));
+    *out_device_bounds = p->bounds_dev;
+    return SBR_OK;
+}
+
+static sbr_status owner_apply_lists(sbr_fit_plan* p, sbr::PeerLists* pl) {
+    const int n = p->ndev, q = p->rank;
+    std::memset(pl, 0, sizeof(*pl));
+    for (int r = 0; r < n; ++r) {
+        if (r == q) {
+            pl->keys[r] = p->keys_sorted; pl->G[r] = p->glist; pl->gb[r] = p->gblist; pl->fl[r] = p->gfl;
+        } else {
+            if (p->peer_x.empty() || !p->peer_x[r][0].ptr) return SBR_ERR_INVALID_ARGUMENT; /* lists of rank r not imported */
+            pl->keys[r] = reinterpret_cast<const uint64_t*>(p->peer_x[r][0].ptr);
+            pl->G[r] = reinterpret_cast<const float*>(p->peer_x[r][1].ptr);
+            pl->gb[r] = reinterpret_cast<const float*>(p->peer_x[r][2].ptr);
+            pl->fl[r] = reinterpret_cast<const uint32_t*>(p->peer_x[r][3].ptr);
+        }
+    }
+    return SBR_OK;
+}
+
+/* device_all_bounds: the ranks' owner bounds gathered ON THE DEVICE, rank r's num_devices + 1 words at r * (num_devices + 1);
+ * queued, nothing drained */
+sbr_status sbr_fit_step_owner_apply_queued(sbr_fit_plan* p, const void* device_all_bounds, const void* device_dense_all) {
+    if (!p || !device_all_bounds || !device_dense_all || !p->exportable_lists) return SBR_ERR_INVALID_ARGUMENT;
+    sbr_model* m = p->m;
+    SBRCHK(ensure_device(m));
+    sbr::PeerLists pl;
+    SBRCHK(owner_apply_lists(p, &pl));
+    sbr::PeerBounds pb;
+    for (int r = 0; r < 16; ++r)
+        pb.b[r] = r < p->ndev ? reinterpret_cast<const uint32_t*>(device_all_bounds) + (size_t)r * (p->ndev + 1) : nullptr;
+    SBRCHK(apply_dense_blocks(p, device_dense_all));
+    return partition_owner_apply(p, pl, pb);
+}
+
 sbr_status sbr_fit_step_owner_apply(sbr_fit_plan* p, const uint32_t* all_bounds, const void* device_dense_all) {
     if (!p || !all_bounds || !device_dense_all || !p->exportable_lists) return SBR_ERR_INVALID_ARGUMENT;
     sbr_model* m = p->m;
     SBRCHK(ensure_device(m));
-    const int n = p->ndev, q = p->rank;
-    sbr::PeerLists pl;
-    std::memset(&pl, 0, sizeof(pl));
-    uint32_t total = 0;
-    for (int r = 0; r < n; ++r) {
-        if (r == q) {
-            pl.keys[r] = p->keys_sorted; pl.G[r] = p->glist; pl.gb[r] = p->gblist; pl.fl[r] = p->gfl;
-        } else {
-            if (p->peer_x.empty() || !p->peer_x[r][0].ptr) return SBR_ERR_INVALID_ARGUMENT; /* lists of rank r not imported */
-            pl.keys[r] = reinterpret_cast<const uint64_t*>(p->peer_x[r][0].ptr);
-            pl.G[r] = reinterpret_cast<const float*>(p->peer_x[r][1].ptr);
-            pl.gb[r] = reinterpret_cast<const float*>(p->peer_x[r][2].ptr);
-            pl.fl[r] = reinterpret_cast<const uint32_t*>(p->peer_x[r][3].ptr);
-        }
-        pl.lo[r] = all_bounds[(size_t)r * (n + 1) + q];
-        pl.base[r] = total;
-        total += all_bounds[(size_t)r * (n + 1) + q + 1] - pl.lo[r];
-    }
-    for (int r = n; r <= 16; ++r) pl.base[r] = total;
-    SBRCHK(apply_dense_blocks(p, device_dense_all));
-    SBRCHK(partition_owner_apply(p, pl, total));
+    const size_t words = (size_t)p->ndev * (p->ndev + 1);
+    if (!p->all_bounds_dev) SBRCHK(dmalloc(&p->all_bounds_dev, 17 * 16));
+    HIPCHK(hipMemcpyAsync(p->all_bounds_dev, all_bounds, words * sizeof(uint32_t), hipMemcpyHostToDevice, m->stream));
+    SBRCHK(sbr_fit_step_owner_apply_queued(p, p->all_bounds_dev, device_dense_all));
     HIPCHK(hipStreamSynchronize(m->stream));
     return SBR_OK;
 }
@@ -2685,7 +2715,6 @@ struct sbr_group_plan {
     uint32_t epochs_prepared = 0;
     int64_t local_done = -1;         /* minibatch whose local half sbr_group_step_local has queued (parity access), or -1 */
     int64_t async_local_done = -1;   /* Asynchronous: minibatch whose local half the pipeline has queued ahead */
-    std::vector<uint32_t> hbounds;
     std::unique_ptr<PhaseWorkers> workers;
     double enqueue_ms = 0.0;         /* host time spent inside sbr_group_step (queueing; a partitioned step includes its rendezvous) */
     uint64_t steps = 0;
@@ -2825,9 +2854,10 @@ struct sbr_group_plan {
         return SBR_OK;
     }
     /* Partitioned item table: every row is stored once (on its owner) and read by everybody through the shared mapping.  A step:
-     * all devices compute on the current table; each reduces its own entries into a list; after a host-side rendezvous (the
-     * owners need the list bounds to size their merge, and nobody may still be READING the table) every owner merges the peers'
-     * lists over its rows in device order and updates them in place.  Bitwise the replicated Synchronous exchange. */
+     * all devices compute on the current table; each reduces its own entries into a list and binary-searches its owner bounds;
+     * every owner then waits — on its stream, through the devices' events — until nobody is READING the table any more, builds
+     * its merge plan from the peers' bounds on the device, merges the peers' lists over its rows in device order and updates them in
+     * place.  Bitwise the replicated Synchronous exchange.  Nothing of a step waits for the host. */
     sbr_status partitioned_step(uint64_t mb) {
         const bool have_local = local_done == (int64_t)mb;
         SBRCHK(phase([&](uint32_t r) -> sbr_status {
@@ -2835,27 +2865,28 @@ struct sbr_group_plan {
             SBRCHK(ensure_device(models[r]));
             SBRCHK(partition_reduce_own(dev[r].plan, mb));
             SBRCHK(sbr_fit_step_dense(dev[r].plan, dev[r].dense));
-            HIPCHK(hipStreamSynchronize(models[r]->stream));
-            HIPCHK(hipMemcpy(&hbounds[(size_t)r * (n + 1)], dev[r].plan->bounds_dev, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            /* `scattered`: device r has finished READING the table, its list, owner bounds and dense block are complete — what the
+             * owners wait for, on their own streams; the host reads nothing back and drains nothing (until round 5: a stream
+             * synchronise + a blocking copy of the bounds per device and step, 0.96 of the step's time on the host) */
+            HIPCHK(hipEventRecord(dev[r].scattered, models[r]->stream));
             return SBR_OK;
         }));
         SBRCHK(phase([&](uint32_t q) -> sbr_status {
             SBRCHK(ensure_device(models[q]));
             sbr::PeerLists pl;
+            sbr::PeerBounds pb;
             std::memset(&pl, 0, sizeof(pl));
-            uint32_t total = 0;
+            for (uint32_t r = 0; r < 16; ++r) pb.b[r] = nullptr;
             for (uint32_t r = 0; r < n; ++r) {
                 const sbr_fit_plan* pr = dev[r].plan;
                 pl.keys[r] = pr->keys_sorted; pl.G[r] = pr->glist; pl.gb[r] = pr->gblist; pl.fl[r] = pr->gfl;
-                pl.lo[r] = hbounds[(size_t)r * (n + 1) + q];
-                pl.base[r] = total;
-                total += hbounds[(size_t)r * (n + 1) + q + 1] - pl.lo[r];
+                pb.b[r] = pr->bounds_dev; /* read in place by merge_plan_kernel (peer-readable like the lists) */
+                if (r != q) HIPCHK(hipStreamWaitEvent(models[q]->stream, dev[r].scattered, 0));
             }
-            for (uint32_t r = n; r <= 16; ++r) pl.base[r] = total;
             for (uint32_t r = 0; r < n; ++r)
                 HIPCHK(hipMemcpyAsync(dev[q].dense_all + r * db, dev[r].dense, db, hipMemcpyDefault, models[q]->stream));
             SBRCHK(apply_dense_blocks(dev[q].plan, dev[q].dense_all));
-            SBRCHK(partition_owner_apply(dev[q].plan, pl, total));
+            SBRCHK(partition_owner_apply(dev[q].plan, pl, pb));
             HIPCHK(hipEventRecord(dev[q].applied, models[q]->stream));
             return SBR_OK;
         }));
@@ -2911,7 +2942,6 @@ struct sbr_group_plan {
         n = count;
         models.assign(ms, ms + count);
         dev.resize(n);
-        hbounds.assign((size_t)n * (n + 1), 0);
         partitioned = models[0]->shared != nullptr;
         /* a partitioned table is updated in place by its owners after a rendezvous, so there is no staleness-one pipeline for
          * it: Parallelism::Asynchronous runs the synchronous step there (same everywhere a partitioned table is driven) */

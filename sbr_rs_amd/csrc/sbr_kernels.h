@@ -112,14 +112,23 @@ struct SegScratch {
  * (disjoint table rows). */
 void launch_seg_prelist(const SegScratch& sc, hipStream_t s);
 
+/* where the owner's row range lies in every device's sorted keys — DEVICE-resident, written by merge_plan_kernel from the devices'
+ * owner bounds (round 6: the host no longer reads the bounds back, so a partitioned step is queued without a host rendezvous) */
+struct MergePlan {
+    uint32_t lo[16];   /* first position of the owner's row range in device r's sorted keys */
+    uint32_t base[17]; /* exclusive prefix sum of the range lengths; base[16] = their total */
+};
 /* the devices' gradient lists as the owner of a row range sees them (device pointers, peer-readable) */
 struct PeerLists {
     const uint64_t* keys[16];
     const float* G[16];
     const float* gb[16];
     const uint32_t* fl[16];
-    uint32_t lo[16];   /* first position of the owner's row range in device r's sorted keys */
-    uint32_t base[17]; /* exclusive prefix sum of the range lengths */
+    const MergePlan* plan; /* on the owner's device */
+};
+/* device r's owner bounds [ndev + 1] (owner_bounds_kernel), peer-readable or gathered */
+struct PeerBounds {
+    const uint32_t* b[16];
 };
 
 /* recurrent forward over all steps of the minibatch (LSTM d <= 128: one sequence-resident launch; d = 256: one launch per step) */
@@ -246,8 +255,8 @@ void launch_table_apply(const ModelView& m, const ChunkPtrs& table, uint64_t sli
 void launch_owner_update(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, uint64_t row0, uint64_t nrows, hipStream_t s);
 /* partitioned item table: the owner merges the peers' lists (read through peer mappings) in device order
  * and updates its rows */
-void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
-                             uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
+void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, const PeerBounds& pb, int ndev, int owner, MergePlan* plan,
+                             uint32_t capacity, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s);
 /* accumulate loss/examples headers of all blocks into the plan accumulators */
 /* owner side of the partitioned table: (row, device, position) keys of the peers' list heads in that order
  * (generated in (device, position) order, so again a stable sort on the row bits) */

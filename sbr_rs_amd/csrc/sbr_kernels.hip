@@ -2831,13 +2831,32 @@ __global__ void owner_bounds_kernel(const uint64_t* keys, uint32_t n, int ndev, 
     bounds[q] = q == ndev ? n : lo;
 }
 
+// where owner q's row range lies in every device's sorted keys, from the devices' owner bounds — on the device (one thread)
+__global__ void merge_plan_kernel(PeerBounds pb, int ndev, int q, MergePlan* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t total = 0;
+    for (int r = 0; r < 16; ++r) {
+        if (r < ndev) {
+            const uint32_t lo = pb.b[r][q], hi = pb.b[r][q + 1];
+            out->lo[r] = lo;
+            out->base[r] = total;
+            total += hi - lo;
+        } else {
+            out->lo[r] = 0;
+            out->base[r] = total;
+        }
+    }
+    out->base[16] = total;
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, PeerLists pl, const uint64_t* mkeys, uint64_t n) {
+__global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, PeerLists pl, const uint64_t* mkeys) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t n = pl.plan->base[16];  /* merge keys of this step (grid-stride: the launch does not depend on it) */
     for (uint64_t i = wave * GPW + grp; i < n; i += nwaves * GPW) {
         const uint64_t key = mkeys[i];
         if (key == ~0ull) continue; /* padding sorts to the end */
@@ -3604,13 +3623,20 @@ void launch_seg_list(const ModelView& m, const BlockView& blk, uint32_t rows_hos
     hipLaunchKernelGGL(owner_bounds_kernel, dim3(1), dim3(64), 0, s, keys_sorted, (uint32_t)(3ull * rows_host), ndev, slice_rows, bounds);
 }
 
-void launch_owner_list_apply(const ModelView& m, const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys,
-                             uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
-    if (total == 0) return;
-    launch_merge_sort(pl, ndev, total, mkeys, mkeys_sorted, sort_temp, sort_temp_bytes, s);  /* (row, device, position) order */
+void launch_owner_list_apply(const ModelView& m, const PeerLists& pl_in, const PeerBounds& pb, int ndev, int owner, MergePlan* plan,
+                             uint32_t capacity, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp, size_t sort_temp_bytes, hipStream_t s) {
+    if (capacity == 0) return;
+    PeerLists pl = pl_in;
+    pl.plan = plan;
+    hipLaunchKernelGGL(merge_plan_kernel, dim3(1), dim3(64), 0, s, pb, ndev, owner, plan);
+    launch_merge_sort(pl, ndev, capacity, mkeys, mkeys_sorted, sort_temp, sort_temp_bytes, s);  /* (row, device, position) order */
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((owner_list_apply_kernel<DD>), dim3(grid_for_groups((long long)total, gpb)), dim3(256), 0, s, m, pl, mkeys_sorted, (uint64_t)total);
+        /* grid-stride over the merge keys, whose number only the device knows: as many lane groups as the capacity would take, at
+         * most 2 048 workgroups */
+        int grid = grid_for_groups((long long)capacity, gpb);
+        if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL((owner_list_apply_kernel<DD>), dim3(grid), dim3(256), 0, s, m, pl, mkeys_sorted);
     });
 }
 

@@ -99,13 +99,14 @@ struct SrcRows {  // self-test: entry e of a plain row array
     const uint32_t* rows;
     __device__ __forceinline__ uint64_t operator()(uint32_t e) const { return ((uint64_t)rows[e] << 32) | e; }
 };
-struct SrcMerge {  // partitioned table: (row, device, position) of every list head in the owner's row range
-    PeerLists pl;
+struct SrcMerge {  // partitioned table: (row, device, position) of every list head in the owner's row range; where that range
+    PeerLists pl;   // lies in every device's sorted keys is DEVICE-resident (merge_plan_kernel): the host never learns it
     int ndev;
     __device__ __forceinline__ uint64_t operator()(uint32_t i) const {
+        const MergePlan& mp = *pl.plan;
         int r = 0;
-        while (r + 1 < ndev && i >= pl.base[r + 1]) ++r;
-        const uint32_t p = pl.lo[r] + (i - pl.base[r]);
+        while (r + 1 < ndev && i >= mp.base[r + 1]) ++r;
+        const uint32_t p = mp.lo[r] + (i - mp.base[r]);
         return (pl.fl[r][p] & 1u) ? ((pl.keys[r][p] >> 32) << 32) | ((uint64_t)r << 28) | (uint64_t)p : ~0ull;
     }
 };
@@ -127,8 +128,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 // ---- one radix pass ----------------------------------------------------------------------------
 template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
-                                                                     uint32_t* __restrict__ counts) {
+                                                                     uint32_t* __restrict__ counts, const uint32_t* __restrict__ n_dev) {
     SORT_PRIO();
+    if (n_dev) {  // the key count lives on the device (the launch is sized for the capacity): surplus workgroups leave at once
+        n = *n_dev;
+        ntiles = (uint32_t)(((uint64_t)n + 64 * ITEMS - 1) / (64 * ITEMS));
+        if (blockIdx.x * SORT_WAVES >= ntiles) return;
+    }
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
@@ -157,8 +163,9 @@ __global__ __launch_bounds__(SORT_WAVES * 64) void radix_hist_kernel(Src src, ui
 
 // one wave per bin: exclusive scan of the bin's tile counts (in place) and the bin total
 __global__ __launch_bounds__(256) void radix_binscan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t nb,
-                                                            uint32_t* __restrict__ bintotal) {
+                                                            uint32_t* __restrict__ bintotal, const uint32_t* __restrict__ n_dev, int items) {
     SORT_PRIO();
+    if (n_dev) ntiles = (uint32_t)(((uint64_t)*n_dev + 64 * (uint64_t)items - 1) / (64 * (uint64_t)items));
     const int lane = threadIdx.x & 63;
     const uint32_t bin = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (bin >= nb) return;
@@ -186,8 +193,14 @@ __global__ __launch_bounds__(256) void radix_binscan_kernel(uint32_t* __restrict
 template <class Src, int ITEMS>
 __global__ __launch_bounds__(SORT_WAVES * 64) void radix_scatter_kernel(Src src, uint32_t n, int shift, int digit_bits, uint32_t ntiles,
                                                                         const uint32_t* __restrict__ counts,
-                                                                        const uint32_t* __restrict__ bintotal, uint64_t* __restrict__ out) {
+                                                                        const uint32_t* __restrict__ bintotal, uint64_t* __restrict__ out,
+                                                                        const uint32_t* __restrict__ n_dev) {
     SORT_PRIO();
+    if (n_dev) {
+        n = *n_dev;
+        ntiles = (uint32_t)(((uint64_t)n + 64 * ITEMS - 1) / (64 * ITEMS));
+        if (blockIdx.x * SORT_WAVES >= ntiles) return;
+    }
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nb = 1u << digit_bits, mask = nb - 1u;
@@ -420,8 +433,10 @@ inline Scratch carve(void* temp, size_t max_entries, int row_bits) {
 
 // stable sort of n generated keys by their row bits: first pass from `first`, later passes between the two buffers,
 // the last pass always writes `out`
+// n_dev != null: `n` is the CAPACITY the launches are sized for and the key count is read from device memory by every kernel
 template <class Src, int ITEMS>
-void radix_sort_tiles(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
+void radix_sort_tiles(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s,
+                      const uint32_t* n_dev = nullptr) {
     const PassPlan pp = plan_passes(row_bits);
     const uint32_t ntiles = tiles_of(n, ITEMS), nb = 1u << pp.digit_bits;
     const unsigned grid = (ntiles + SORT_WAVES - 1) / SORT_WAVES;
@@ -431,27 +446,28 @@ void radix_sort_tiles(const Src& first, uint32_t n, int row_bits, uint64_t* tmp,
         uint64_t* dst = ((pp.passes - 1 - p) & 1) ? tmp : out;
         const uint64_t* from = dst == out ? tmp : out;
         if (p == 0) {
-            hipLaunchKernelGGL((radix_hist_kernel<Src, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts);
+            hipLaunchKernelGGL((radix_hist_kernel<Src, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts, n_dev);
         } else {
             hipLaunchKernelGGL((radix_hist_kernel<SrcKeys, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
-                               sc.counts);
+                               sc.counts, n_dev);
         }
-        hipLaunchKernelGGL(radix_binscan_kernel, dim3((nb * 64 + 255) / 256), dim3(256), 0, s, sc.counts, ntiles, nb, sc.bintotal);
+        hipLaunchKernelGGL(radix_binscan_kernel, dim3((nb * 64 + 255) / 256), dim3(256), 0, s, sc.counts, ntiles, nb, sc.bintotal, n_dev, ITEMS);
         if (p == 0) {
             hipLaunchKernelGGL((radix_scatter_kernel<Src, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, first, n, shift, pp.digit_bits, ntiles, sc.counts,
-                               sc.bintotal, dst);
+                               sc.bintotal, dst, n_dev);
         } else {
             hipLaunchKernelGGL((radix_scatter_kernel<SrcKeys, ITEMS>), dim3(grid), dim3(SORT_WAVES * 64), lds, s, SrcKeys{from}, n, shift, pp.digit_bits, ntiles,
-                               sc.counts, sc.bintotal, dst);
+                               sc.counts, sc.bintotal, dst, n_dev);
         }
     }
 }
 // stable sort of n generated keys by their row bits: first pass from `first`, later passes between the two buffers,
 // the last pass always writes `out`
 template <class Src>
-void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s) {
-    if (items_of(n) == SORT_ITEMS_FINE) radix_sort_tiles<Src, SORT_ITEMS_FINE>(first, n, row_bits, tmp, out, sc, s);
-    else radix_sort_tiles<Src, SORT_ITEMS>(first, n, row_bits, tmp, out, sc, s);
+void radix_sort(const Src& first, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, const Scratch& sc, hipStream_t s,
+                const uint32_t* n_dev = nullptr) {
+    if (items_of(n) == SORT_ITEMS_FINE) radix_sort_tiles<Src, SORT_ITEMS_FINE>(first, n, row_bits, tmp, out, sc, s, n_dev);
+    else radix_sort_tiles<Src, SORT_ITEMS>(first, n, row_bits, tmp, out, sc, s, n_dev);
 }
 
 // keys in (row, entry) order + segment heads: one launch for small inputs, the tiled passes otherwise
@@ -514,11 +530,13 @@ void launch_own_sort(const BlockView& blk, uint32_t rows_host, uint64_t* keys, u
         sort_and_list(SrcBlock{blk.in_idx, blk.out_idx, blk.neg}, total, row_bits, keys, keys_sorted, scr, sc.head_pos, sc.nheads, s);
 }
 
-void launch_merge_sort(const PeerLists& pl, int ndev, uint32_t total, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp,
+// `capacity` keys at most; the count itself is pl.plan->base[16] on the device (merge_plan_kernel): launches sized for the
+// capacity, the tile granularity chosen by it as well (the scratch is carved for it)
+void launch_merge_sort(const PeerLists& pl, int ndev, uint32_t capacity, uint64_t* mkeys, uint64_t* mkeys_sorted, void* sort_temp,
                        size_t sort_temp_bytes, hipStream_t s) {
     (void)sort_temp_bytes;
-    if (total == 0) return;
-    radix_sort(SrcMerge{pl, ndev}, total, 32, mkeys, mkeys_sorted, carve(sort_temp, total, 32), s);
+    if (capacity == 0) return;
+    radix_sort(SrcMerge{pl, ndev}, capacity, 32, mkeys, mkeys_sorted, carve(sort_temp, capacity, 32), s, &pl.plan->base[16]);
 }
 
 void launch_selftest_sort(const uint32_t* rows, uint32_t n, int row_bits, uint64_t* tmp, uint64_t* out, void* temp, uint32_t* head_pos,

@@ -153,6 +153,9 @@ class PartitionedStepper:
         self.dense = torch.zeros(self.db, dtype=torch.uint8, device="cuda")
         self.dense_all = torch.zeros(self.world * self.db, dtype=torch.uint8, device="cuda")
         self.bounds = np.zeros(self.world + 1, dtype=np.uint32)
+        self.all_bounds = torch.zeros(self.world * (self.world + 1) * 4, dtype=torch.uint8, device="cuda")
+        self.token = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self._bounds_view = None
         self.num_minibatches = 0
 
     def begin_epoch(self, prefetch_next: bool = False) -> int:
@@ -161,8 +164,28 @@ class PartitionedStepper:
             self.plan.epoch_prefetch()
         return self.num_minibatches
 
+    def _step_queued(self, mb: int) -> None:
+        """Device collectives (RCCL): nothing of the step waits for the host.  The ranks' owner bounds and dense blocks are
+        all-gathered ON THE DEVICE — a collective completes on a rank only after every rank's contribution, i.e. after every rank
+        has finished READING the table — the owner builds its merge plan from the gathered bounds on the device, and a one-word
+        all-reduce behind the owners' updates keeps the next step's reads behind every owner's WRITES."""
+        from .distributed import device_bytes_as_tensor
+
+        torch, dist, L, plan = self.torch, self.dist, self.L, self.plan
+        plan.step_local(mb)
+        bptr = C.c_void_p()
+        _check(L.sbr_fit_step_reduce_own_queued(plan._h, mb, C.byref(bptr), C.c_void_p(self.dense.data_ptr())))
+        if self._bounds_view is None or self._bounds_view[0] != bptr.value:
+            self._bounds_view = (bptr.value, device_bytes_as_tensor(torch, bptr.value, (self.world + 1) * 4))
+        dist.all_gather_into_tensor(self.all_bounds, self._bounds_view[1], group=self.group)
+        dist.all_gather_into_tensor(self.dense_all, self.dense, group=self.group)
+        _check(L.sbr_fit_step_owner_apply_queued(plan._h, C.c_void_p(self.all_bounds.data_ptr()), C.c_void_p(self.dense_all.data_ptr())))
+        dist.all_reduce(self.token, group=self.group)  # every owner has finished WRITING its rows (ordered on the stream, not on the host)
+
     def step(self, mb: int) -> None:
         torch, dist, L, plan, world = self.torch, self.dist, self.L, self.plan, self.world
+        if not self.staged:
+            return self._step_queued(mb)
         plan.step_local(mb)
         _check(L.sbr_fit_step_reduce_own(plan._h, mb, self.bounds.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(self.dense.data_ptr())))
         # rendezvous: after these all-gathers every rank has finished READING the table

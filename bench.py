@@ -211,8 +211,35 @@ def cpu_baseline(args, model_kind=0, loss_kind=2):
                      f"each leg bounded by {args.cpu_seconds:.0f} s of wall time; C oracle",
            "single_thread_value": legs["single_thread"]["interactions_per_s"], "host_cores_available": cores, "legs": legs}
     del m
+    out["rust_toolchain"] = rust_toolchain_probe()
     if workload_label(args, 1).startswith("BASELINE.json configs[2]"):
         out["movielens_batch1"] = cpu_movielens_batch1(workers)
+    return out
+
+
+def rust_toolchain_probe():
+    """BASELINE.md section 2.2 "probe, do not assume": is there a Rust toolchain on THIS host?  The reference's CPU path is Rust +
+    rayon; where `cargo` exists and SBR_RS_CHECKOUT names a checkout of maciejkula/sbr-rs whose dependencies are already
+    fetched, its own Criterion bench (benches/benchmark.rs) is run (offline, bounded) and its output kept — that would be a
+    "reference" CPU figure.  Everywhere else the C port above stands in, and this says why."""
+    import shutil
+    import subprocess
+
+    cargo, rustc = shutil.which("cargo"), shutil.which("rustc")
+    out = {"cargo": cargo, "rustc": rustc, "status": "present" if cargo and rustc else "absent"}
+    if not (cargo and rustc):
+        out["consequence"] = "cpu_baseline.kind stays \"port\" (the C oracle); integration/rust_check/ is the comparison kit for a host that has cargo"
+        return out
+    src = os.environ.get("SBR_RS_CHECKOUT")
+    if not src or not os.path.exists(os.path.join(src, "Cargo.toml")):
+        out["consequence"] = "toolchain present but no crate checkout (SBR_RS_CHECKOUT unset; no network here): cargo bench not run"
+        return out
+    try:
+        res = subprocess.run([cargo, "bench", "--offline", "--bench", "benchmark"], cwd=src, capture_output=True, text=True, timeout=900)
+        out["cargo_bench_rc"] = res.returncode
+        out["cargo_bench_tail"] = (res.stdout + res.stderr)[-1500:]
+    except Exception as e:
+        out["cargo_bench_error"] = repr(e)
     return out
 
 

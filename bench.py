@@ -133,7 +133,7 @@ def live_traffic(kernel, warmup_dispatches, timed_dispatches, timeout_s=150):
     if not os.path.exists(rocprof):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from pmc_dispatches import per_dispatch
+    from pmc_dispatches import per_dispatch, step_window
 
     tmp = tempfile.mkdtemp(prefix="sbr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
@@ -151,7 +151,7 @@ def live_traffic(kernel, warmup_dispatches, timed_dispatches, timeout_s=150):
         argv.append(a)
     child = [sys.executable, os.path.abspath(__file__)] + argv + ["--traffic", "off", "--no-cpu-baseline", "--no-mrr", "--batch-sweep=",
                                                                   "--standalone-steps", "0", "--cold-items", "0"]
-    vals, line = {}, None
+    vals, line, step = {}, None, {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
@@ -163,6 +163,7 @@ def live_traffic(kernel, warmup_dispatches, timed_dispatches, timeout_s=150):
             # the timed region's dispatches only (the child goes on with the second, all-timers pass and the model keeps learning:
             # later launches try more negatives per row)
             vals[counter] = per_dispatch(dbs[0], counter, kernel)[warmup_dispatches:warmup_dispatches + timed_dispatches]
+            step[counter] = step_window(dbs[0], counter, kernel, warmup_dispatches, timed_dispatches)  # every kernel of the timed steps
             line = json.loads([x for x in res.stdout.splitlines() if x.startswith('{"metric"')][-1])
         n = min(len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"]))
         if n == 0 or not line or not line.get("roofline"):
@@ -170,7 +171,15 @@ def live_traffic(kernel, warmup_dispatches, timed_dispatches, timeout_s=150):
         f, w = sum(vals["FETCH_SIZE"][:n]) / n, sum(vals["WRITE_SIZE"][:n]) / n
         roof = line["roofline"]
         up = (2.0 * f + w) * 1024.0
-        return {"hbm_bytes_per_launch": up, "hbm_bytes_per_launch_lower": up - 64.0 * (1 + roof["mean_negatives_scored"]) * roof["rows_per_launch"],
+        whole = None
+        if step.get("FETCH_SIZE") and step.get("WRITE_SIZE"):
+            names = sorted(set(step["FETCH_SIZE"]) | set(step["WRITE_SIZE"]))
+            by = {k: (2.0 * step["FETCH_SIZE"].get(k, 0.0) + step["WRITE_SIZE"].get(k, 0.0)) * 1024.0 / timed_dispatches for k in names}
+            whole = {"hbm_bytes_per_step": sum(by.values()), "by_kernel": {k: v for k, v in sorted(by.items(), key=lambda kv: -kv[1]) if v >= 1e6},
+                     "read_bytes_per_step": sum(step["FETCH_SIZE"].values()) * 2048.0 / timed_dispatches,
+                     "written_bytes_per_step": sum(step["WRITE_SIZE"].values()) * 1024.0 / timed_dispatches,
+                     "what": "every dispatch between the first and the last timed dispatch of the roofline kernel, (2 F + W) x 1024 per step"}
+        return {"step": whole, "hbm_bytes_per_launch": up, "hbm_bytes_per_launch_lower": up - 64.0 * (1 + roof["mean_negatives_scored"]) * roof["rows_per_launch"],
                 "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "dispatches_averaged": n, "rows_per_launch": roof["rows_per_launch"],
                 "mean_negatives_scored": roof["mean_negatives_scored"], "kernel": kernel}
     except Exception:
@@ -988,13 +997,14 @@ def main():
             # runs) around the default bench command, the timed dispatches only, corrected per profiles/r03_counter_calibration.md;
             # printed only when this run's rows per launch and mean k are within 5 % of the profiled run's, else null
             traffic = traffic_lower = None
-            traffic_source = None
+            traffic_source = traffic_step = None
             pmc_kernel = "ewma_seq_kernel" if model_kind == 2 and loss_kind != 2 else "score_kernel" if loss_kind == 2 else "score_single_kernel"
             if args.traffic == "live" and world == 1 and not args.force_exchange:
                 lt = live_traffic(pmc_kernel, args.warmup, args.steps)
                 # the child's operating point must be this run's (same command line): rows per launch and negatives per row within 5 %
                 if lt and abs(lt["rows_per_launch"] / max(rows_per_launch, 1) - 1) <= 0.05 and abs(lt["mean_negatives_scored"] / max(k_mean, 1e-9) - 1) <= 0.05:
                     traffic, traffic_lower = lt["hbm_bytes_per_launch"], lt["hbm_bytes_per_launch_lower"]
+                    traffic_step = lt.get("step")
                     traffic_source = (f"measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) around a child run of "
                                       f"the same command line, the {lt['dispatches_averaged']} timed dispatches of {pmc_kernel}; FETCH_SIZE {lt['FETCH_SIZE_KiB_mean']:.0f} KiB, "
                                       f"WRITE_SIZE {lt['WRITE_SIZE_KiB_mean']:.0f} KiB per launch; bytes = (2 F + W) x 1024, lower figure = minus 64 B per bias read "
@@ -1008,7 +1018,7 @@ def main():
                      "score_single_kernel (gather + negative + loss, sbr_kernels.hip)")
             roofline = {"kernel": kname, "bound": "hbm",
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_lower": traffic_lower,
+                        "traffic": traffic, "traffic_lower": traffic_lower, "traffic_step": traffic_step,
                         "traffic_source": traffic_source, "traffic_over_algorithmic": [traffic_lower / bytes_per_launch, traffic / bytes_per_launch] if traffic else None,
                         "algorithmic_bytes_per_launch": bytes_per_launch,
                         "rows_per_launch": rows_per_launch, "mean_negatives_scored": k_mean,
@@ -1063,6 +1073,35 @@ def main():
                     tf = flops_per_row * rows_families / (kernels[fam]["ms_total"] * 1e-3) / 1e12
                     mfma.append({"kernel": fam, "what": what, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
                                  "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF})
+        # EWMA + single-negative loss (configs[4]'s step): a purely memory-bound step — its byte budget per optimiser step
+        # (profiles/r06_ewma_bytes.md) beside what the PMC counters saw over the same steps
+        step_bytes = None
+        if model_kind == 2 and loss_kind != 2 and world == 1 and sparse_entries and not args.partition_table:
+            R_, B_ = rows_per_launch, min(args.batch_sequences, args.users)
+            fwd = R_ * (2 * 4 * d + 4 * d + 8 + 12 + 24) + B_ * 4 * d          # target + negative rows, H written, biases, ids, result words; step 0's input
+            bwd = R_ * (4 * d + 4 * d + 12) + B_ * 4 * d                        # s_{t-1} read, dX written, ids / coefficient; the last target row
+            regather = R_ * 2 * 4 * d                                           # the backward scan's own gather of E[in], E[neg] (forward had them in registers)
+            upd = sparse_unique * (16 * d + 16) + sparse_entries * (4 * d + 12)  # distinct rows read-modify-written once, one source row per entry
+            srt = sparse_entries * 8 * 2 * 3                                    # three radix passes over 64-bit keys
+            step_s = elapsed / max(args.steps, 1)
+            necessary, two_pass, formula = fwd + bwd + upd + srt, fwd + bwd + regather + upd + srt, (12 * d + 8 + 36 * d + 24) * R_
+            step_bytes = {"rows_per_step": R_, "entries_per_step": sparse_entries, "distinct_rows_per_step": sparse_unique,
+                          "formula_8d": formula, "necessary": necessary, "two_pass": two_pass,
+                          "parts": {"scan_score": fwd, "backward_scan": bwd, "backward_regather": regather, "update": upd, "sort": srt},
+                          "frac_of_hbm_peak": {"formula_8d": formula / step_s / 1e9 / HBM_PEAK_GBS, "necessary": necessary / step_s / 1e9 / HBM_PEAK_GBS,
+                                               "two_pass": two_pass / step_s / 1e9 / HBM_PEAK_GBS},
+                          "what": ("necessary = scan + score (target and negative rows gathered, h written once) + backward scan (s_{t-1} read, dX written) + "
+                                   "update (distinct rows x (16d + 16) read-modify-written once + entries x (4d + 12) of gradient source and key) + three radix "
+                                   "passes; two_pass = necessary + the backward scan's own gather of E[in], E[neg] (8d per row: the rows the forward scan held in "
+                                   "registers; a sequence's rows do not stay on chip between the two scans at this size); formula_8d = SURVEY section 8d's "
+                                   "(2+k)4d + (1+k)4 + 36d + 24 per row, which prices no BPTT intermediate and no de-duplication")}
+            if roofline and roofline.get("traffic_step"):
+                ts = roofline["traffic_step"]
+                step_bytes["measured"] = ts["hbm_bytes_per_step"]
+                step_bytes["measured_over_necessary"] = ts["hbm_bytes_per_step"] / necessary
+                step_bytes["measured_rate_GBps"] = ts["hbm_bytes_per_step"] / step_s / 1e9
+                step_bytes["measured_rate_note"] = ("read + write traffic of every kernel of the step over the step's wall time; this device's ceilings for such a mix "
+                                                    "(tools/hbm_ceiling.hip, profiles/r02_hbm_ceiling.jsonl): copy 4.6 TB/s, random 1 KiB row read-modify-write 4.95, read-only gather 6.0-6.2")
         workload_tag = workload_label(args, world)
         out = {
             "metric": "train interactions/sec", "value": rows_total / elapsed, "unit": "interactions/s",
@@ -1081,7 +1120,7 @@ def main():
             "ms_per_step_per_rank": per_rank,
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
-            "roofline": roofline, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
+            "roofline": roofline, "step_bytes": step_bytes, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
             "kernels_source": ("HIP events on every family inside the timed region" if timers == "all" else
                                f"SCORE: HIP events inside the timed region; the other families: a second pass of {args.steps} steps of the same schedule "
                                "with every family bracketed (events cost the step 1.5-2 %, so the timed region brackets the roofline kernel only)"),

@@ -991,6 +991,12 @@ def main():
         roofline = None
         if score:
             bytes_per_row = (2 + k_mean) * 4 * d + (1 + k_mean) * 4
+            # EWMA + single-negative loss since round 6: the sequence's backward scan runs in the same launch (no RECURRENT_BWD family);
+            # the launch is then priced at the scan + score bytes plus the BPTT intermediates no decomposition avoids — h written,
+            # s_{t-1} read, dX written (3 x 4d) — and NOT at the backward scan's own gather of E[in], E[neg] (8d: `step_bytes.two_pass`)
+            ewma_whole = model_kind == 2 and loss_kind != 2 and "RECURRENT_BWD" not in kernels
+            if ewma_whole:
+                bytes_per_row += 12 * d
             bytes_per_launch = bytes_per_row * rows_per_launch
             achieved = bytes_per_launch / (score["ms_per_launch"] * 1e-3) / 1e9
             # HBM bytes per launch MEASURED for this very configuration: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
@@ -1012,7 +1018,9 @@ def main():
             if traffic is None and args.traffic != "off":
                 traffic, traffic_lower = measured_traffic("warm", rows_per_launch, k_mean, d, args.items)
                 traffic_source = "profiles/score_kernel_traffic.json (PMC passes of the same command at this operating point; interval: profiles/r03_counter_calibration.md)" if traffic else None
-            kname = ("ewma_seq_kernel (EWMA scan + gather + negative + loss in one pass per sequence; x_t replaces the h_t read, h_t is written "
+            kname = ("ewma_seq_kernel<D, WHOLE> (EWMA scan + gather + negative + loss + backward scan of a sequence in one pass; priced at "
+                     "(2+k)4d + (1+k)4 + 12d per row: section 8d's gather + score bytes, h written, s_{t-1} read, dX written; sbr_kernels.hip)" if ewma_whole else
+                     "ewma_seq_kernel (EWMA scan + gather + negative + loss in one pass per sequence; x_t replaces the h_t read, h_t is written "
                      "once on top of the priced bytes; sbr_kernels.hip)" if model_kind == 2 and loss_kind != 2 else
                      "score_kernel (gather + negative sampling + loss, sbr_kernels.hip)" if loss_kind == 2 else
                      "score_single_kernel (gather + negative + loss, sbr_kernels.hip)")

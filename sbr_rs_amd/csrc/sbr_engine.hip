@@ -192,7 +192,7 @@ void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<flo
 }
 
 #ifndef SBR_EWMA_FUSED_DEFAULT
-#define SBR_EWMA_FUSED_DEFAULT 1
+#define SBR_EWMA_FUSED_DEFAULT 2
 #endif
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 

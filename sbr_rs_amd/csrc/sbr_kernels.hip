@@ -63,6 +63,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SBR_BWD_RT4_MIN_TILES
 #define SBR_BWD_RT4_MIN_TILES 3000
 #endif
+#ifndef SBR_DW_LDS_PAD
+#define SBR_DW_LDS_PAD 0
+#endif
 #ifndef SBR_DW_WPE
 #define SBR_DW_WPE 4 /* waves per SIMD the dense-gradient kernel's register budget is set for (110 registers at 16-row slabs) */
 #endif
@@ -811,20 +814,15 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
     }
 }
 template <int D, bool WHOLE, bool TAIL = false>
-__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail) {
-#ifdef SBR_EWMA_WHOLE_GRID /* experiment (profiles/r06_ewma_bytes.md): the whole-sequence form on few enough waves that a sequence's rows are still cached for its backward scan */
-    if constexpr (WHOLE && !TAIL) {
-        const int cap = SBR_EWMA_WHOLE_GRID < (int)gridDim.x ? SBR_EWMA_WHOLE_GRID : (int)gridDim.x;
-        if ((int)blockIdx.x >= cap) {
-            if (threadIdx.x == 0) { w.part_loss[blockIdx.x] = 0.0; w.part_tries[blockIdx.x] = 0u; }
-            return;
-        }
-        ewma_seq_body<D, WHOLE, TAIL>(m, mb, blk, w, epoch_key, tail, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), (cap * (int)blockDim.x) >> 6, (int)blockIdx.x);
+__global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail, int active_blocks) {
+    /* the grid is the score launch's (block_header_kernel adds that many loss partials); the sequences are walked by the first
+     * active_blocks workgroups only — see launch_ewma_forward_score — and the others leave a zero partial */
+    if ((int)blockIdx.x >= active_blocks) {
+        if (threadIdx.x == 0) { w.part_loss[blockIdx.x] = 0.0; w.part_tries[blockIdx.x] = 0u; }
         return;
     }
-#endif
     ewma_seq_body<D, WHOLE, TAIL>(m, mb, blk, w, epoch_key, tail, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6),
-                                  (int)((gridDim.x * blockDim.x) >> 6), (int)blockIdx.x);
+                                  (int)((active_blocks * blockDim.x) >> 6), (int)blockIdx.x);
 }
 
 // dalpha: chunk partials (chain over sequences inside a chunk), then chain across chunks
@@ -2543,154 +2541,10 @@ __device__ __forceinline__ void seg_short_rows(const BlockView& blk, const uint6
         emit.template row<D>(row, p, lg, g, has_b, gb, pre);
     }
 }
-// NS segments in flight per lane group (the large steps' form; seg_short_rows is NS = 1 plus the small steps' inline hot rows).  Beside the
-// dense-gradient GEMM an update workgroup holds a GEMM workgroup's place on its CU whatever it does with it (the GEMM's waves take 112
-// registers, four workgroups fill a CU's register file): what the update gets out of the places it holds is bytes in flight per wave.
-// Slot s of a lane group walks the heads h + s * stride, h + (s + NS) * stride, ...; per iteration every slot's row quads and gradient
-// source rows are requested before any of them is consumed.  Per segment the arithmetic — entry order, first-initialises, the routing
-// of long segments — is seg_short_rows', so the bits are.
-template <int D, class Emit, int NS>
-__device__ __forceinline__ void seg_short_rows_multi(const BlockView& blk, const uint64_t* keys, uint64_t n, const SegScratch& sc, const Emit& emit,
-                                                     uint32_t wave, uint32_t nwaves) {
-    constexpr int L = D / 4;
-    constexpr int GPW = 64 / L;
-    const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
-    const int gbase = grp * L;
-    const uint32_t nheads = *sc.nheads;
-    const uint32_t stride = nwaves * GPW, sstride = NS * stride;
-    auto head_at = [&](uint32_t hh) { return sc.head_pos[hh < nheads ? hh : nheads]; };
-    auto window_key = [&](uint32_t p0, uint32_t p1) {
-        const uint32_t c = p1 - p0 < (uint32_t)L ? p1 - p0 : (uint32_t)L;
-        return keys[(uint32_t)lg < c ? (uint64_t)p0 + lg : ((uint64_t)p0 < n ? (uint64_t)p0 : 0)];
-    };
-    uint32_t p_cur[NS], p_end[NS], p_next[NS], p_next_end[NS];
-    uint64_t kmine[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const uint32_t hs = wave * GPW + grp + s * stride;
-        p_cur[s] = head_at(hs); p_end[s] = head_at(hs + 1);
-        p_next[s] = head_at(hs + sstride); p_next_end[s] = head_at(hs + sstride + 1);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) kmine[s] = window_key(p_cur[s], p_end[s]);
-    for (uint32_t h0 = wave * GPW; h0 < nheads; h0 += sstride) {  // wave-uniform trip count (slot 0 of group 0)
-        RowPrefetch pre[NS];
-        float4 v[NS][4];
-        float scl[NS][4];
-        bool bias[NS][4], go[NS];
-        uint32_t row[NS], len[NS], cnt[NS], lo[NS];
-        uint64_t p[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint32_t hs = h0 + grp + s * stride;
-            const bool active = hs < nheads;
-            const uint32_t p_nn = head_at(hs + 2 * sstride), p_nn_end = head_at(hs + 2 * sstride + 1);
-            p[s] = p_cur[s];
-            len[s] = active ? p_end[s] - p_cur[s] : 0u;
-            cnt[s] = len[s] < (uint32_t)L ? len[s] : (uint32_t)L;
-            lo[s] = (uint32_t)kmine[s];
-            row[s] = (uint32_t)__shfl((int)(uint32_t)(kmine[s] >> 32), gbase, 64);
-            kmine[s] = window_key(p_next[s], p_next_end[s]);
-            p_cur[s] = p_next[s];
-            p_end[s] = p_next_end[s];
-            p_next[s] = p_nn;
-            p_next_end[s] = p_nn_end;
-            go[s] = active;
-            if (len[s] > SBR_SEG_ROUTE) { /* long segment: registered for the chunked path (or listed already: seg_long_list_kernel) */
-                if (lg == 0 && !sc.prelisted) {
-                    const uint32_t slot = atomicAdd(&sc.counters[0], 1u);
-                    if (slot < sc.cap) {
-                        sc.long_start[slot] = (uint32_t)p[s];
-                        sc.long_end[slot] = (uint32_t)p[s] + len[s];
-                    }
-                }
-                go[s] = false;
-            }
-            if (go[s]) {
-                pre[s] = emit.template pre<D>(row[s], lg);
-                if (len[s] <= (uint32_t)L) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[s][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        scl[s][i] = 0.0f;
-                        bias[s][i] = false;
-                        if (i < (int)cnt[s]) {
-                            const uint32_t src = (uint32_t)__shfl((int)lo[s], gbase + i, 64);
-                            const uint32_t r = src / 3, kind = src % 3;
-                            v[s][i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
-                            scl[s][i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
-                            bias[s][i] = kind != 0;
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (!go[s]) continue;
-            float4 g;
-            float gb;
-            bool has_b;
-            if (len[s] <= (uint32_t)L) { /* the whole segment is in the window: its first four entries are in flight already */
-                g = make_float4(0.f, 0.f, 0.f, 0.f);
-                gb = 0.0f;
-                has_b = false;
-                bool first = true;
-                for (int e = 0; e < (int)cnt[s]; e += 4) {
-                    float4 vv[4];
-                    float sl[4];
-                    bool bi[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        vv[i] = v[s][i]; sl[i] = scl[s][i]; bi[i] = bias[s][i];
-                        if (e > 0) {
-                            vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            sl[i] = 0.0f;
-                            bi[i] = false;
-                            if (e + i < (int)cnt[s]) {
-                                const uint32_t src = (uint32_t)__shfl((int)lo[s], gbase + e + i, 64);
-                                const uint32_t r = src / 3, kind = src % 3;
-                                vv[i] = ld4((kind == 0 ? blk.dX : blk.H) + (size_t)r * D + 4 * lg);
-                                sl[i] = kind == 0 ? 1.0f : (kind == 1 ? -blk.coef[r] : blk.coef[r]);
-                                bi[i] = kind != 0;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (e + i < (int)cnt[s]) {
-                            if (first) {
-                                g = make_float4(sl[i] * vv[i].x, sl[i] * vv[i].y, sl[i] * vv[i].z, sl[i] * vv[i].w);
-                                first = false;
-                            } else {
-                                g.x = g.x + sl[i] * vv[i].x; g.y = g.y + sl[i] * vv[i].y;
-                                g.z = g.z + sl[i] * vv[i].z; g.w = g.w + sl[i] * vv[i].w;
-                            }
-                            if (bi[i]) {
-                                gb = has_b ? gb + sl[i] : sl[i];
-                                has_b = true;
-                            }
-                        }
-                    }
-                }
-            } else {
-                seg_accumulate<D>(blk, keys, p[s], p[s] + len[s], lg, &g, &gb, &has_b);
-            }
-            emit.template row<D>(row[s], p[s], lg, g, has_b, gb, pre[s]);
-        }
-    }
-}
-#ifndef SBR_SEG_NS
-#define SBR_SEG_NS 1 /* segments in flight per lane group in the large steps' update (A/B: profiles/r06_tail.md) */
-#endif
-#ifndef SBR_SEG_GRID_CAP
-#define SBR_SEG_GRID_CAP 1024
-#endif
 template <int D, class Emit, bool INLINE_LONG = false>
 __global__ __launch_bounds__(256) void seg_short_kernel(BlockView blk, const uint64_t* keys, uint64_t n, SegScratch sc, Emit emit) {
-    const uint32_t wave = (uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6), nwaves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
-    if constexpr (!INLINE_LONG && SBR_SEG_NS > 1) seg_short_rows_multi<D, Emit, SBR_SEG_NS>(blk, keys, n, sc, emit, wave, nwaves);
-    else seg_short_rows<D, Emit, INLINE_LONG>(blk, keys, n, sc, emit, wave, nwaves);
+    seg_short_rows<D, Emit, INLINE_LONG>(blk, keys, n, sc, emit, (uint32_t)((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6),
+                                         (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6));
 }
 
 // ---- the optimiser half of a SMALL single-device LSTM step at d <= 32 in ONE launch (launch_small_back) ----
@@ -3461,7 +3315,17 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
 }
 
 /* EWMA + single-negative loss: scan and score in one pass per sequence (ewma_seq_kernel); whole = the backward scan too.  The
- * grid is launch_score's, so that launch_block_header finds the same number of loss partials. */
+ * grid is launch_score's, so that launch_block_header finds the same number of loss partials.
+ * whole (the default since round 6): a sequence's backward scan re-reads what its forward scan touched moments earlier — the target
+ * and negative rows and its own h rows, ~3 x 4d bytes per step — and whether those re-reads come from the Infinity Cache or from
+ * HBM is a matter of how many sequences are in flight between a row's two uses.  With every wave slot taken (7 workgroups per CU,
+ * ~7 000 sequences at d = 256: ~1 GB between the two uses) they all come from HBM and the whole form only saves a launch; on TWO
+ * workgroups per CU (SBR_EWMA_WHOLE_WG = 512: ~200 MB in flight) a good part of them hits: step 6.28 -> 5.73-5.95 ms at d = 256 /
+ * 1e7 items / 50 000 sequences, 4.09 -> 3.59 ms at d = 128 / 1e6 items; one workgroup per CU has too few requests in flight (6.4-6.5 ms),
+ * three (768) 5.8-5.9 (profiles/r06_ewma_bytes.md).  Same arithmetic, same bits. */
+#ifndef SBR_EWMA_WHOLE_WG
+#define SBR_EWMA_WHOLE_WG 512
+#endif
 void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                                int rows_host, bool whole, hipStream_t s, const SmallTail* tail) {
     if (rows_host <= 0) return;
@@ -3469,13 +3333,13 @@ void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const Block
     DISPATCH_D(m.d, {
         if constexpr (DD <= 32) {
             if (tail) { /* one sequence: scan, score, backward scan and the step's bookkeeping + key ordering in one workgroup's launch */
-                hipLaunchKernelGGL((ewma_seq_kernel<DD, true, true>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail);
+                hipLaunchKernelGGL((ewma_seq_kernel<DD, true, true>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail, 1);
                 return;
             }
         }
         const int grid = score_grid(DD, rows_host, true);
-        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
-        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none);
+        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none, grid < SBR_EWMA_WHOLE_WG ? grid : SBR_EWMA_WHOLE_WG);
+        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none, grid);
     });
 }
 
@@ -3599,7 +3463,7 @@ int launch_dense_gradient(const ModelView& m, const MbView& mb, const BlockView&
          * are out of range and read as zeros; on its 64-bit address path they are cleared here */
         const bool buffer_path = DD >= 128 && !w.wide_addresses && (size_t)rows_host * DD * 4 < ((size_t)1 << 31);
         const size_t pad_rows = buffer_path ? 0 : (size_t)nch * SBR_DW_CHUNK_ROWS - (size_t)rows_host;
-        constexpr int lds_pad = 0; /* (a residency cap through extra dynamic LDS — three workgroups per CU instead of four, room for
+        constexpr int lds_pad = SBR_DW_LDS_PAD; /* (a residency cap through extra dynamic LDS — three workgroups per CU instead of four, room for
                                     * the sparse update's waves beside them — measured and dropped: profiles/r03_dw_experiments.md) */
         if (m.ng == 4) {
             if constexpr (full4) {
@@ -3673,7 +3537,7 @@ static void launch_seg_reduce(int d, const BlockView& blk, uint32_t rows_host, c
         /* 4 workgroups per CU: with 8 the update's waves fill the register file and the dense-gradient GEMM on the side
          * stream cannot become resident beside it (measured: 14.04 ms per step at 2048, 13.92 at 1024; the update alone
          * takes the same 1.13-1.2 ms either way) */
-        constexpr int seg_grid_cap = SBR_SEG_GRID_CAP;
+        constexpr int seg_grid_cap = 1024;
         int seg_grid = grid_for_groups((long long)total / 2 + 1, gpb);
         if (seg_grid > seg_grid_cap) seg_grid = seg_grid_cap;
         hipLaunchKernelGGL((seg_short_kernel<DD, Emit>), dim3(seg_grid), dim3(256), 0, s, blk, keys_sorted, total, sc, emit);

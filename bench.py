@@ -670,6 +670,8 @@ def main():
                     help="Synchronous multi-GPU step over a replicated table: owner = the owner of a slice reduces AND updates it in place, "
                          "the updated parameter slices are all-gathered into every replica's table (round 6); gradient = rounds 1-5: the "
                          "reduced gradient chunks are all-gathered and every replica updates the whole table.  Same bits")
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="keep the GPU busy with a model-neutral load for this long before the warm-up steps (see the comment at its use)")
     ap.add_argument("--scale-shape", action="store_true",
                     help="N = 1 on the shape the N > 1 runs use per GPU (BASELINE configs[3]: 125 000 users, seq_len <= 128): the denominator of a "
                          "weak-scaling efficiency (every N > 1 line also carries it as `single_gpu_same_shape`)")
@@ -802,6 +804,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    prewarm = None
+    if args.prewarm_seconds > 0 and torch.cuda.is_available():
+        # The timed region is K steps of a few milliseconds each, entered seconds after the process has generated its synthetic data on
+        # the host with the GPU idle: without this the K steps are measured on a GPU that is still leaving its idle power state (the
+        # HBM-bound kernels read ~10 % slow, profiles/r06_prewarm.md).  A model-neutral load (no optimiser step, no model state
+        # touched: a torch f32 matmul and a device copy) keeps the GPU busy for --prewarm-seconds first; the W warm-up steps and the
+        # K timed steps follow immediately, unchanged.
+        t_w = time.perf_counter()
+        wa = torch.empty(4096, 4096, device="cuda").normal_()
+        wb = torch.empty(4096, 4096, device="cuda").normal_()
+        wc = torch.empty(4096, 4096, device="cuda")
+        big = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+        big2 = torch.empty_like(big)
+        n_w = 0
+        while time.perf_counter() - t_w < args.prewarm_seconds:
+            for _ in range(4):
+                torch.mm(wa, wb, out=wc)
+                big2.copy_(big)
+            torch.cuda.synchronize()
+            n_w += 4
+        prewarm = {"seconds": time.perf_counter() - t_w, "what": "torch f32 4096^3 matmul + 256 MiB device copy in a loop before the warm-up steps; touches no model state",
+                   "iterations": n_w}
+        del wa, wb, wc, big, big2
     for _ in range(args.warmup):
         one_step(False)
     sync()
@@ -1128,7 +1153,7 @@ def main():
             "ms_per_step_per_rank": per_rank,
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
             "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
-            "roofline": roofline, "step_bytes": step_bytes, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
+            "gpu_prewarm": prewarm, "roofline": roofline, "step_bytes": step_bytes, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
             "kernels_source": ("HIP events on every family inside the timed region" if timers == "all" else
                                f"SCORE: HIP events inside the timed region; the other families: a second pass of {args.steps} steps of the same schedule "
                                "with every family bracketed (events cost the step 1.5-2 %, so the timed region brackets the roofline kernel only)"),

@@ -191,9 +191,6 @@ void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<flo
     }
 }
 
-#ifndef SBR_EWMA_FUSED_DEFAULT
-#define SBR_EWMA_FUSED_DEFAULT 2
-#endif
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
 }  // namespace
@@ -1621,17 +1618,16 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
         }
         p->sort_off_stream = false;
     }
-    /* EWMA + single-negative loss (BASELINE configs[4]): scan and score in one pass per sequence, optionally the backward scan too
-     * (0: three launches — EWMA + WARP / 1: scan + score fused / 2: the whole sequence in one pass; same bits) */
-    int ewma_fused = (!m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0) ? SBR_EWMA_FUSED_DEFAULT : 0;
-    if (ewma_fused && small_tail) ewma_fused = 2; /* a one-sequence step: the backward scan rides along as well */
-    if (m->reference_order) ewma_fused = 0;       /* scan, then the sequential-stream scorer, then the backward scan */
+    /* EWMA + single-negative loss (BASELINE configs[4]): scan, scores and backward scan of a sequence in ONE pass (ewma_seq_kernel; same
+     * bits as scan | score | backward scan, which EWMA + WARP and the reference-order mode still take: their negatives depend on the
+     * scores / on a sequential stream) */
+    const bool ewma_fused = !m->ng && m->hp.loss != SBR_LOSS_WARP && mb.R > 0 && !m->reference_order;
     if (ewma_fused) {
         ScopedTimer t(m, SBR_K_SCORE, 1);
         p->header_accumulated = p->ndev == 1;
         const sbr::SmallTail tail{bv.header, p->header_accumulated ? p->loss_acc : nullptr, p->header_accumulated ? p->ex_acc : nullptr,
                                   p->lag_state, p->keys_sorted, p->seg.head_pos, p->seg.nheads};
-        sbr::launch_ewma_forward_score(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, ewma_fused >= 2, m->stream, small_tail ? &tail : nullptr);
+        sbr::launch_ewma_sequences(m->mv, mv, bv, p->wb.v, epoch_key, mb.R, m->stream, small_tail ? &tail : nullptr);
     } else {
         {
             ScopedTimer t(m, SBR_K_RECURRENT_FWD, m->ng && m->d > 128 ? (uint64_t)mb.Tm : 1); /* d <= 128: one sequence-resident launch */
@@ -1679,7 +1675,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     const bool sort_first = place == SORT_PRE;
     if (!early_sort && sort_first && !small_tail) SBRCHK(launch_sort(sorter));
     if (!early_sort && place == SORT_OWN_STREAM && !side_header) HIPCHK(hipEventRecord(m->ev_scored, m->stream));
-    if (ewma_fused < 2) {
+    if (!ewma_fused) {
         ScopedTimer t(m, SBR_K_RECURRENT_BWD, m->ng && m->d > 128 ? 2 * (uint64_t)mb.Tm : 1);
         sbr::launch_recurrent_backward(m->mv, mv, bv, p->wb.v, mb.Tm, mb.R, mb.B, off_host, m->stream);
     }

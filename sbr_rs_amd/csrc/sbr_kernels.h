@@ -194,11 +194,11 @@ void launch_small_back(const ModelView& m, const MbView& mb, const BlockView& bl
                        const uint64_t* keys_sorted, const SegScratch& sc, hipStream_t s);
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                   int rows_host, hipStream_t s, const SmallTail* tail = nullptr);
-/* EWMA with a single-negative loss (hinge / BPR): forward scan + scoring in ONE pass per sequence (replaces launch_recurrent_forward
- * + launch_score; same outputs bit for bit); whole = true: the backward scan of the sequence in the same pass as well (replaces
- * launch_recurrent_backward's scan; the dalpha reduction stays launch_dense_gradient's) */
-void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
-                               int rows_host, bool whole, hipStream_t s, const SmallTail* tail = nullptr);
+/* EWMA with a single-negative loss (hinge / BPR): forward scan, scoring and backward scan of a sequence in ONE pass (replaces
+ * launch_recurrent_forward + launch_score + launch_recurrent_backward's scan; same outputs bit for bit; the dalpha reduction stays
+ * launch_dense_gradient's) */
+void launch_ewma_sequences(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                           int rows_host, hipStream_t s, const SmallTail* tail = nullptr);
 /* debug only: dloss/dh of every packed row (the training path never materialises it) */
 void launch_materialize_dh(const ModelView& m, const BlockView& blk, int rows_host, float* dH, hipStream_t s);
 /* header of the exchange block (rows, loss sum, examples); loss_acc / ex_acc non-null (single device): the plan's accumulators

@@ -596,10 +596,11 @@ __global__ __launch_bounds__(256) void ewma_backward_kernel(ModelView m, MbView 
 // group that walks a sequence keeps s_t in registers, gathers x_t, the target row and the negative row of EWMA_U steps
 // together, scores each step against the s_t it has just formed (ewma.rs:302-335: the scan node and the two dot nodes of a
 // step) and writes H once — for the sparse update and the backward scan; the separate scan launch, its H round trip (write
-// 4d B + read 4d B per row) and the score pass's own index traffic are gone.  WHOLE = true continues with the backward scan of
-// the same sequence in the same lane group (ewma_backward_seq): its x / target / negative rows and its H rows were touched
-// moments ago by this very group, newest first in the order the backward scan wants them.
-// Same arithmetic, same bits as ewma_forward_kernel + score_single_kernel (+ ewma_backward_kernel).
+// 4d B + read 4d B per row) and the score pass's own index traffic are gone.  The lane group then continues with the backward
+// scan of the same sequence (ewma_backward_seq): its x / target / negative rows and its H rows were touched moments ago by this
+// very group, newest first in the order the backward scan wants them — out of the Infinity Cache when few enough sequences are in
+// flight (launch_ewma_sequences).
+// Same arithmetic, same bits as ewma_forward_kernel + score_single_kernel + ewma_backward_kernel.
 // ------------------------------------------------------------------------------------------------
 // Packing invariant both scans rest on (sbr_engine.hip pack_sequences / the epoch packer: in_idx = item[t], out_idx = item[t + 1] of
 // ONE item slice): the target of step t is the input of step t + 1, out_idx[row(t, b)] == in_idx[row(t + 1, b)].  A step's target
@@ -688,7 +689,7 @@ __device__ __forceinline__ void ewma_backward_seq(const ModelView& m, const MbVi
 }
 
 // TAIL (one workgroup, a one-sequence step): the step's SmallTail follows in the same launch
-template <int D, bool WHOLE, bool TAIL>
+template <int D, bool TAIL>
 __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
                                               const SmallTail& tail, int wave, int nwaves, int part) {
     constexpr int L = D / 4;
@@ -785,11 +786,9 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
             for (int q = 0; q < EWMA_U; ++q) { r[q] = rn[q]; pi[q] = pin[q]; }
             ctr = ctrn;
         }
-        if constexpr (WHOLE) {
-            /* lane 0's stores to blk.neg / coef / out_idx are read back by the whole group below */
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            ewma_backward_seq<D>(m, mb, blk, w, b, n, lg, a, oma);
-        }
+        /* lane 0's stores to blk.neg / coef / out_idx are read back by the whole group below */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        ewma_backward_seq<D>(m, mb, blk, w, b, n, lg, a, oma);
     }
     __shared__ double s_loss[4];
     __shared__ unsigned int s_tries[4];
@@ -813,15 +812,15 @@ __device__ __forceinline__ void ewma_seq_body(const ModelView& m, const MbView& 
         if constexpr (TAIL) small_tail<256>(mb, blk, w, tail, lsum, tsum);
     }
 }
-template <int D, bool WHOLE, bool TAIL = false>
+template <int D, bool TAIL = false>
 __global__ __launch_bounds__(256) void ewma_seq_kernel(ModelView m, MbView mb, BlockView blk, WorkView w, uint64_t epoch_key, SmallTail tail, int active_blocks) {
     /* the grid is the score launch's (block_header_kernel adds that many loss partials); the sequences are walked by the first
-     * active_blocks workgroups only — see launch_ewma_forward_score — and the others leave a zero partial */
+     * active_blocks workgroups only — see launch_ewma_sequences — and the others leave a zero partial */
     if ((int)blockIdx.x >= active_blocks) {
         if (threadIdx.x == 0) { w.part_loss[blockIdx.x] = 0.0; w.part_tries[blockIdx.x] = 0u; }
         return;
     }
-    ewma_seq_body<D, WHOLE, TAIL>(m, mb, blk, w, epoch_key, tail, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6),
+    ewma_seq_body<D, TAIL>(m, mb, blk, w, epoch_key, tail, (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6),
                                   (int)((active_blocks * blockDim.x) >> 6), (int)blockIdx.x);
 }
 
@@ -3314,32 +3313,31 @@ void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, co
     }
 }
 
-/* EWMA + single-negative loss: scan and score in one pass per sequence (ewma_seq_kernel); whole = the backward scan too.  The
- * grid is launch_score's, so that launch_block_header finds the same number of loss partials.
- * whole (the default since round 6): a sequence's backward scan re-reads what its forward scan touched moments earlier — the target
+/* EWMA + single-negative loss: scan, scores and backward scan of a sequence in one pass (ewma_seq_kernel).  The grid is
+ * launch_score's, so that launch_block_header finds the same number of loss partials.
+ * A sequence's backward scan re-reads what its forward scan touched moments earlier — the target
  * and negative rows and its own h rows, ~3 x 4d bytes per step — and whether those re-reads come from the Infinity Cache or from
  * HBM is a matter of how many sequences are in flight between a row's two uses.  With every wave slot taken (7 workgroups per CU,
- * ~7 000 sequences at d = 256: ~1 GB between the two uses) they all come from HBM and the whole form only saves a launch; on TWO
+ * ~7 000 sequences at d = 256: ~1 GB between the two uses) they all come from HBM and the one-pass form only saves a launch (rounds 4-5 therefore ran the backward scan as its own launch); on TWO
  * workgroups per CU (SBR_EWMA_WHOLE_WG = 512: ~200 MB in flight) a good part of them hits: step 6.28 -> 5.73-5.95 ms at d = 256 /
  * 1e7 items / 50 000 sequences, 4.09 -> 3.59 ms at d = 128 / 1e6 items; one workgroup per CU has too few requests in flight (6.4-6.5 ms),
  * three (768) 5.8-5.9 (profiles/r06_ewma_bytes.md).  Same arithmetic, same bits. */
 #ifndef SBR_EWMA_WHOLE_WG
 #define SBR_EWMA_WHOLE_WG 512
 #endif
-void launch_ewma_forward_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
-                               int rows_host, bool whole, hipStream_t s, const SmallTail* tail) {
+void launch_ewma_sequences(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,
+                           int rows_host, hipStream_t s, const SmallTail* tail) {
     if (rows_host <= 0) return;
     const SmallTail none{};
     DISPATCH_D(m.d, {
         if constexpr (DD <= 32) {
             if (tail) { /* one sequence: scan, score, backward scan and the step's bookkeeping + key ordering in one workgroup's launch */
-                hipLaunchKernelGGL((ewma_seq_kernel<DD, true, true>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail, 1);
+                hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(1), dim3(256), 0, s, m, mb, blk, w, epoch_key, *tail, 1);
                 return;
             }
         }
         const int grid = score_grid(DD, rows_host, true);
-        if (whole) hipLaunchKernelGGL((ewma_seq_kernel<DD, true>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none, grid < SBR_EWMA_WHOLE_WG ? grid : SBR_EWMA_WHOLE_WG);
-        else hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none, grid);
+        hipLaunchKernelGGL((ewma_seq_kernel<DD, false>), dim3(grid), dim3(256), 0, s, m, mb, blk, w, epoch_key, none, grid < SBR_EWMA_WHOLE_WG ? grid : SBR_EWMA_WHOLE_WG);
     });
 }
 

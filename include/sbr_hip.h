@@ -147,7 +147,8 @@ sbr_status sbr_fit_steps(sbr_fit_plan* p, uint64_t first, uint64_t count);
  * additionally runs of steps in one launch through sbr_fit_steps / sbr_model_fit where the shape allows.  No result bit depends
  * on it (tests run all three). */
 sbr_status sbr_model_set_step_fusion(sbr_model* m, int32_t level);
-/* REFERENCE ORDER of the negatives (one subsequence per step, embedding_dim <= 32, max_sequence_length <= 256): the
+/* REFERENCE ORDER of the negatives (one subsequence per step; every embedding_dim; steps whose h rows and 64-draw candidate window fit
+ * one workgroup's LDS: max_sequence_length <= 256 at embedding_dim <= 64, <= 221 at <= 128, <= 81 at <= 256): the
  * negatives of a step are drawn from the worker's own sequential generator exactly as sequence_model.rs:58-65 / :137 draw them —
  * `Uniform::new(0, num_items).sample(thread_rng)` (rand 0.5 as recalled), one draw per try, the same generator that shuffles the
  * worker's partition every epoch (:109) — instead of the engine's counter-keyed draws (which exist so that draws can be evaluated in

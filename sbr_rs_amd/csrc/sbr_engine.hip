@@ -1573,7 +1573,7 @@ sbr_status sbr_fit_step_local(sbr_fit_plan* p, uint64_t minibatch) {
     /* ONE subsequence per step at d <= 32 (the reference's own schedule): header, lagged loss figure and the ordering of the step's
      * keys run at the end of the score launch (sbr::SmallTail) — three launches of ~5 us fewer in a step of ~40-100 us */
     const bool small_tail = (m->step_fusion >= 1 || m->reference_order) && !overlap && (p->ndev == 1 || m->reference_order) &&
-                            sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R);
+                            sbr::small_tail_shape_ok(m->mv, (int)mb.B, (int)mb.R, m->reference_order);
     auto launch_sort = [&](hipStream_t on) -> sbr_status {
         if (on != m->stream) {
             /* everything before: the previous step's readers of the keys, this step's score (a WARP step records the event
@@ -1874,9 +1874,10 @@ sbr_status sbr_fit_block_bytes(const sbr_fit_plan* p, uint64_t* out_bytes) {
 
 sbr_status sbr_model_set_reference_order(sbr_model* m, int32_t on) {
     if (!m) return SBR_ERR_INVALID_ARGUMENT;
-    if (on && (m->hp.batch_sequences != 1 || (m->d != 16 && m->d != 32) || m->hp.max_sequence_length - 1 > SBR_SMALL_TAIL_MAX_ROWS ||
+    if (on && (m->hp.batch_sequences != 1 || !sbr::reference_order_shape_ok(m->d, (int)m->hp.max_sequence_length - 1) ||
                (m->hp.num_devices != 1 && (m->hp.parallelism != SBR_PAR_SYNCHRONOUS || m->shared))))
-        return SBR_ERR_UNSUPPORTED; /* one sequence per step in the one-workgroup step's shapes; several workers: Synchronous, replicated */
+        return SBR_ERR_UNSUPPORTED; /* one sequence per step whose h rows + candidate window fit one workgroup's LDS (255 rows at d <= 64, 220 at
+                                     * d = 128, 80 at d = 256); several workers: Synchronous, replicated */
     m->reference_order = on != 0;
     return SBR_OK;
 }

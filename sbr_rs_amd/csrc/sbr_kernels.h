@@ -156,7 +156,8 @@ struct SmallTail {
     uint32_t* head_pos;
     uint32_t* nheads;
 };
-bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host);
+bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host, bool wide = false); /* wide: every kernel width (the reference-order step) */
+bool reference_order_shape_ok(int d, int max_rows); /* sbr_steps.hip: the sequential-stream scorer's LDS */
 /* Reference order (one sequence per step, one device): negatives from the worker's sequential xorshift stream (rng_state: 4 words on
  * the device, advanced by exactly the draws consumed), then the SmallTail.  Returns false where the one-sequence form does not exist. */
 bool launch_score_reference_order(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t* rng_state,

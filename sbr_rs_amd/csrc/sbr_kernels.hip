@@ -3277,8 +3277,8 @@ static int score_grid(int d, int rows, bool single_negative) {
     return grid_for_groups(rows, gpb);
 }
 
-bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host) {
-    return sequences_host == 1 && rows_host > 0 && rows_host <= SBR_SMALL_TAIL_MAX_ROWS && (m.d == 16 || m.d == 32);
+bool small_tail_shape_ok(const ModelView& m, int sequences_host, int rows_host, bool wide) {
+    return sequences_host == 1 && rows_host > 0 && rows_host <= SBR_SMALL_TAIL_MAX_ROWS && (m.d == 16 || m.d == 32 || wide);
 }
 
 void launch_score(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint64_t epoch_key,

@@ -1030,13 +1030,41 @@ __global__ __launch_bounds__(512) void lstm_steps_kernel(ModelView m, EpochView 
     }
 }
 
-/* reference-order scoring of a one-sequence step (score_refstream_kernel); false: the shape has no such form */
+/* reference-order scoring of a one-sequence step (score_refstream_kernel): every kernel width; what bounds a step is the workgroup's
+ * LDS — the step's h rows, a 64-draw candidate window, four words per row beside 12 KB of static arrays (the step's key ordering):
+ * 255 rows at d <= 64, 220 at d = 128, 80 at d = 256 */
+#define SBR_REFSTREAM_MAX_LDS (147 * 1024)
+static size_t score_refstream_lds(int d, int rows) { return ((size_t)rows * d + 64 * (size_t)d + 4 * (size_t)rows + 64 * 6) * 4; }
+bool reference_order_shape_ok(int d, int max_rows) {
+    return (d == 16 || d == 32 || d == 64 || d == 128 || d == 256) && max_rows > 0 && max_rows <= SBR_SMALL_TAIL_MAX_ROWS &&
+           score_refstream_lds(d, max_rows) <= SBR_REFSTREAM_MAX_LDS;
+}
+/* false: the shape has no such form */
 bool launch_score_reference_order(const ModelView& m, const MbView& mb, const BlockView& blk, const WorkView& w, uint32_t* rng_state,
                                   int rows_host, hipStream_t s, const SmallTail& tail) {
-    if (!small_tail_shape_ok(m, mb.B, rows_host)) return false;
-    const size_t lds = ((size_t)rows_host * m.d + 64 * (size_t)m.d + 4 * (size_t)rows_host + 64 * 6) * 4;
-    if (m.d == 32) hipLaunchKernelGGL((score_refstream_kernel<32>), dim3(1), dim3(256), lds, s, m, mb, blk, w, rng_state, tail);
-    else hipLaunchKernelGGL((score_refstream_kernel<16>), dim3(1), dim3(256), lds, s, m, mb, blk, w, rng_state, tail);
+    if (!small_tail_shape_ok(m, mb.B, rows_host, /*wide=*/true) || !reference_order_shape_ok(m.d, rows_host)) return false;
+    const size_t lds = score_refstream_lds(m.d, rows_host);
+#define SBR_REFSTREAM(DD)                                                                                                                    \
+    {                                                                                                                                        \
+        static std::atomic<size_t> granted[64]; /* dynamic LDS beyond 64 KB is granted per kernel and device, once */                        \
+        int dev = 0;                                                                                                                         \
+        (void)hipGetDevice(&dev);                                                                                                            \
+        dev = dev >= 0 && dev < 64 ? dev : 0;                                                                                                \
+        if (lds > 65536 && lds > granted[dev]) {                                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(score_refstream_kernel<DD>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)SBR_REFSTREAM_MAX_LDS);                                                                           \
+            granted[dev] = SBR_REFSTREAM_MAX_LDS;                                                                                            \
+        }                                                                                                                                    \
+        hipLaunchKernelGGL((score_refstream_kernel<DD>), dim3(1), dim3(256), lds, s, m, mb, blk, w, rng_state, tail);                        \
+    }
+    switch (m.d) {
+        case 16: SBR_REFSTREAM(16) break;
+        case 32: SBR_REFSTREAM(32) break;
+        case 64: SBR_REFSTREAM(64) break;
+        case 128: SBR_REFSTREAM(128) break;
+        default: SBR_REFSTREAM(256) break;
+    }
+#undef SBR_REFSTREAM
     return true;
 }
 

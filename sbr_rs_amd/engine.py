@@ -459,7 +459,8 @@ class Model:
 
     def set_reference_order(self, on: bool = True):
         """Negatives from the worker's own sequential xorshift stream (sequence_model.rs:58-65, :137) instead of the counter-keyed
-        draws: one subsequence per step, one device, d <= 32 (sbr_model_set_reference_order)."""
+        draws: one subsequence per step; one device, or a Synchronous replicated group driven by `group_fit` (every worker's gradient then
+        goes in as its own optimiser step); max_sequence_length <= 256 / 221 / 81 at d <= 64 / 128 / 256 (sbr_model_set_reference_order)."""
         _check(self._L.sbr_model_set_reference_order(self._h, 1 if on else 0))
 
     def set_step_fusion(self, level: int):

@@ -1401,6 +1401,11 @@ def test_step_runs_in_one_launch_equal_single_steps(loss, d, T, items):
     (ModelKind.LSTM_NORMAL, LOSS_WARP, 32, 40, 23),    # 23 items: long retry runs, windows refilled inside a step
     (ModelKind.LSTM_COUPLED, LOSS_BPR, 16, 128, 400),
     (ModelKind.EWMA, LOSS_WARP, 32, 200, 1683),        # up to 199 rows per step: several 64-draw windows per sequence
+    (ModelKind.LSTM_COUPLED, LOSS_HINGE, 64, 50, 150),  # round 6: every kernel width (the MFMA recurrent kernels around the stream scorer)
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 30, 211),
+    (ModelKind.EWMA, LOSS_WARP, 128, 221, 1683),       # 220 rows: the most one workgroup's LDS holds at d = 128
+    (ModelKind.EWMA, LOSS_HINGE, 256, 24, 97),
+    (ModelKind.LSTM_NORMAL, LOSS_BPR, 100, 12, 64),    # embedding_dim 100: the 128-wide model with zero columns
 ])
 def test_reference_order_negatives_follow_the_workers_stream(kind, loss, d, T, items):
     """sbr_model_set_reference_order: the engine draws a step's negatives from the worker's own sequential xorshift128 stream with
@@ -1432,6 +1437,8 @@ def test_reference_order_negatives_follow_the_workers_stream(kind, loss, d, T, i
         assert_lagged_equal(g, o, f"reference order, fit call {call}")
     with pytest.raises(EngineError):  # the mode is defined for the reference's schedule only
         Model(hparams(items, T, d, int(kind), loss, B=2)).set_reference_order(True)
+    with pytest.raises(EngineError):  # ... and for steps whose h rows and candidate window fit one workgroup's LDS
+        Model(hparams(items, 128, 256, int(kind), loss, B=1)).set_reference_order(True)
 
 
 @pytest.mark.parametrize("name,kind,loss", [("lstm hinge 1 thread", ModelKind.LSTM_NORMAL, LOSS_HINGE), ("lstm warp", ModelKind.LSTM_NORMAL, LOSS_WARP),
@@ -1460,6 +1467,7 @@ def test_movielens_protocol_in_reference_order(name, kind, loss):
 @pytest.mark.parametrize("kind,loss,d,world,T,items,users", [
     (ModelKind.LSTM_NORMAL, LOSS_HINGE, 32, 2, 128, 1683, 40),   # the shape of the reference's mrr_test_two_threads
     (ModelKind.EWMA, LOSS_WARP, 16, 3, 20, 97, 60),
+    (ModelKind.LSTM_NORMAL, LOSS_WARP, 128, 2, 24, 131, 40),     # round 6: beyond d = 32
 ])
 def test_reference_order_several_workers_apply_one_after_the_other(kind, loss, d, world, T, items, users):
     """Reference order with num_threads(n) (Parallelism::Synchronous): every worker draws from its OWN sequential stream, the

@@ -191,6 +191,9 @@ void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<flo
     }
 }
 
+#ifndef SBR_PACK_THREADS
+#define SBR_PACK_THREADS 4 /* host threads that fill a large minibatch's packed index arrays (build_epoch) */
+#endif
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
 }  // namespace
@@ -1419,7 +1422,7 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
                 }
             }
         };
-        const int nthreads = R > (1 << 18) ? 4 : 1;
+        const int nthreads = R > (1 << 18) ? SBR_PACK_THREADS : 1;
         if (nthreads == 1) fill(0, Tm);
         else {
             std::vector<std::thread> workers;

@@ -78,3 +78,49 @@ def test_gpus_n_without_a_launcher_starts_n_ranks():
     else:
         assert "must be launched through" not in res.stderr
         assert res.stderr.count("bench.py needs an MI355X") == 2, res.stderr[-2000:]
+
+
+def _trace_db(path, dispatches):
+    """A rocpd-shaped database: `kernels` (name, start, duration) and `counters_collection` (dispatch_id, kernel_name, counter_name,
+    value) with the given (kernel name, duration ns, FETCH_SIZE) dispatches in order."""
+    import sqlite3
+
+    db = sqlite3.connect(path)
+    db.execute("create table kernels (name text, start integer, end integer, duration integer)")
+    db.execute("create table counters_collection (dispatch_id integer, kernel_name text, counter_name text, value real)")
+    t = 0
+    for i, (name, dur, fetch) in enumerate(dispatches):
+        db.execute("insert into kernels values (?, ?, ?, ?)", (name, t, t + dur, dur))
+        for inst in range(2):  # two counter instances per dispatch: the tools sum them
+            db.execute("insert into counters_collection values (?, ?, 'FETCH_SIZE', ?)", (i, name, fetch / 2))
+        t += dur + 10
+    db.commit()
+    db.close()
+
+
+def test_pmc_step_window_and_timed_region_table(tmp_path, capsys):
+    """tools/pmc_dispatches.step_window (bench.py's `roofline.traffic_step`) and tools/rocpd_stats.py --window (the timed region's own
+    kernel table): only the dispatches from the first-th up to the (first + count)-th dispatch of the marking kernel are counted."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_dispatches
+    import rocpd_stats
+
+    step = [("void sbr::ewma_seq_kernel<256, false>(sbr::ModelView)", 2000, 100.0), ("void sbr::seg_short_kernel<256, sbr::EmitApply, false>(x)", 3000, 200.0),
+            ("radix_hist_kernel", 100, 4.0)]
+    disp = [("warm_up_only_kernel", 50, 1000.0)] + step * 5  # five steps after one unrelated dispatch
+    path = str(tmp_path / "run_results.db")
+    _trace_db(path, disp)
+    assert pmc_dispatches.per_dispatch(path, "FETCH_SIZE", "ewma_seq_kernel") == [100.0] * 5
+    win = pmc_dispatches.step_window(path, "FETCH_SIZE", "ewma_seq_kernel", 1, 3)  # steps 1, 2, 3
+    assert win == {"ewma_seq_kernel": 300.0, "seg_short_kernel": 600.0, "radix_hist_kernel": 12.0}
+    assert pmc_dispatches.step_window(path, "FETCH_SIZE", "ewma_seq_kernel", 2, 3)["seg_short_kernel"] == 600.0  # to the end of the trace
+    assert pmc_dispatches.step_window(path, "FETCH_SIZE", "ewma_seq_kernel", 4, 3) is None  # not that many steps
+    sys.argv = ["rocpd_stats.py", path, str(tmp_path / "out.md"), "--window", "ewma_seq_kernel", "1", "3"]
+    rocpd_stats.main()
+    text = open(tmp_path / "out.md").read()
+    whole, timed = text.split("Timed region only")
+    assert "| `ewma_seq_kernel<256, false>` | 5 | 0.010 | 2.00 |" in whole and "warm_up_only_kernel" in whole
+    assert "| `ewma_seq_kernel<256, false>` | 3 | 0.006 | 2.00 |" in timed and "warm_up_only_kernel" not in timed
+    capsys.readouterr()

@@ -697,6 +697,13 @@ def main():
         args.max_len = 128 if multi else 64
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    shared_devices_note = None
+    if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count() and args.backend != "gloo":
+        # more ranks than devices on this node (a one-GPU box): RCCL refuses two ranks on one device; the host-staged test transport
+        # does not.  Every rank takes this branch (LOCAL_WORLD_SIZE is the launcher's), and the line says what it is.
+        shared_devices_note = (f"{os.environ.get('LOCAL_WORLD_SIZE', world)} ranks on {torch.cuda.device_count()} device(s): ranks share a GPU, "
+                               "gloo (host-staged) transport — a functional run, not a scaling measurement")
+        args.backend = "gloo"
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()  # ranks may share a device
     torch.cuda.set_device(local_rank)
@@ -706,7 +713,7 @@ def main():
 
     engine.set_device(local_rank)
     dist = None
-    backend_note = None
+    backend_note = shared_devices_note
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
 

@@ -2770,34 +2770,82 @@ __global__ __launch_bounds__(256) void owner_reduce_kernel(ChunkPtrs recv, int n
 // sums) is what the devices then all-gather, straight into every replica's table.  Same sums, same update arithmetic as
 // owner_reduce_kernel + table_apply_kernel: same bits; no device walks the whole table any more, and a row's optimiser state
 // lives on its owner only.
-template <int D>
+template <int D, int NQ>  // NQ: devices the row's requests are unrolled for (ndev <= NQ)
 __global__ __launch_bounds__(256) void owner_update_kernel(ModelView m, ChunkPtrs recv, int ndev, uint64_t S, uint64_t row0, uint64_t nrows) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
     const int lane = threadIdx.x & 63, lg = lane % L, grp = lane / L;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t i = wave * GPW + grp; i < nrows; i += nwaves * GPW) {
-        uint32_t f[16];
+    const bool adam = m.optimizer == SBR_OPT_ADAM;
+    /* A row is TWO dependent round trips: the devices' flags of the row, then — all requested together — the touched devices'
+     * contributions, their bias words and the row's own parameter / optimiser-state quads; the adds stay in device order.  (The
+     * first form requested a contribution only after the previous device's had been added: up to ten round trips per row.) */
+    auto flags_of = [&](uint64_t i, uint32_t (&f)[NQ]) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q)  /* the devices' flags of this row first: one round trip, then only the touched contributions */
-            f[q] = q < ndev ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(recv.p[q]) + S * D + S)[i] : 0u;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        float gb = 0.0f;
+        for (int q = 0; q < NQ; ++q)
+            f[q] = (q < ndev && i < nrows) ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(recv.p[q]) + S * D + S)[i] : 0u;
+    };
+    uint64_t i = wave * GPW + grp;
+    uint32_t f[NQ];
+    flags_of(i, f);
+    for (uint64_t i0 = wave * GPW; i0 < nrows; i0 += nwaves * GPW, i += nwaves * GPW) {  // wave-uniform trip count
         uint32_t fl = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {  /* (f[q] = 0 beyond ndev: nothing is read there) */
+        for (int q = 0; q < NQ; ++q) fl |= f[q];
+        float4 v[NQ];
+        float vb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {  /* (f[q] = 0 beyond ndev and past the slice: nothing is read there) */
             const float* c = reinterpret_cast<const float*>(recv.p[q]);
-            if (f[q] & 1u) {
-                const float4 v = ld4(c + i * D + 4 * lg);
-                if (fl & 1u) { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
-                else g = v;
-            }
-            if (f[q] & 2u) gb = (fl & 2u) ? gb + c[S * D + i] : c[S * D + i];
-            fl |= f[q];
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[q] = 0.0f;
+            if (f[q] & 1u) v[q] = ld4(c + i * D + 4 * lg);
+            if (f[q] & 2u) vb[q] = c[S * D + i];
         }
-        if (fl & 1u) row_update<D>(m, row0 + i, lg, g, false, 0.0f);
-        if (fl & 2u) bias_update(m, row0 + i, lg, gb);
+        const uint64_t row = row0 + i;
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), av = wv, mv = wv;
+        float bv = 0.0f, ba = 0.0f, bmm = 0.0f;
+        if (fl & 1u) {
+            wv = ld4(m.E + row * D + 4 * lg);
+            av = ld4(m.Eacc + row * D + 4 * lg);
+            if (adam) mv = ld4(m.Em + row * D + 4 * lg);
+        }
+        if ((fl & 2u) && lg == 0) {
+            bv = m.b[row]; ba = m.bacc[row];
+            if (adam) bmm = m.bm[row];
+        }
+        uint32_t fcur[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fcur[q] = f[q];
+        flags_of(i + nwaves * GPW, f);  /* the next row's flags travel underneath this row's contributions */
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gb = 0.0f;
+        uint32_t seen = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (fcur[q] & 1u) {
+                if (seen & 1u) { g.x = g.x + v[q].x; g.y = g.y + v[q].y; g.z = g.z + v[q].z; g.w = g.w + v[q].w; }
+                else g = v[q];
+            }
+            if (fcur[q] & 2u) gb = (seen & 2u) ? gb + vb[q] : vb[q];
+            seen |= fcur[q];
+        }
+        if (fl & 1u) {  /* row_update */
+            opt_update(m, &wv.x, &av.x, &mv.x, g.x);
+            opt_update(m, &wv.y, &av.y, &mv.y, g.y);
+            opt_update(m, &wv.z, &av.z, &mv.z, g.z);
+            opt_update(m, &wv.w, &av.w, &mv.w, g.w);
+            st4(m.E + row * D + 4 * lg, wv);
+            st4(m.Eacc + row * D + 4 * lg, av);
+            if (adam) st4(m.Em + row * D + 4 * lg, mv);
+        }
+        if ((fl & 2u) && lg == 0) {  /* bias_update */
+            opt_update(m, &bv, &ba, &bmm, gb);
+            m.b[row] = bv;
+            m.bacc[row] = ba;
+            if (adam) m.bm[row] = bmm;
+        }
     }
 }
 
@@ -2857,7 +2905,12 @@ __global__ void merge_plan_kernel(PeerBounds pb, int ndev, int q, MergePlan* out
     out->base[16] = total;
 }
 
-template <int D>
+// A row of the merge has at most one entry per device (every device reduced its own entries per row first), so a row is TWO
+// dependent round trips: its window of NQ merge keys (with the predecessor's, which says whether the position is a head), then —
+// all requested together — the touched devices' list rows, their bias words and flags, and the row's own parameter /
+// optimiser-state quads; the adds stay in device order.  (The first form walked key -> list row -> next key -> ... -> table row:
+// up to 2 ndev + 2 dependent round trips per row, each of them an xGMI round trip for a peer's list.)
+template <int D, int NQ>
 __global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, PeerLists pl, const uint64_t* mkeys) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
@@ -2865,28 +2918,69 @@ __global__ __launch_bounds__(256) void owner_list_apply_kernel(ModelView m, Peer
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t n = pl.plan->base[16];  /* merge keys of this step (grid-stride: the launch does not depend on it) */
-    for (uint64_t i = wave * GPW + grp; i < n; i += nwaves * GPW) {
-        const uint64_t key = mkeys[i];
-        if (key == ~0ull) continue; /* padding sorts to the end */
-        const uint32_t row = (uint32_t)(key >> 32);
-        if (i > 0 && (uint32_t)(mkeys[i - 1] >> 32) == row) continue;
+    const bool adam = m.optimizer == SBR_OPT_ADAM;
+    for (uint64_t i0 = wave * GPW; i0 < n; i0 += nwaves * GPW) {  // wave-uniform trip count
+        const uint64_t i = i0 + grp;
+        uint64_t k[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) k[j] = i + j < n ? mkeys[i + j] : ~0ull;
+        const uint64_t kprev = (i > 0 && i < n) ? mkeys[i - 1] : ~0ull;
+        const uint32_t row = (uint32_t)(k[0] >> 32);
+        const bool head = k[0] != ~0ull && (i == 0 || (uint32_t)(kprev >> 32) != row);  /* padding sorts to the end */
+        if (!head) continue;
+        float4 v[NQ];
+        float vb[NQ];
+        uint32_t vf[NQ];
+        bool in[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {  /* devices in ascending order: the row's keys are consecutive */
+            in[j] = k[j] != ~0ull && (uint32_t)(k[j] >> 32) == row;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[j] = 0.0f;
+            vf[j] = 0u;
+            if (in[j]) {
+                const int r = (int)((k[j] >> 28) & 15u);
+                const uint32_t p = (uint32_t)(k[j] & 0x0FFFFFFFu);
+                v[j] = ld4(pl.G[r] + (size_t)p * D + 4 * lg);
+                vf[j] = pl.fl[r][p];
+                vb[j] = pl.gb[r][p];
+            }
+        }
+        float4 wv = ld4(m.E + (size_t)row * D + 4 * lg), av = ld4(m.Eacc + (size_t)row * D + 4 * lg);
+        float4 mv = adam ? ld4(m.Em + (size_t)row * D + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float bv = 0.0f, ba = 0.0f, bmm = 0.0f;
+        if (lg == 0) {  /* requested with the rest; used only if some device's entry carries a bias term */
+            bv = m.b[row]; ba = m.bacc[row];
+            if (adam) bmm = m.bm[row];
+        }
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float gb = 0.0f;
         bool has_b = false, first = true;
-        for (uint64_t e = i; e < n; ++e) { /* devices in ascending order; the first toucher initialises */
-            const uint64_t ke = mkeys[e];
-            if (ke == ~0ull || (uint32_t)(ke >> 32) != row) break;
-            const int r = (int)((ke >> 28) & 15u);
-            const uint32_t p = (uint32_t)(ke & 0x0FFFFFFFu);
-            const float4 v = ld4(pl.G[r] + (size_t)p * D + 4 * lg);
-            if (first) { g = v; first = false; }
-            else { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
-            if (pl.fl[r][p] & 2u) {
-                gb = has_b ? gb + pl.gb[r][p] : pl.gb[r][p];
-                has_b = true;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (in[j]) {
+                if (first) { g = v[j]; first = false; }
+                else { g.x = g.x + v[j].x; g.y = g.y + v[j].y; g.z = g.z + v[j].z; g.w = g.w + v[j].w; }
+                if (vf[j] & 2u) {
+                    gb = has_b ? gb + vb[j] : vb[j];
+                    has_b = true;
+                }
             }
         }
-        row_update<D>(m, row, lg, g, has_b, gb);
+        /* row_update + bias_update */
+        opt_update(m, &wv.x, &av.x, &mv.x, g.x);
+        opt_update(m, &wv.y, &av.y, &mv.y, g.y);
+        opt_update(m, &wv.z, &av.z, &mv.z, g.z);
+        opt_update(m, &wv.w, &av.w, &mv.w, g.w);
+        st4(m.E + (size_t)row * D + 4 * lg, wv);
+        st4(m.Eacc + (size_t)row * D + 4 * lg, av);
+        if (adam) st4(m.Em + (size_t)row * D + 4 * lg, mv);
+        if (has_b && lg == 0) {
+            opt_update(m, &bv, &ba, &bmm, gb);
+            m.b[row] = bv;
+            m.bacc[row] = ba;
+            if (adam) m.bm[row] = bmm;
+        }
     }
 }
 
@@ -3621,7 +3715,10 @@ void launch_owner_update(const ModelView& m, const ChunkPtrs& recv, int ndev, ui
     if (nrows == 0) return;
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((owner_update_kernel<DD>), dim3(grid_for_groups((long long)nrows, gpb)), dim3(256), 0, s, m, recv, ndev, slice_rows, row0, nrows);
+        const dim3 grid(grid_for_groups((long long)nrows, gpb));
+        if (ndev <= 4) hipLaunchKernelGGL((owner_update_kernel<DD, 4>), grid, dim3(256), 0, s, m, recv, ndev, slice_rows, row0, nrows);
+        else if (ndev <= 8) hipLaunchKernelGGL((owner_update_kernel<DD, 8>), grid, dim3(256), 0, s, m, recv, ndev, slice_rows, row0, nrows);
+        else hipLaunchKernelGGL((owner_update_kernel<DD, 16>), grid, dim3(256), 0, s, m, recv, ndev, slice_rows, row0, nrows);
     });
 }
 
@@ -3653,7 +3750,9 @@ void launch_owner_list_apply(const ModelView& m, const PeerLists& pl_in, const P
          * most 2 048 workgroups */
         int grid = grid_for_groups((long long)capacity, gpb);
         if (grid > 2048) grid = 2048;
-        hipLaunchKernelGGL((owner_list_apply_kernel<DD>), dim3(grid), dim3(256), 0, s, m, pl, mkeys_sorted);
+        if (ndev <= 4) hipLaunchKernelGGL((owner_list_apply_kernel<DD, 4>), dim3(grid), dim3(256), 0, s, m, pl, mkeys_sorted);
+        else if (ndev <= 8) hipLaunchKernelGGL((owner_list_apply_kernel<DD, 8>), dim3(grid), dim3(256), 0, s, m, pl, mkeys_sorted);
+        else hipLaunchKernelGGL((owner_list_apply_kernel<DD, 16>), dim3(grid), dim3(256), 0, s, m, pl, mkeys_sorted);
     });
 }
 

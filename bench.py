@@ -215,8 +215,9 @@ def cpu_baseline(args, model_kind=0, loss_kind=2):
         legs[name] = {"interactions_per_s": rows / secs, "interactions": rows, "seconds": secs, "workers": w}
     best = max(legs, key=lambda k: legs[k]["interactions_per_s"])  # the strongest leg of all, whatever its worker count
     out = {"value": legs[best]["interactions_per_s"], "unit": "interactions/s", "cores": legs[best]["workers"], "kind": "port", "mode": best,
-           "sample": f"{users} users of the same generator, {args.model}+{args.loss} dim {args.dim}, {args.items} items; {workers} worker threads on "
-                     f"ONE shared parameter set, one partition each (sequence_model.rs:90-102), one optimiser step per subsequence; "
+           "sample": f"{users} users of the same generator, {args.model}+{args.loss} dim {args.dim}, {args.items} items; {legs[best]['workers']} worker thread(s) (the fastest "
+                     f"of the legs timed with 1 .. {workers} workers) on ONE shared parameter set, one partition each (sequence_model.rs:90-102), one "
+                     f"optimiser step per subsequence; "
                      f"each leg bounded by {args.cpu_seconds:.0f} s of wall time; C oracle",
            "single_thread_value": legs["single_thread"]["interactions_per_s"], "host_cores_available": cores, "legs": legs}
     del m

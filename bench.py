@@ -1051,7 +1051,7 @@ def main():
             if traffic is None and args.traffic != "off":
                 traffic, traffic_lower = measured_traffic("warm", rows_per_launch, k_mean, d, args.items)
                 traffic_source = "profiles/score_kernel_traffic.json (PMC passes of the same command at this operating point; interval: profiles/r03_counter_calibration.md)" if traffic else None
-            kname = ("ewma_seq_kernel<D, WHOLE> (EWMA scan + gather + negative + loss + backward scan of a sequence in one pass; priced at "
+            kname = ("ewma_seq_kernel<D> (EWMA scan + gather + negative + loss + backward scan of a sequence in one pass; priced at "
                      "(2+k)4d + (1+k)4 + 12d per row: section 8d's gather + score bytes, h written, s_{t-1} read, dX written; sbr_kernels.hip)" if ewma_whole else
                      "ewma_seq_kernel (EWMA scan + gather + negative + loss in one pass per sequence; x_t replaces the h_t read, h_t is written "
                      "once on top of the priced bytes; sbr_kernels.hip)" if model_kind == 2 and loss_kind != 2 else

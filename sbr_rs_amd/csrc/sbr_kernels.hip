@@ -2732,7 +2732,7 @@ __global__ void clear_chunk_flags_kernel(void* buf, int nchunks, uint64_t S, int
 }
 
 // owner: contributions of the devices added in device order (first toucher initialises)
-template <int D>
+template <int D, int NQ>  // NQ: devices the row's requests are unrolled for (ndev <= NQ); flags first, then every touched contribution together
 __global__ __launch_bounds__(256) void owner_reduce_kernel(ChunkPtrs recv, int ndev, uint64_t S, void* own) {
     constexpr int L = D / 4;
     constexpr int GPW = 64 / L;
@@ -2741,25 +2741,40 @@ __global__ __launch_bounds__(256) void owner_reduce_kernel(ChunkPtrs recv, int n
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     float* out = reinterpret_cast<float*>(own);
     uint32_t* ofl = reinterpret_cast<uint32_t*>(out + S * D + S);
-    for (uint64_t i = wave * GPW + grp; i < S; i += nwaves * GPW) {
+    for (uint64_t i0 = wave * GPW; i0 < S; i0 += nwaves * GPW) {  // wave-uniform trip count
+        const uint64_t i = i0 + grp;
+        uint32_t f[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            f[q] = (q < ndev && i < S) ? reinterpret_cast<const uint32_t*>(reinterpret_cast<const float*>(recv.p[q]) + S * D + S)[i] : 0u;
+        float4 v[NQ];
+        float vb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float* c = reinterpret_cast<const float*>(recv.p[q]); /* device q's contribution to this owner's rows */
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vb[q] = 0.0f;
+            if (f[q] & 1u) v[q] = ld4(c + i * D + 4 * lg);
+            if (f[q] & 2u) vb[q] = c[S * D + i];
+        }
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         float gb = 0.0f;
         uint32_t fl = 0;
-        for (int q = 0; q < ndev; ++q) {
-            const float* c = reinterpret_cast<const float*>(recv.p[q]); /* device q's contribution to this owner's rows */
-            const uint32_t f = reinterpret_cast<const uint32_t*>(c + S * D + S)[i];
-            if (f & 1u) {
-                const float4 v = ld4(c + i * D + 4 * lg);
-                if (fl & 1u) { g.x = g.x + v.x; g.y = g.y + v.y; g.z = g.z + v.z; g.w = g.w + v.w; }
-                else g = v;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (f[q] & 1u) {
+                if (fl & 1u) { g.x = g.x + v[q].x; g.y = g.y + v[q].y; g.z = g.z + v[q].z; g.w = g.w + v[q].w; }
+                else g = v[q];
             }
-            if (f & 2u) gb = (fl & 2u) ? gb + c[S * D + i] : c[S * D + i];
-            fl |= f;
+            if (f[q] & 2u) gb = (fl & 2u) ? gb + vb[q] : vb[q];
+            fl |= f[q];
         }
-        if (fl & 1u) st4(out + i * D + 4 * lg, g);
-        if (lg == 0) {
-            if (fl & 2u) out[S * D + i] = gb;
-            ofl[i] = fl;
+        if (i < S) {
+            if (fl & 1u) st4(out + i * D + 4 * lg, g);
+            if (lg == 0) {
+                if (fl & 2u) out[S * D + i] = gb;
+                ofl[i] = fl;
+            }
         }
     }
 }
@@ -3707,7 +3722,10 @@ void launch_seg_scatter(const ModelView& m, const BlockView& blk, uint32_t rows_
 void launch_owner_reduce(const ModelView& m, const ChunkPtrs& recv, int ndev, uint64_t slice_rows, void* own, hipStream_t s) {
     DISPATCH_D(m.d, {
         const int gpb = 4 * (64 / (DD / 4));
-        hipLaunchKernelGGL((owner_reduce_kernel<DD>), dim3(grid_for_groups((long long)slice_rows, gpb)), dim3(256), 0, s, recv, ndev, slice_rows, own);
+        const dim3 grid(grid_for_groups((long long)slice_rows, gpb));
+        if (ndev <= 4) hipLaunchKernelGGL((owner_reduce_kernel<DD, 4>), grid, dim3(256), 0, s, recv, ndev, slice_rows, own);
+        else if (ndev <= 8) hipLaunchKernelGGL((owner_reduce_kernel<DD, 8>), grid, dim3(256), 0, s, recv, ndev, slice_rows, own);
+        else hipLaunchKernelGGL((owner_reduce_kernel<DD, 16>), grid, dim3(256), 0, s, recv, ndev, slice_rows, own);
     });
 }
 

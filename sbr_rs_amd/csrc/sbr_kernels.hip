@@ -2279,8 +2279,11 @@ struct EmitChunk {  // replicated multi-device: the row's sum goes into the owne
     __device__ __forceinline__ RowPrefetch pre(uint32_t, int) const { return RowPrefetch{}; }
     template <int D>
     __device__ __forceinline__ void row(uint32_t r, uint64_t, int lg, float4 g, bool has_b, float gb, RowPrefetch) const {
-        float* c = reinterpret_cast<float*>(send) + (r / S) * S * ((uint64_t)D + 2);
-        const uint64_t lr = r % S;
+        /* (S = ceil(num_items / num_devices) < 2^32: the owner and the row inside its slice by 32-bit division — the 64-bit one cost this
+         * kernel a third of its registers) */
+        const uint32_t S32 = (uint32_t)S, owner = r / S32;
+        float* c = reinterpret_cast<float*>(send) + (uint64_t)owner * S * ((uint64_t)D + 2);
+        const uint64_t lr = r - owner * S32;
         st4(c + lr * D + 4 * lg, g);
         if (lg == 0) {
             if (has_b) c[S * D + lr] = gb;

@@ -791,15 +791,17 @@ def main():
             loop.bufs = tuple(torch.zeros(n, dtype=torch.uint8, device="cuda") for n in (c, c, db))
 
     tp0 = time.perf_counter()
-    state = {"nmb": loop.begin_epoch(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0}
+    state = {"nmb": loop.begin_epoch(prefetch_next=True), "mb": 0, "reprepared_in_timed_region": 0, "epoch_switch_ms": 0.0}
     epoch_prepare_ms = 1e3 * (time.perf_counter() - tp0)
 
     def one_step(timed: bool) -> int:
         if state["mb"] >= state["nmb"]:
+            t_e = time.perf_counter()
             state["nmb"] = loop.begin_epoch(prefetch_next=True)  # epoch switch; the host packed it in the background
             state["mb"] = 0
             if timed:
                 state["reprepared_in_timed_region"] += 1
+                state["epoch_switch_ms"] += 1e3 * (time.perf_counter() - t_e)  # host time of the switch: waits for the packing thread if it is behind
         mb = state["mb"]
         rows = plan.minibatch_rows(mb)
         loop.step(mb)  # compute_local + (exchange: scatter, all-to-all, owner reduce, all-gather) + apply
@@ -1160,7 +1162,7 @@ def main():
             "collective_backend": (backend_note or (args.backend if args.backend == "gloo" else "nccl (RCCL)")) if dist is not None else None,
             "ms_per_step_per_rank": per_rank,
             "interactions_timed": rows_total, "epoch_prepares_in_timed_region": state["reprepared_in_timed_region"],
-            "epoch_prepare_ms": epoch_prepare_ms, "minibatches_per_epoch": state["nmb"],
+            "epoch_prepare_ms": epoch_prepare_ms, "epoch_switch_host_ms_in_timed_region": state["epoch_switch_ms"], "minibatches_per_epoch": state["nmb"],
             "gpu_prewarm": prewarm, "roofline": roofline, "step_bytes": step_bytes, "roofline_cold": cold, "roofline_mfma": mfma, "kernels": kernels, "kernels_standalone": kernels_sa,
             "kernels_source": ("HIP events on every family inside the timed region" if timers == "all" else
                                f"SCORE: HIP events inside the timed region; the other families: a second pass of {args.steps} steps of the same schedule "

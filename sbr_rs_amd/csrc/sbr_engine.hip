@@ -192,7 +192,7 @@ void draw_lstm_weights(sbr_xorshift* rng, int dl, int d, int ng, std::vector<flo
 }
 
 #ifndef SBR_PACK_THREADS
-#define SBR_PACK_THREADS 4 /* host threads that fill a large minibatch's packed index arrays (build_epoch) */
+#define SBR_PACK_THREADS 8 /* host threads that fill a large minibatch's packed index arrays (build_epoch) */
 #endif
 struct TimingPair { hipEvent_t a, b; int family; uint64_t launches; };
 
@@ -1422,7 +1422,12 @@ static sbr_status build_epoch(sbr_fit_plan* p, sbr_fit_plan::Epoch& e) {
                 }
             }
         };
-        const int nthreads = R > (1 << 18) ? SBR_PACK_THREADS : 1;
+        static const int pack_threads = [] {  /* at most half of the host's cores */
+            const unsigned hc = std::thread::hardware_concurrency();
+            const int half = hc >= 2 ? (int)(hc / 2) : 1;
+            return half < SBR_PACK_THREADS ? half : SBR_PACK_THREADS;
+        }();
+        const int nthreads = R > (1 << 18) ? pack_threads : 1;
         if (nthreads == 1) fill(0, Tm);
         else {
             std::vector<std::thread> workers;
